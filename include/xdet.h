@@ -1,0 +1,173 @@
+/*
+ * libxdet_hip.so -- C-ABI of the MI355X-native Light-Head R-CNN forward path.
+ *
+ * Every entry point replaces one interface of HiKapok/X-Detector's eval path
+ * (reference file:line cited per function).  Plain pointers and sizes only; all tensor
+ * pointers are DEVICE pointers unless the name ends in _host.  Every function returns
+ * 0 on success or a negative code (XDET_ERR_*); xdet_last_error() gives the message.
+ * Nothing here synchronises the stream unless stated; `stream` is a hipStream_t (NULL =
+ * default stream).  The caller owns every buffer; a net handle owns only its weights and
+ * a fixed workspace sized at xdet_net_build().
+ *
+ * Activation layout inside the library is NHWC with the channel count padded to a
+ * multiple of 32 ("ld"); the public PsRoiAlign op also accepts the reference's NCHW.
+ * Boxes are (ymin, xmin, ymax, xmax) normalised to [0,1]; ROIs to PsRoiAlign (cy,cx,h,w).
+ */
+#ifndef XDET_H_
+#define XDET_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XDET_OK 0
+#define XDET_ERR_INVALID_ARG (-1) /* the op's OP_REQUIRES -> InvalidArgument, ps_roi_align_op.cc:209-226 */
+#define XDET_ERR_HIP (-2)         /* HIP failure; reference: fprintf + exit(-1), ps_roi_align_op.cu:150-155 */
+#define XDET_ERR_STATE (-3)
+#define XDET_ERR_UNSUPPORTED (-4)
+
+const char* xdet_last_error(void);
+int xdet_version(void);
+int xdet_device_count(int* n);
+int xdet_set_device(int dev);
+
+/* ---- memory / streams (what TF's allocator and stream executor did for the op) ---------- */
+int xdet_malloc(void** dptr, size_t bytes);
+int xdet_free(void* dptr);
+int xdet_memset(void* dptr, int value, size_t bytes, void* stream);
+int xdet_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream);
+int xdet_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream);
+int xdet_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+int xdet_stream_create(void** stream);
+int xdet_stream_destroy(void* stream);
+int xdet_stream_sync(void* stream);
+/* hipEvent timing on `stream` (bench.py's roofline leg) */
+int xdet_event_create(void** ev);
+int xdet_event_destroy(void* ev);
+int xdet_event_record(void* ev, void* stream);
+int xdet_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms); /* syncs on ev_stop */
+
+/* ---- A9: PsRoiAlign forward --------------------------------------------------------------
+ * Replaces op_module.ps_roi_align(inputs, rois, grid_dim_width, grid_dim_height, pool_method)
+ * (light_head_rfcn_eval.py:143-155; REGISTER_OP ps_roi_align_op.cc:38-76; CPU functor
+ * :81-201; CUDA kernel ps_roi_align_op.cu:36-132).
+ *   feat   f32 [N,C,H,W] (feat_layout 0) or [N,H,W,ldc] (feat_layout 1, first C channels used)
+ *   rois   f32 [N,R,4] (cy,cx,h,w) -- or corner boxes when rois_are_corners != 0, in which case
+ *          _point2center (net/xception_body.py:215-218) is applied on the fly
+ *   pooled f32 [N,R,out_ld] (first C = gh*gw*bank entries per ROI, = [N,R,gh*gw,bank] when out_ld == C)
+ *   index  i32 same shape, may be NULL.  Degenerate ROI: pooled 0 and index 0.
+ * Errors: same argument checks as PSROIAlignOp::Compute (:209-226) -> XDET_ERR_INVALID_ARG. */
+int xdet_psroialign_fwd(const float* feat, const float* rois, float* pooled, int32_t* index, int N, int C, int H,
+                        int W, int R, int grid_w, int grid_h, int use_max, int feat_layout, int ldc, int out_ld,
+                        int rois_are_corners, void* stream);
+
+/* ---- layer objects: the tf.layers.* kernels the graph builders call ---------------------
+ * xdet_conv_create: tf.layers.conv2d / dense (+ folded inference BN / bias, + ReLU)
+ * (net/xception_body.py:243-265,381-400,450-475,540-558; net/resnet_v2.py:89-100).
+ *   kernel_hwio_host f32 [kh,kw,cin,cout]; scale_host/shift_host f32 [cout] (y = conv*scale+shift),
+ *   either may be NULL (1 / 0).  pad_mode 0 = VALID, 1 = SAME (TF rule), 2 = explicit pad_t/pad_l.
+ * xdet_conv_forward: in NHWC [N,H,W,ld_in] -> out NHWC [N,Ho,Wo,ld_out]; residual (may be NULL)
+ *   has the output shape.  ld_in must be round_up(cin,32) (4 when cin <= 4), ld_out = round_up(cout,32).
+ *   relu_in applies ReLU to the input on the fly (the `relu -> conv` edges of the graph). */
+int xdet_conv_create(void** layer, int kh, int kw, int cin, int cout, int stride, int dilation, int pad_mode,
+                     int pad_t, int pad_l, const float* kernel_hwio_host, const float* scale_host,
+                     const float* shift_host, int relu_out);
+int xdet_conv_forward(void* layer, const float* in, int N, int H, int W, int ld_in, float* out, int ld_out,
+                      const float* residual, int relu_in, void* stream);
+int xdet_conv_out_shape(void* layer, int H, int W, int* Ho, int* Wo);
+int xdet_layer_destroy(void* layer);
+/* depthwise 3x3 SAME stride 1 (the depthwise half of tf.layers.separable_conv2d,
+ * net/xception_body.py:224-231); dw_kernel_host f32 [3,3,C,1]; in/out NHWC with stride ld. */
+int xdet_depthwise_create(void** layer, int C, int dilation, const float* dw_kernel_host);
+int xdet_depthwise_forward(void* layer, const float* in, int N, int H, int W, int ld, float* out, int relu_in,
+                           void* stream);
+/* tf.layers.max_pooling2d(3,2,'same') + tf.add(residual) (net/xception_body.py:281-286) */
+int xdet_maxpool3x3s2_add(const float* in, const float* residual, float* out, int N, int H, int W, int C, int ld,
+                          void* stream);
+int xdet_nchw_to_nhwc4(const float* in_nchw, float* out_nhwc4, int N, int C, int H, int W, void* stream);
+
+/* ---- A4+A6: RPN glue + AnchorEncoder.decode_all_anchors ----------------------------------
+ * (light_head_rfcn_eval.py:389-397; preprocessing/anchor_manipulator.py:641-669,698-757)
+ *   rpn_out NHWC [N,Hh,Ww,ld]: cls logits at channels [cls_off, cls_off+2A), box deltas at
+ *   [box_off, box_off+4A); anchors_yx [Hh*Ww,2] centres, anchors_hw [A,2] sizes.
+ *   -> objectness [N,Hh*Ww*A], boxes [N,Hh*Ww*A,4] */
+int xdet_rpn_decode(const float* rpn_out, int ld, int cls_off, int box_off, int N, int Hh, int Ww, int A,
+                    const float* anchors_yx, const float* anchors_hw, float* objectness, float* boxes, void* stream);
+
+/* ---- A7: get_proposals (net/xception_body.py:402-448) ------------------------------------
+ *   objectness [N,n_anchor], boxes [N,n_anchor,4] -> rois [N,post_n,4]; workspace from
+ *   xdet_proposals_workspace_bytes().  counts_out (may be NULL) i32 [N,4] device:
+ *   {n_valid, n_candidates, n_kept_by_nms, 0}. */
+size_t xdet_proposals_workspace_bytes(int N, int n_anchor, int pre_n, int post_n);
+int xdet_get_proposals(const float* objectness, const float* boxes, int N, int n_anchor, int pre_n, int post_n,
+                       float nms_thr, float min_size, void* workspace, float* rois, int* counts_out, void* stream);
+
+/* ---- A11: AnchorEncoder.ext_decode_rois (anchor_manipulator.py:671-683) ------------------ */
+int xdet_ext_decode_rois(const float* rois, const float* reg, int ld_reg, int64_t n, float* out, void* stream);
+
+/* ---- A12: bboxes_eval detection part (light_head_rfcn_eval.py:263-287) -------------------
+ *   cls logits [N,R,ld_cls], boxes [N,R,4], image_shapes i32 [N,2] (H,W of the raw image),
+ *   bbox_img f32 [N,4] -> det_scores [N,num_classes-1,nms_topk], det_boxes [..,4], zero padded. */
+int xdet_bboxes_eval(const float* cls, int ld_cls, const float* boxes, int N, int R, int num_classes,
+                     const int* image_shapes, const float* bbox_img, int net_h, int net_w, float select_thr,
+                     float nms_thr, int nms_topk, float* det_scores, float* det_boxes, void* stream);
+
+/* ---- the model: lighr_head_model_fn in eval mode (light_head_rfcn_eval.py:364-433) -------
+ * Weights enter by TF variable name (scope prefix stripped), TF layouts (HWIO / [in,out]). */
+typedef struct {
+  int image_size;         /* train_image_size, 480 */
+  int max_batch;          /* workspace is sized for this many images per call */
+  int num_classes;        /* 21 */
+  int num_anchors;        /* 22 */
+  int rpn_pre_nms_top_n;  /* 5000 */
+  int rpn_post_nms_top_n; /* 1000 (300 in BASELINE config 3) */
+  float rpn_nms_thres;    /* 0.7 */
+  float rpn_min_size;     /* 16/480 */
+  float select_threshold; /* 0.01 */
+  float nms_threshold;    /* 0.3 */
+  int nms_topk;           /* 200 */
+  int grid;               /* 7 */
+  int bank;               /* 10 */
+} xdet_lighthead_config;
+
+int xdet_net_create(void** net, const xdet_lighthead_config* cfg);
+int xdet_net_set_weight(void* net, const char* name, const float* data_host, int ndim, const int64_t* dims);
+int xdet_net_build(void* net);     /* folds BN, transposes/pads weights, allocates the workspace */
+int xdet_net_destroy(void* net);
+/* named workspace buffers (views, owned by the net): "mid","out","rpn_out","feat","objectness",
+ * "rpn_boxes","proposals","pooled","fc","cls_reg","head_boxes","prop_counts" */
+int xdet_net_buffer(void* net, const char* name, void** dptr, int64_t dims[4], int* ld);
+/* stage entry points = the reference's graph-builder functions (net/xception_body.py) */
+int xdet_net_xception_body(void* net, const float* images_nchw, int N, void* stream);  /* :236 -> "mid","out" */
+int xdet_net_get_rpn(void* net, int N, void* stream);                                  /* :381 -> "rpn_out" */
+int xdet_net_large_sep(void* net, int N, void* stream);                                /* :450 -> "feat" */
+int xdet_net_rpn_decode(void* net, int N, void* stream);                               /* -> "objectness","rpn_boxes" */
+int xdet_net_get_proposals(void* net, int N, void* stream);                            /* :402 -> "proposals" */
+int xdet_net_get_head(void* net, int N, void* stream);                                 /* :477 -> "cls_reg" */
+int xdet_net_head_decode(void* net, int N, void* stream);                              /* -> "head_boxes" */
+int xdet_net_bboxes_eval(void* net, int N, const int* image_shapes, const float* bbox_img, float* det_scores,
+                         float* det_boxes, void* stream);
+/* whole forward: images f32 [N,3,S,S] -> det_scores [N,20,topk], det_boxes [N,20,topk,4].
+ * image_shapes / bbox_img may be NULL (S x S, [0,0,1,1]).  use_graph != 0 replays a hipGraph
+ * captured on first use for this N. */
+int xdet_net_forward(void* net, const float* images_nchw, int N, const int* image_shapes, const float* bbox_img,
+                     float* det_scores, float* det_boxes, int use_graph, void* stream);
+/* per-kernel accounting of the last build: total dense FLOPs (2*MAC, unpadded) of one image */
+int xdet_net_flops_per_image(void* net, double* backbone, double* rpn, double* large_sep, double* head);
+
+/* ---- A13: ResNet-50 v2 trunk (net/resnet_v2.py:311-345), BASELINE config 2 --------------- */
+int xdet_resnet_create(void** net, int image_size, int max_batch);
+int xdet_resnet_set_weight(void* net, const char* name, const float* data_host, int ndim, const int64_t* dims);
+int xdet_resnet_build(void* net);
+int xdet_resnet_forward(void* net, const float* images_nchw, int N, float* out_nhwc, void* stream);
+int xdet_resnet_out_shape(void* net, int* Ho, int* Wo, int* C);
+int xdet_resnet_flops_per_image(void* net, double* flops);
+int xdet_resnet_destroy(void* net);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XDET_H_ */

@@ -1,0 +1,122 @@
+"""Whole Light-Head R-CNN forward on the GPU vs the oracle on the same seeded 480x480 inputs
+(BASELINE config 3: 300 proposals).  north_star tolerance: boxes/scores within 1e-3."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+@pytest.fixture(scope='module')
+def run(oracle, lh_weights):
+    from xdet import weights as W
+    from xdet.model import LightHeadDetector
+    imgs = W.synthetic_images(2, 480, seed=0)
+    det = LightHeadDetector(lh_weights, image_size=480, max_batch=2, rpn_post_nms_top_n=300)
+    got = det.forward(imgs)
+    trace = {}
+    ref = oracle.lighthead_forward(imgs, lh_weights, rpn_post_nms_top_n=300, trace=trace)
+    return det, got, ref, trace, imgs
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max()))
+
+
+def test_dense_stages(run):
+    det, got, ref, tr, _ = run
+    n = 2
+    mid_x = det.buffer('mid_x', n).numpy()
+    assert rel_err(np.maximum(mid_x, 0), tr['mid']) < 1e-4
+    assert rel_err(det.buffer('out', n).numpy(), tr['out']) < 1e-4
+    rpn = det.buffer('rpn_out', n).numpy()
+    assert rel_err(rpn[..., :44], tr['rpn_cls']) < 1e-4
+    assert rel_err(rpn[..., 44:132], tr['rpn_box']) < 1e-4
+    assert rel_err(det.buffer('feat', n).numpy(), tr['feat']) < 1e-4
+    na = 30 * 30 * 22
+    assert np.abs(det.flat('objectness', (n, na)) - tr['objectness']).max() < 1e-4
+    assert np.abs(det.flat('rpn_boxes', (n, na, 4)) - tr['rpn_boxes']).max() < 1e-4
+
+
+def test_proposals_and_head(run):
+    det, got, ref, tr, _ = run
+    n = 2
+    props = det.flat('proposals', (n, 300, 4))
+    # same proposal set (order may differ only where two scores are within float noise)
+    for i in range(n):
+        a = props[i][np.lexsort(props[i].T)]
+        b = tr['proposals'][i][np.lexsort(tr['proposals'][i].T)]
+        assert np.abs(a - b).max() < TOL
+    if np.abs(props - tr['proposals']).max() < 1e-5:      # identical order -> compare the head row by row
+        cr = det.buffer('cls_reg', n).numpy().reshape(n, 300, -1)
+        assert np.abs(cr[..., :21] - tr['cls']).max() < 1e-3
+        assert np.abs(cr[..., 21:25] - tr['reg']).max() < 1e-3
+        assert np.abs(det.flat('head_boxes', (n, 300, 4)) - tr['head_boxes']).max() < TOL
+
+
+def match_detections(got, ref, tol=TOL):
+    """set matching per class: every oracle detection needs a distinct GPU detection whose score
+    and box agree within tol (two detections whose scores differ by float noise may legitimately
+    swap places in the score-ordered output)."""
+    total = matched = extra = 0
+    for c in ref:
+        gs, gb = got[c]
+        rs, rb = ref[c]
+        kg, kr = int((gs > 0).sum()), int((rs > 0).sum())
+        assert np.all(gs[kg:] == 0) and np.all(gb[kg:] == 0)            # zero padding
+        used = np.zeros(kg, bool)
+        for j in range(kr):
+            d = np.maximum(np.abs(gs[:kg] - rs[j]), np.abs(gb[:kg] - rb[j]).max(1)) if kg else np.array([])
+            d = np.where(used, np.inf, d)
+            if kg and d.min() < tol:
+                used[int(d.argmin())] = True
+                matched += 1
+        total += kr
+        extra += kg - int(used.sum())
+    return total, matched, extra
+
+
+def test_detections_within_1e3(run):
+    det, got, ref, tr, _ = run
+    total = matched = extra = 0
+    for i in range(2):
+        t, m, e = match_detections(got[i], ref[i])
+        total, matched, extra = total + t, matched + m, extra + e
+    print('detections: oracle %d, matched within 1e-3: %d, unmatched gpu: %d' % (total, matched, extra))
+    assert total > 100
+    assert matched == total and extra == 0, (matched, total, extra)
+
+
+def test_graph_replay_equals_eager(run):
+    det, got, _, _, imgs = run
+    det.set_images(imgs)
+    det.forward_device(2, use_graph=True)
+    s1, b1 = det.detections(2)
+    det.forward_device(2, use_graph=True)       # replay
+    s2, b2 = det.detections(2)
+    det.forward_device(2, use_graph=False)
+    s3, b3 = det.detections(2)
+    assert np.array_equal(s1, s2) and np.array_equal(b1, b2)
+    assert np.array_equal(s1, s3) and np.array_equal(b1, b3)
+
+
+def test_graph_builder_api_mirrors_reference(run, oracle, lh_weights):
+    """XceptionBody / get_rpn / large_sep_kernel / get_proposals / get_head with the reference's
+    signatures (net/xception_body.py:236,381,402,450,477), fed stage by stage."""
+    from xdet import model as M
+    det, _, _, tr, imgs = run
+    with det.scope():
+        mid, out = M.XceptionBody(imgs, 21, is_training=False, data_format='channels_first')
+        assert rel_err(mid.numpy(), tr['mid']) < 1e-4
+        cls, box = M.get_rpn(mid, 22, False, 'channels_first', 'rpn_head')
+        assert cls.shape[1:] == (30, 30, 44) and box.shape[1:] == (30, 30, 88)
+        assert rel_err(box.numpy(), tr['rpn_box']) < 1e-4
+        feat = M.large_sep_kernel(out, 256, 490, False, 'channels_first', 'large_sep_feature')
+        # feed the oracle's scores/boxes: the discrete stage must then agree exactly
+        props = M.get_proposals(tr['objectness'], tr['rpn_boxes'], None, 5000, 300, 0.7, 16. / 480, False,
+                                'channels_first')
+        assert np.array_equal(props, tr['proposals'])
+        c, r = M.get_head(tr['feat'], None, 7, 7, None, tr['proposals'], 21, False, False, 0, 'channels_first',
+                          'final_head')
+        assert np.abs(c - tr['cls']).max() < 2e-4 and np.abs(r - tr['reg']).max() < 2e-4

@@ -1,0 +1,90 @@
+"""Dense / window kernels on the GPU vs the oracle's restatement of the tf.layers semantics.
+Tolerance: exact-f32 MFMA differs from BLAS only by summation order -> 2e-5 of the output scale."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, tol=2e-5):
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, (err, scale)
+
+
+CONV_CASES = [
+    # (N, H, W, cin, cout, kh, kw, stride, padding, dilation)
+    (2, 30, 30, 728, 728, 1, 1, 1, 'SAME', 1),       # pointwise (block5-12)
+    (1, 61, 61, 64, 128, 1, 1, 2, 'SAME', 1),        # residual projection, stride 2, odd size
+    (1, 30, 30, 728, 512, 3, 3, 1, 'SAME', 1),       # RPN 3x3
+    (1, 41, 41, 3, 32, 3, 3, 2, 'VALID', 1),         # stem conv1 (small-cin path)
+    (1, 33, 33, 32, 64, 3, 3, 1, 'VALID', 1),        # stem conv2
+    (1, 30, 30, 96, 64, 15, 1, 1, 'SAME', 1),        # large-sep (15,1)
+    (1, 30, 30, 64, 490, 1, 15, 1, 'SAME', 1),       # large-sep (1,15), cout not a tile multiple
+    (1, 300, 1, 490, 2048, 1, 1, 1, 'VALID', 1),     # dense subnet_fc (rows = ROIs)
+    (1, 300, 1, 2048, 25, 1, 1, 1, 'VALID', 1),      # dense fc_cls+fc_loc (narrow N tile)
+    (3, 17, 19, 40, 44, 3, 3, 1, 'SAME', 2),         # dilation 2, ragged channel counts
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_matches_oracle(case, oracle):
+    from xdet.ops import Conv2D
+    from xdet.runtime import DeviceTensor
+    N, H, W, cin, cout, kh, kw, stride, padding, dil = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((N, H, W, cin)).astype(np.float32)
+    k = (rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.standard_normal(cout).astype(np.float32)
+    ref = oracle.conv2d(x, k, stride, padding, dil) * scale + shift
+    y = Conv2D(k, stride, padding, dil, scale, shift)(DeviceTensor.from_numpy(x)).numpy()
+    assert y.shape == ref.shape
+    close(y, ref)
+    # fused residual + ReLU, and ReLU applied to the input on load
+    res = rng.standard_normal(ref.shape).astype(np.float32)
+    ref2 = np.maximum(oracle.conv2d(np.maximum(x, 0), k, stride, padding, dil) * scale + shift + res, 0)
+    y2 = Conv2D(k, stride, padding, dil, scale, shift, relu=True)(DeviceTensor.from_numpy(x),
+                                                                   residual=DeviceTensor.from_numpy(res),
+                                                                   relu_in=True).numpy()
+    close(y2, ref2)
+
+
+def test_conv_explicit_padding_resnet_stem(oracle):
+    """conv2d_fixed_padding(7, stride 2): pad 3/3 then VALID (net/resnet_v2.py:89-100)."""
+    from xdet.ops import Conv2D
+    from xdet.runtime import DeviceTensor
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 64, 64, 3)).astype(np.float32)
+    k = (rng.standard_normal((7, 7, 3, 64)) / 12).astype(np.float32)
+    ref = oracle.conv2d(x, k, 2, ((3, 3), (3, 3)))
+    y = Conv2D(k, 2, 'EXPLICIT', explicit_pad=3)(DeviceTensor.from_numpy(x)).numpy()
+    assert y.shape == ref.shape == (2, 32, 32, 64)
+    close(y, ref)
+
+
+@pytest.mark.parametrize('dil,relu_in,C,H', [(1, False, 64, 37), (1, True, 728, 30), (2, False, 1024, 30), (2, True, 40, 9)])
+def test_depthwise_matches_oracle(dil, relu_in, C, H, oracle):
+    from xdet.ops import DepthwiseConv2D
+    from xdet.runtime import DeviceTensor
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, H, H + 3, C)).astype(np.float32)
+    k = rng.standard_normal((3, 3, C, 1)).astype(np.float32)
+    ref = oracle.depthwise_conv2d(np.maximum(x, 0) if relu_in else x, k, dil)
+    y = DepthwiseConv2D(k, dil)(DeviceTensor.from_numpy(x), relu_in=relu_in).numpy()
+    close(y, ref, 1e-6)
+
+
+@pytest.mark.parametrize('H,W', [(237, 237), (119, 119), (60, 60), (7, 10)])
+def test_maxpool_same_padding_asymmetry(H, W, oracle):
+    """TF SAME puts the odd padding pixel at the bottom/right: 60->30 pads 0/1, 237->119 pads 1/1."""
+    from xdet.ops import max_pool_3x3_s2_same_add
+    from xdet.runtime import DeviceTensor
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, H, W, 40)).astype(np.float32)
+    ref = oracle.max_pool_3x3_s2_same(x)
+    res = rng.standard_normal(ref.shape).astype(np.float32)
+    y = max_pool_3x3_s2_same_add(DeviceTensor.from_numpy(x), DeviceTensor.from_numpy(res)).numpy()
+    assert np.array_equal(y, ref + res)
+    y0 = max_pool_3x3_s2_same_add(DeviceTensor.from_numpy(x)).numpy()
+    assert np.array_equal(y0, ref)

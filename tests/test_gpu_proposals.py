@@ -1,0 +1,92 @@
+"""RPN tail on the GPU vs the oracle.  Given identical scores/boxes every discrete step
+(filter, top-k order, NMS keep set, upsample order) must match exactly."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def synth_rpn(rng, n, hw=30, A=22, spread=2.0):
+    cls = (rng.standard_normal((n, hw, hw, 2 * A)) * spread).astype(np.float32)
+    box = (rng.standard_normal((n, hw, hw, 4 * A)) * 0.4).astype(np.float32)
+    return cls, box
+
+
+def test_rpn_decode_matches_oracle(oracle):
+    from xdet import ops
+    rng = np.random.default_rng(0)
+    cls, box = synth_rpn(rng, 2)
+    anchors = oracle.layer_anchors((480, 480), (30, 30))
+    obj, boxes = ops.rpn_decode(cls, box, anchors)
+    ref_obj = oracle.softmax(cls.reshape(-1, 2))[:, -1].reshape(2, -1)
+    ref_boxes = oracle.decode_all_anchors(box.reshape(2, -1, 4), anchors)
+    assert np.abs(obj - ref_obj).max() <= 2e-7
+    assert np.abs(boxes - ref_boxes).max() <= 1e-6 * max(1.0, np.abs(ref_boxes).max())
+    # AnchorCreator mirror == oracle anchors
+    ac = ops.AnchorCreator([480, 480], [(30, 30)], [[0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]], [[0.1]], [[1., 2., .5]], [16])
+    (y, x, h, w), = ac.get_all_anchors()[0]
+    for a, b in zip((y, x, h, w), anchors):
+        assert np.array_equal(a, b)
+
+
+def _boxes_scores(rng, n, cnt, scale=0.25):
+    cy, cx = rng.uniform(-0.1, 1.1, (n, cnt)), rng.uniform(-0.1, 1.1, (n, cnt))
+    h, w = rng.uniform(0.0, scale, (n, cnt)) + 0.01, rng.uniform(0.0, scale, (n, cnt)) + 0.01
+    boxes = np.stack([cy - h / 2, cx - w / 2, cy + h / 2, cx + w / 2], -1).astype(np.float32)
+    scores = rng.uniform(0.001, 0.999, (n, cnt)).astype(np.float32)
+    return scores, boxes
+
+
+@pytest.mark.parametrize('n,cnt,pre,post,thr', [(2, 19800, 5000, 300, 0.7), (1, 19800, 5000, 1000, 0.7),
+                                                (3, 4000, 600, 100, 0.5), (1, 55000, 5000, 300, 0.7)])
+def test_get_proposals_exact(n, cnt, pre, post, thr, oracle):
+    from xdet import ops
+    rng = np.random.default_rng(cnt + post)
+    scores, boxes = _boxes_scores(rng, n, cnt)
+    scores[:, ::7] = scores[:, 3:4]            # many exact score ties -> index tie-break
+    rois, counts = ops.get_proposals(scores, boxes, None, pre, post, thr, 16. / 480, False, 'channels_first',
+                                     return_counts=True)
+    traces = []
+    ref = oracle.get_proposals(scores, boxes, pre, post, thr, 16. / 480, traces)
+    for i in range(n):
+        assert counts[i, 1] == traces[i]['n_cand']
+        assert counts[i, 2] == min(traces[i]['n_keep'], post)
+    assert np.array_equal(rois, ref)
+
+
+def test_get_proposals_few_and_none(oracle):
+    """fewer survivors than post_n -> tiled upsample; none -> the [.2,.2,.8,.8] fallback (:196-213)."""
+    from xdet import ops
+    rng = np.random.default_rng(1)
+    scores, boxes = _boxes_scores(rng, 2, 500)
+    boxes[0, 40:] = [0.5, 0.5, 0.5, 0.5]        # zero-size -> filtered; image 0 keeps <= 40 candidates
+    boxes[1, :] = [0.3, 0.3, 0.3001, 0.3001]    # all below rpn_min_size -> nothing survives
+    rois, counts = ops.get_proposals(scores, boxes, None, 300, 64, 0.7, 16. / 480, False, 'channels_first',
+                                     return_counts=True)
+    ref = oracle.get_proposals(scores, boxes, 300, 64, 0.7, 16. / 480)
+    assert 0 < counts[0, 2] < 64 and counts[1, 2] == 0
+    assert np.array_equal(rois, ref)
+    assert np.all(rois[1] == np.array([.2, .2, .8, .8], np.float32))
+
+
+def test_ext_decode_and_bboxes_eval(oracle):
+    from xdet import ops
+    rng = np.random.default_rng(2)
+    R = 300
+    _, rois = _boxes_scores(rng, 1, R, 0.5)
+    rois = oracle.bboxes_clip([0, 0, 1, 1], rois[0])
+    reg = (rng.standard_normal((R, 4)) * 0.2).astype(np.float32)
+    dec = ops.ext_decode_rois(rois, reg)
+    ref_dec = oracle.ext_decode_rois(rois, reg)
+    assert np.abs(dec - ref_dec).max() <= 1e-6
+    logits = (rng.standard_normal((R, 21)) * 3).astype(np.float32)
+    for shape in ((480, 480), (333, 500)):
+        got = ops.bboxes_eval(logits, ref_dec, shape)
+        ref = oracle.bboxes_eval(logits, ref_dec, shape)
+        for c in range(1, 21):
+            gs, gb = got[c]
+            rs, rb = ref[c]
+            assert gs.shape == (200,) and gb.shape == (200, 4)
+            assert (gs > 0).sum() == (rs > 0).sum(), c
+            assert np.abs(gs - rs).max() <= 1e-6
+            assert np.abs(gb - rb).max() <= 1e-6

@@ -1,0 +1,82 @@
+"""PsRoiAlign on the GPU through the C-ABI vs the oracle: bit-exact values AND indices."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# known-answer vectors for the reference's own test inputs (cpp/PSROIPooling/test_op.py:52-81),
+# as recorded in SURVEY.md 8c
+KAT_ROIS = np.array([[[0.2, 0.2, 0.7, 0.7], [0.5, 0.5, 0.9, 0.9], [0.9, 0.9, 1., 1.]]], np.float32)
+KAT = {
+    'mean': ([[5.125, 6.5, 12., 13.375], [9.25, 11.375, 19.875, 22.], [17.5, 18.6875, 23.4375, 24.625]], [0, 0, 0]),
+    'max': ([[7.1875, 8.5625, 14.0625, 15.4375], [13.75, 15.625, 23.125, 25.], [19.75, 20.625, 24.125, 25.]], [3, 8, 3]),
+}
+
+
+def kat_input():
+    plane = np.arange(1, 26, dtype=np.float32).reshape(5, 5)
+    return np.tile(plane, (1, 16, 1, 1)).astype(np.float32)
+
+
+@pytest.mark.parametrize('method', ['mean', 'max'])
+def test_reference_test_op_inputs(method, oracle):
+    import xdet
+    p, i = xdet.ps_roi_align(kat_input(), KAT_ROIS, 2, 2, method)
+    assert p.shape == (1, 3, 4, 4) and i.shape == (1, 3, 4, 4) and i.dtype == np.int32
+    vals, idx = KAT[method]
+    for r in range(3):
+        for b in range(4):
+            assert np.all(p[0, r, b] == np.float32(vals[r][b]))
+        assert np.all(i[0, r] == idx[r])
+    po, io = oracle.ps_roi_align(kat_input(), KAT_ROIS, 2, 2, method)
+    assert np.array_equal(p, po) and np.array_equal(i, io)
+
+
+def random_rois(rng, n, r):
+    cy, cx = rng.uniform(0.02, 0.98, (n, r)), rng.uniform(0.02, 0.98, (n, r))
+    h, w = rng.uniform(0.01, 1.0, (n, r)), rng.uniform(0.01, 1.0, (n, r))
+    rois = np.stack([cy, cx, h, w], -1).astype(np.float32)
+    # edge cases: full image, 1-pixel, image border, the fallback box, degenerate (zero h / w)
+    rois[:, 0] = [0.5, 0.5, 1.0, 1.0]
+    rois[:, 1] = [0.5, 0.5, 1. / 30, 1. / 30]
+    rois[:, 2] = [0.0, 0.0, 0.3, 0.3]
+    rois[:, 3] = [1.0, 1.0, 0.2, 0.2]
+    rois[:, 4] = [0.5, 0.5, 0.6, 0.6]
+    rois[:, 5] = [0.5, 0.5, 0.0, 0.4]
+    rois[:, 6] = [0.5, 0.5, 0.4, 0.0]
+    rois[:, 7] = [0.999, 0.001, 0.001, 0.001]
+    return rois
+
+
+@pytest.mark.parametrize('method', ['max', 'mean'])
+@pytest.mark.parametrize('shape', [(1, 490, 30, 30, 300, 7), (2, 490, 30, 30, 1000, 7), (1, 36, 50, 50, 64, 3),
+                                   (3, 16, 5, 7, 9, 2)])
+def test_random_bit_exact(method, shape, oracle):
+    import xdet
+    n, c, h, w, r, g = shape
+    rng = np.random.default_rng(7)
+    feat = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    rois = random_rois(rng, n, max(r, 8))[:, :r]
+    p, i = xdet.ps_roi_align(feat, rois, g, g, method)
+    po, io = oracle.ps_roi_align(feat, rois, g, g, method)
+    assert np.array_equal(p, po)
+    assert np.array_equal(i, io)
+
+
+def test_empty_and_errors():
+    import xdet
+    feat = np.zeros((1, 8, 4, 4), np.float32)
+    p, i = xdet.ps_roi_align(feat, np.zeros((1, 0, 4), np.float32), 2, 2, 'max')
+    assert p.shape == (1, 0, 4, 2)
+    with pytest.raises(xdet.InvalidArgumentError):
+        xdet.ps_roi_align(feat[0], np.zeros((1, 2, 4), np.float32), 2, 2, 'max')          # rank-4 NCHW
+    with pytest.raises(xdet.InvalidArgumentError):
+        xdet.ps_roi_align(feat, np.zeros((1, 2, 5), np.float32), 2, 2, 'max')             # last dim 4
+    with pytest.raises(xdet.InvalidArgumentError):
+        xdet.ps_roi_align(feat, np.zeros((2, 2, 4), np.float32), 2, 2, 'max')             # batch mismatch
+    with pytest.raises(xdet.InvalidArgumentError):
+        xdet.ps_roi_align(feat, np.zeros((1, 2, 4), np.float32), 2, 2, 'median')          # pool_method
+    with pytest.raises(xdet.InvalidArgumentError):
+        xdet.ps_roi_align(feat, np.zeros((1, 2, 4), np.float32), -1, 2, 'max')            # grid >= 0
+    with pytest.raises(xdet.InvalidArgumentError):
+        xdet.ps_roi_align(feat, np.zeros((1, 2, 4), np.float32), 3, 1, 'max')             # C % grid

@@ -1,0 +1,97 @@
+// Shared host-side helpers for libxdet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/xdet.h"   // XDET_OK / XDET_ERR_* codes
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+namespace xdet {
+
+void set_last_error(const std::string& s);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define XDET_HIP(expr)                                                          \
+  do {                                                                          \
+    hipError_t _e = (expr);                                                     \
+    if (_e != hipSuccess) return ::xdet::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+#define XDET_LAUNCH_CHECK() XDET_HIP(hipGetLastError())
+
+#define XDET_REQUIRE(cond, msg)                                   \
+  do {                                                            \
+    if (!(cond)) {                                                \
+      ::xdet::set_last_error(std::string("invalid argument: ") + (msg)); \
+      return XDET_ERR_INVALID_ARG;                        \
+    }                                                             \
+  } while (0)
+
+#define XDET_TRY(expr)            \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc != 0) return _rc;     \
+  } while (0)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- implicit-GEMM convolution on the f32 MFMA pipe (conv_mfma.hip) -------------------
+struct ConvParams {
+  const float* in;   // NHWC, channel stride ldi (padded channels are zero)
+  const float* wt;   // [Cout_pad][Kp], K contiguous, k = tap*Cin_p + ci
+  float* out;        // NHWC, channel stride ldo
+  const float* scale;   // [Cout_pad] folded BN scale (1 for plain bias)
+  const float* shift;   // [Cout_pad] folded BN shift / bias
+  const float* res;     // optional residual, same N,Ho,Wo, channel stride ldr
+  int N, H, W, ldi;
+  int Ho, Wo, ldo, ldr;
+  int Cin_p;         // channels walked per tap (multiple of 32; 4 in small-cin mode)
+  int Kp;            // padded reduction length (multiple of 32)
+  int Cout_pad;      // multiple of the N tile
+  int KH, KW, stride, dil, pad_t, pad_l;
+  int M;             // N*Ho*Wo
+  int relu_in, relu_out;
+};
+int launch_conv_mfma_f32(const ConvParams& p, bool small_cin, int n_tile, hipStream_t s);
+
+// ---- element-wise / window kernels (elementwise.hip) ---------------------------------
+int launch_nchw_to_nhwc4(const float* in, float* out, int N, int C, int H, int W, int ldo, hipStream_t s);
+int launch_depthwise3x3(const float* in, const float* w9c, float* out, int N, int H, int W, int C, int ld,
+                        int dil, int relu_in, hipStream_t s);
+int launch_maxpool3x3s2_add(const float* in, const float* res, float* out, int N, int H, int W, int C, int ld,
+                            int Ho, int Wo, int pad_t, int pad_l, hipStream_t s);
+int launch_relu_copy(const float* in, float* out, int64_t n, hipStream_t s);
+
+// ---- PsRoiAlign (psroialign.hip) -------------------------------------------------------
+int launch_psroialign(const float* feat, const float* rois, float* pooled, int32_t* index, int N, int C, int H,
+                      int W, int R, int gw, int gh, int use_max, int layout, int ldc, int out_ld,
+                      int rois_are_corners, hipStream_t s);
+
+// ---- RPN tail / proposals (proposals.hip) ----------------------------------------------
+struct ProposalWorkspace {
+  // all per image, sized for n_anchor / pre_n
+  unsigned long long* keys;   // [N][n_anchor]
+  float* cboxes;              // [N][n_anchor][4] clipped boxes
+  int* ranks;                 // [N][n_anchor]
+  int* counts;                // [N][4]: n_valid, n_cand, n_keep, pad
+  float* sboxes;              // [N][pre_n][4]
+  float* sscores;             // [N][pre_n]
+  unsigned long long* mask;   // [N][pre_n][W64]
+  int* kept;                  // [N][post_n]
+};
+size_t proposal_workspace_bytes(int N, int n_anchor, int pre_n, int post_n);
+void proposal_workspace_carve(void* base, int N, int n_anchor, int pre_n, int post_n, ProposalWorkspace* ws);
+int launch_rpn_decode(const float* rpn_out, int ld, int cls_off, int box_off, int N, int Hh, int Ww, int A,
+                      const float* anchors_yx, const float* anchors_hw, float* objectness, float* boxes,
+                      hipStream_t s);
+int launch_get_proposals(const float* objectness, const float* boxes, int N, int n_anchor, int pre_n, int post_n,
+                         float nms_thr, float min_size, const ProposalWorkspace& ws, float* rois, hipStream_t s);
+
+// ---- detection post-processing (detect.hip) --------------------------------------------
+int launch_ext_decode_rois(const float* rois, const float* reg, int ld_reg, int64_t n, float* out, hipStream_t s);
+int launch_bboxes_eval(const float* cls, int ld_cls, const float* boxes, int N, int R, int num_classes,
+                       const int* image_shapes, const float* bbox_img, int net_h, int net_w, float select_thr,
+                       float nms_thr, int nms_topk, float* det_scores, float* det_boxes, hipStream_t s);
+
+}  // namespace xdet

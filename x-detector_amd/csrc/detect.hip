@@ -1,0 +1,216 @@
+// Detection post-processing on the GPU (the reference pins it to /device:CPU:0,
+// light_head_rfcn_eval.py:273).
+//
+//   ext_decode_rois  A11  preprocessing/anchor_manipulator.py:671-683
+//   bboxes_eval      A12  light_head_rfcn_eval.py:263-287 -> utility/eval_helper.py:
+//                         tf_bboxes_select (:556-625) -> bboxes_clip (:365-404) -> filter_boxes
+//                         (:278-317) -> bboxes_resize (:423-447) -> bboxes_sort (:333-361)
+//                         -> bboxes_nms_batch (:449-506)
+//
+// One workgroup per (image, class): softmax column, mask, clip, filter, rank-sort (top 2*topk),
+// bitmask NMS and the ordered scan all stay in LDS; output is the reference's zero-padded
+// per-class (scores[topk], boxes[topk,4]).
+#include "common.h"
+
+namespace xdet {
+
+typedef unsigned long long u64;
+
+__global__ void ext_decode_rois_kernel(const float* __restrict__ rois, const float* __restrict__ reg, int ld_reg,
+                                       int64_t n, float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 r = *reinterpret_cast<const float4*>(rois + i * 4);
+    const float* p = reg + i * ld_reg;
+    const float href = r.z - r.x, wref = r.w - r.y;
+    const float yref = r.x + href / 2.f, xref = r.y + wref / 2.f;
+    const float ph = expf(p[2]) * href;
+    const float pw = expf(p[3]) * wref;
+    const float pcy = p[0] * href + yref;
+    const float pcx = p[1] * wref + xref;
+    *reinterpret_cast<float4*>(out + i * 4) =
+        make_float4(pcy - ph / 2.f, pcx - pw / 2.f, pcy + ph / 2.f, pcx + pw / 2.f);
+  }
+}
+
+int launch_ext_decode_rois(const float* rois, const float* reg, int ld_reg, int64_t n, float* out, hipStream_t s) {
+  if (n == 0) return XDET_OK;
+  hipLaunchKernelGGL(ext_decode_rois_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 2048)), dim3(256), 0, s,
+                     rois, reg, ld_reg, n, out);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
+__device__ __forceinline__ bool iou_gt_d(const float4 a, const float4 b, float thr) {
+  const float ay0 = fminf(a.x, a.z), ay1 = fmaxf(a.x, a.z), ax0 = fminf(a.y, a.w), ax1 = fmaxf(a.y, a.w);
+  const float by0 = fminf(b.x, b.z), by1 = fmaxf(b.x, b.z), bx0 = fminf(b.y, b.w), bx1 = fmaxf(b.y, b.w);
+  const float aa = (ay1 - ay0) * (ax1 - ax0);
+  const float ab = (by1 - by0) * (bx1 - bx0);
+  if (aa <= 0.f || ab <= 0.f) return false;
+  const float ih = fmaxf(fminf(ay1, by1) - fmaxf(ay0, by0), 0.f);
+  const float iw = fmaxf(fminf(ax1, bx1) - fmaxf(ax0, bx0), 0.f);
+  const float inter = ih * iw;
+  return inter / ((aa + ab) - inter) > thr;
+}
+
+__device__ __forceinline__ u64 shfl_u64d(u64 v, int src) {
+  const unsigned lo = __shfl((unsigned)v, src), hi = __shfl((unsigned)(v >> 32), src);
+  return ((u64)hi << 32) | lo;
+}
+
+constexpr int EV_MAXR = 1024;   // ROIs per image supported by one workgroup
+constexpr int EV_MAXS = 512;    // 2*nms_topk upper bound (sorted candidates)
+constexpr int EV_W = EV_MAXS / 64;
+
+// grid (num_classes-1, N), 256 threads
+__global__ __launch_bounds__(256) void bboxes_eval_kernel(const float* __restrict__ cls, int ld_cls,
+                                                          const float* __restrict__ boxes, int R, int num_classes,
+                                                          const int* __restrict__ image_shapes,
+                                                          const float* __restrict__ bbox_img, int net_h, int net_w,
+                                                          float select_thr, float nms_thr, int nms_topk,
+                                                          float* __restrict__ det_scores,
+                                                          float* __restrict__ det_boxes) {
+  __shared__ u64 keys[EV_MAXR];
+  __shared__ float4 bx[EV_MAXR];
+  __shared__ float4 sbox[EV_MAXS];
+  __shared__ float sscore[EV_MAXS];
+  __shared__ u64 mask[EV_MAXS * EV_W];
+  __shared__ int s_nvalid;
+  __shared__ int s_keptidx[EV_MAXS];
+  __shared__ int s_nkeep;
+
+  const int c = blockIdx.x + 1;
+  const int n = blockIdx.y;
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_nvalid = 0; s_nkeep = 0; }
+  __syncthreads();
+
+  const float4 ref = *reinterpret_cast<const float4*>(bbox_img + n * 4);
+  // eval_helper.filter_boxes :296  min_size = max(1e-4, ratio*sqrt(H*W / (net_h*net_w)))
+  const float area = (float)((long long)image_shapes[n * 2] * (long long)image_shapes[n * 2 + 1]);
+  const float min_size = fmaxf(0.0001f, 0.03f * sqrtf(area / (float)(net_h * net_w)));
+  const float sx = ref.z - ref.x, sy = ref.w - ref.y;   // bboxes_resize scale (h, w)
+
+  int local_valid = 0;
+  for (int r = tid; r < R; r += 256) {
+    const float* lg = cls + ((int64_t)n * R + r) * ld_cls;
+    float m = lg[0];
+    for (int k = 1; k < num_classes; ++k) m = fmaxf(m, lg[k]);
+    float sum = 0.f, ec = 0.f;
+    for (int k = 0; k < num_classes; ++k) {
+      const float e = expf(lg[k] - m);
+      sum += e;
+      if (k == c) ec = e;
+    }
+    float s = ec / sum;
+    const float fmask = s > select_thr ? 1.f : 0.f;          // tf_bboxes_select_layer :581-585
+    s = s * fmask;
+    float4 b = *reinterpret_cast<const float4*>(boxes + ((int64_t)n * R + r) * 4);
+    b.x *= fmask; b.y *= fmask; b.z *= fmask; b.w *= fmask;
+    // bboxes_clip(bbox_img, .)
+    float ymin = fmaxf(b.x, ref.x), xmin = fmaxf(b.y, ref.y);
+    const float ymax = fminf(b.z, ref.z), xmax = fminf(b.w, ref.w);
+    ymin = fminf(ymin, ymax);
+    xmin = fminf(xmin, xmax);
+    // filter_boxes
+    const float ws = xmax - xmin, hs = ymax - ymin;
+    const float xc = xmin + ws / 2.f, yc = ymin + hs / 2.f;
+    // zero-score survivors only ever act as zero padding downstream -> drop them here
+    const bool valid = ws > min_size && hs > min_size && xc > 0.f && yc > 0.f && xc < 1.f && yc < 1.f && s > 0.f;
+    // bboxes_resize
+    bx[r] = make_float4((ymin - ref.x) / sx, (xmin - ref.y) / sy, (ymax - ref.x) / sx, (xmax - ref.y) / sy);
+    keys[r] = valid ? (((u64)__float_as_uint(s) << 32) | (u64)(0xFFFFFFFFu - (unsigned)r)) : 0ull;
+    local_valid += valid;
+  }
+  if (local_valid) atomicAdd(&s_nvalid, local_valid);
+  __syncthreads();
+
+  const int max_sorted = min(2 * nms_topk, EV_MAXS);
+  const int n_sorted = min(s_nvalid, max_sorted);            // bboxes_sort: top_k(min(n, 2*topk))
+  // rank sort (descending score, ties -> lower ROI index)
+  for (int r = tid; r < R; r += 256) {
+    const u64 mine = keys[r];
+    if (mine == 0ull) continue;
+    int rank = 0;
+    for (int j = 0; j < R; ++j) rank += keys[j] > mine;
+    if (rank < max_sorted) {
+      sbox[rank] = bx[r];
+      sscore[rank] = __uint_as_float((unsigned)(mine >> 32));
+    }
+  }
+  __syncthreads();
+
+  // NMS bitmask: bit (i,j) for j > i
+  const int w64 = (n_sorted + 63) / 64;
+  for (int t = tid; t < n_sorted * w64; t += 256) {
+    const int i = t / w64, wq = t - i * w64;
+    u64 bits = 0ull;
+    const float4 me = sbox[i];
+    const int jend = min(64, n_sorted - wq * 64);
+    for (int j = 0; j < jend; ++j) {
+      const int col = wq * 64 + j;
+      if (col > i && iou_gt_d(me, sbox[col], nms_thr)) bits |= 1ull << j;
+    }
+    mask[i * EV_W + wq] = bits;
+  }
+  __syncthreads();
+
+  // ordered scan by wave 0 (lane q < EV_W holds removed word q)
+  if (tid < 64) {
+    const int lane = tid;
+    u64 removed = 0ull;
+    int n_keep = 0;
+    for (int cch = 0; cch < w64 && n_keep < nms_topk; ++cch) {
+      const int i = cch * 64 + lane;
+      const u64 diag = i < n_sorted ? mask[i * EV_W + cch] : 0ull;
+      u64 cur = shfl_u64d(removed, cch);
+      const int lim = min(64, n_sorted - cch * 64);
+      u64 keepmask = 0ull;
+      int kc = n_keep;
+      for (int b = 0; b < lim && kc < nms_topk; ++b) {
+        const u64 d = shfl_u64d(diag, b);
+        if (!((cur >> b) & 1ull)) { keepmask |= 1ull << b; cur |= d; ++kc; }
+      }
+      if ((keepmask >> lane) & 1ull) s_keptidx[n_keep + __popcll(keepmask & ((1ull << lane) - 1ull))] = i;
+      n_keep = kc;
+      u64 km = keepmask;
+      while (km) {
+        const int b = __ffsll((long long)km) - 1;
+        km &= km - 1ull;
+        if (lane < EV_W) removed |= mask[(cch * 64 + b) * EV_W + lane];
+      }
+    }
+    if (lane == 0) s_nkeep = n_keep;
+  }
+  __syncthreads();
+
+  const int n_keep = s_nkeep;
+  float* os = det_scores + ((int64_t)n * (num_classes - 1) + (c - 1)) * nms_topk;
+  float* ob = det_boxes + ((int64_t)n * (num_classes - 1) + (c - 1)) * nms_topk * 4;
+  for (int k = tid; k < nms_topk; k += 256) {
+    float s = 0.f;
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < n_keep) {
+      const int src = s_keptidx[k];
+      s = sscore[src];
+      b = sbox[src];
+    }
+    os[k] = s;
+    *reinterpret_cast<float4*>(ob + k * 4) = b;
+  }
+}
+
+int launch_bboxes_eval(const float* cls, int ld_cls, const float* boxes, int N, int R, int num_classes,
+                       const int* image_shapes, const float* bbox_img, int net_h, int net_w, float select_thr,
+                       float nms_thr, int nms_topk, float* det_scores, float* det_boxes, hipStream_t s) {
+  XDET_REQUIRE(R > 0 && R <= EV_MAXR, "bboxes_eval: 1 <= rois per image <= 1024");
+  XDET_REQUIRE(nms_topk > 0 && 2 * nms_topk <= EV_MAXS, "bboxes_eval: nms_topk must be in 1..256");
+  XDET_REQUIRE(num_classes >= 2 && num_classes <= ld_cls, "bboxes_eval: bad num_classes");
+  if (N == 0) return XDET_OK;
+  hipLaunchKernelGGL(bboxes_eval_kernel, dim3(num_classes - 1, N), dim3(256), 0, s, cls, ld_cls, boxes, R,
+                     num_classes, image_shapes, bbox_img, net_h, net_w, select_thr, nms_thr, nms_topk, det_scores,
+                     det_boxes);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
+}  // namespace xdet

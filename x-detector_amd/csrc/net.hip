@@ -1,0 +1,927 @@
+// Host side of libxdet_hip.so: layer objects, the Light-Head R-CNN eval graph
+// (lighr_head_model_fn, light_head_rfcn_eval.py:364-433) and the ResNet-50 v2 trunk
+// (net/resnet_v2.py:311-345) as static launch plans over the kernels in this directory,
+// plus the C-ABI of include/xdet.h.
+#include "common.h"
+#include "../../include/xdet.h"
+
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+namespace xdet {
+
+// ---------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& s) { g_last_error = s; }
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+  g_last_error = buf;
+  return XDET_ERR_HIP;
+}
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+struct HostTensor {
+  std::vector<float> v;
+  std::vector<int64_t> dims;
+};
+typedef std::map<std::string, HostTensor> WeightMap;
+
+static int upload(const std::vector<float>& h, float** d) {
+  XDET_HIP(hipMalloc(reinterpret_cast<void**>(d), std::max<size_t>(h.size(), 1) * sizeof(float)));
+  XDET_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  return XDET_OK;
+}
+
+static void same_pad(int n, int k, int s, int d, int* before, int* out) {
+  const int k_eff = (k - 1) * d + 1;
+  *out = (n + s - 1) / s;
+  const int total = std::max((*out - 1) * s + k_eff - n, 0);
+  *before = total / 2;   // the extra pixel goes to the bottom / right (TF SAME rule)
+}
+
+// ---------------------------------------------------------------------------------------
+// layer objects
+// ---------------------------------------------------------------------------------------
+struct LayerBase {
+  virtual ~LayerBase() {}
+  int kind = 0;   // 1 conv, 2 depthwise
+};
+
+struct ConvLayer : LayerBase {
+  int kh, kw, cin, cout, stride, dil, pad_mode, pad_t, pad_l, relu_out;
+  int cin_p, kp, cout_pad, n_tile;
+  bool small_cin;
+  float *d_wt = nullptr, *d_scale = nullptr, *d_shift = nullptr;
+
+  ~ConvLayer() override {
+    if (d_wt) (void)hipFree(d_wt);
+    if (d_scale) (void)hipFree(d_scale);
+    if (d_shift) (void)hipFree(d_shift);
+  }
+
+  int init(int kh_, int kw_, int cin_, int cout_, int stride_, int dil_, int pad_mode_, int pad_t_, int pad_l_,
+           const float* w_hwio, const float* scale, const float* shift, int relu_out_) {
+    XDET_REQUIRE(kh_ > 0 && kw_ > 0 && cin_ > 0 && cout_ > 0 && stride_ > 0 && dil_ > 0, "conv: bad geometry");
+    XDET_REQUIRE(pad_mode_ >= 0 && pad_mode_ <= 2, "conv: pad_mode must be 0|1|2");
+    XDET_REQUIRE(w_hwio != nullptr, "conv: kernel is NULL");
+    kind = 1;
+    kh = kh_; kw = kw_; cin = cin_; cout = cout_; stride = stride_; dil = dil_;
+    pad_mode = pad_mode_; pad_t = pad_t_; pad_l = pad_l_; relu_out = relu_out_;
+    small_cin = cin <= 4;
+    cin_p = small_cin ? 4 : round_up(cin, 32);
+    kp = round_up(kh * kw * cin_p, 32);
+    n_tile = round_up(cout, 64) < round_up(cout, 128) ? 64 : 128;
+    cout_pad = round_up(cout, n_tile);
+    std::vector<float> wt((size_t)cout_pad * kp, 0.f), sc(cout_pad, 0.f), sh(cout_pad, 0.f);
+    for (int t = 0; t < kh * kw; ++t)
+      for (int ci = 0; ci < cin; ++ci) {
+        const float* src = w_hwio + ((size_t)t * cin + ci) * cout;
+        for (int co = 0; co < cout; ++co) wt[(size_t)co * kp + (size_t)t * cin_p + ci] = src[co];
+      }
+    for (int co = 0; co < cout; ++co) {
+      sc[co] = scale ? scale[co] : 1.f;
+      sh[co] = shift ? shift[co] : 0.f;
+    }
+    XDET_TRY(upload(wt, &d_wt));
+    XDET_TRY(upload(sc, &d_scale));
+    XDET_TRY(upload(sh, &d_shift));
+    return XDET_OK;
+  }
+
+  void out_shape(int H, int W, int* Ho, int* Wo, int* pt, int* pl) const {
+    if (pad_mode == 1) {
+      same_pad(H, kh, stride, dil, pt, Ho);
+      same_pad(W, kw, stride, dil, pl, Wo);
+    } else {
+      *pt = pad_mode == 2 ? pad_t : 0;
+      *pl = pad_mode == 2 ? pad_l : 0;
+      // explicit padding is symmetric-or-trailing as in resnet_v2.fixed_padding: total = k-1
+      const int tot_h = pad_mode == 2 ? (kh - 1) * dil : 0, tot_w = pad_mode == 2 ? (kw - 1) * dil : 0;
+      *Ho = (H + tot_h - ((kh - 1) * dil + 1)) / stride + 1;
+      *Wo = (W + tot_w - ((kw - 1) * dil + 1)) / stride + 1;
+    }
+  }
+  int ld_in() const { return small_cin ? 4 : round_up(cin, 32); }
+  int ld_out() const { return round_up(cout, 32); }
+  double flops(int H, int W) const {
+    int Ho, Wo, a, b;
+    out_shape(H, W, &Ho, &Wo, &a, &b);
+    return 2.0 * Ho * Wo * (double)cin * cout * kh * kw;
+  }
+
+  int forward(const float* in, int N, int H, int W, int ldi, float* out, int ldo, const float* res, int relu_in,
+              hipStream_t s) const {
+    XDET_REQUIRE(ldi == ld_in(), "conv: ld_in must be round_up(cin,32) (4 for cin<=4)");
+    XDET_REQUIRE(ldo == ld_out(), "conv: ld_out must be round_up(cout,32)");
+    ConvParams p;
+    p.in = in; p.wt = d_wt; p.out = out; p.scale = d_scale; p.shift = d_shift; p.res = res;
+    p.N = N; p.H = H; p.W = W; p.ldi = ldi; p.ldo = ldo; p.ldr = ldo;
+    out_shape(H, W, &p.Ho, &p.Wo, &p.pad_t, &p.pad_l);
+    XDET_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv: empty output");
+    p.Cin_p = cin_p; p.Kp = kp; p.Cout_pad = cout_pad;
+    p.KH = kh; p.KW = kw; p.stride = stride; p.dil = dil;
+    p.M = N * p.Ho * p.Wo;
+    p.relu_in = relu_in; p.relu_out = relu_out;
+    return launch_conv_mfma_f32(p, small_cin, n_tile, s);
+  }
+};
+
+struct DepthwiseLayer : LayerBase {
+  int C, dil, ld;
+  float* d_w = nullptr;
+  ~DepthwiseLayer() override { if (d_w) (void)hipFree(d_w); }
+  int init(int C_, int dil_, const float* w33c1) {
+    XDET_REQUIRE(C_ > 0 && dil_ > 0 && w33c1, "depthwise: bad arguments");
+    kind = 2;
+    C = C_; dil = dil_; ld = round_up(C, 32);
+    std::vector<float> w((size_t)9 * ld, 0.f);
+    for (int t = 0; t < 9; ++t)
+      for (int c = 0; c < C; ++c) w[(size_t)t * ld + c] = w33c1[(size_t)t * C + c];
+    return upload(w, &d_w);
+  }
+  int forward(const float* in, int N, int H, int W, int ld_, float* out, int relu_in, hipStream_t s) const {
+    XDET_REQUIRE(ld_ == ld, "depthwise: ld must be round_up(C,32)");
+    return launch_depthwise3x3(in, d_w, out, N, H, W, C, ld, dil, relu_in, s);
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// static launch plans
+// ---------------------------------------------------------------------------------------
+struct Buf {
+  float* p = nullptr;
+  int H = 0, W = 0, C = 0, ld = 0;
+  size_t per_image() const { return (size_t)H * W * ld; }
+};
+
+struct Op {
+  std::string name;
+  int stage;
+  double flops;      // dense 2*MAC per image (0 for non-MFMA ops)
+  std::function<int(int, hipStream_t)> run;
+};
+
+struct Plan {
+  int max_batch = 1;
+  std::vector<void*> allocs;
+  std::vector<std::unique_ptr<LayerBase>> layers;
+  std::vector<Op> ops;
+  WeightMap w;
+
+  ~Plan() {
+    for (void* p : allocs) (void)hipFree(p);
+  }
+  int alloc_bytes(size_t bytes, void** out, bool zero = true) {
+    XDET_HIP(hipMalloc(out, std::max<size_t>(bytes, 256)));
+    if (zero) XDET_HIP(hipMemset(*out, 0, std::max<size_t>(bytes, 256)));
+    allocs.push_back(*out);
+    return XDET_OK;
+  }
+  int new_buf(int H, int W, int C, Buf* b) {
+    b->H = H; b->W = W; b->C = C;
+    b->ld = C <= 4 ? 4 : round_up(C, 32);
+    // +128 floats of slack: the conv loader may read a full 32-channel slice of the last pixel
+    return alloc_bytes(((size_t)max_batch * b->per_image() + 128) * sizeof(float), reinterpret_cast<void**>(&b->p));
+  }
+  const HostTensor* find(const std::string& name) const {
+    auto it = w.find(name);
+    return it == w.end() ? nullptr : &it->second;
+  }
+  int need(const std::string& name, const HostTensor** t, std::initializer_list<int64_t> dims) const {
+    *t = find(name);
+    if (!*t) {
+      set_last_error("missing weight: " + name);
+      return XDET_ERR_STATE;
+    }
+    if ((*t)->dims != std::vector<int64_t>(dims)) {
+      set_last_error("weight has wrong shape: " + name);
+      return XDET_ERR_INVALID_ARG;
+    }
+    return XDET_OK;
+  }
+  // inference BN folded to y = x*scale + shift; an optional conv bias is folded in too
+  int fold_bn(const std::string& bn, int C, float eps, const float* bias, std::vector<float>* scale,
+              std::vector<float>* shift) const {
+    const HostTensor *g, *b, *m, *v;
+    XDET_TRY(need(bn + "/gamma", &g, {C}));
+    XDET_TRY(need(bn + "/beta", &b, {C}));
+    XDET_TRY(need(bn + "/moving_mean", &m, {C}));
+    XDET_TRY(need(bn + "/moving_variance", &v, {C}));
+    scale->resize(C);
+    shift->resize(C);
+    for (int c = 0; c < C; ++c) {
+      const float sc = g->v[c] / std::sqrt(v->v[c] + eps);
+      (*scale)[c] = sc;
+      (*shift)[c] = b->v[c] - m->v[c] * sc + (bias ? bias[c] * sc : 0.f);
+    }
+    return XDET_OK;
+  }
+
+  // ---- op builders ----
+  int add_conv(const std::string& name, int stage, const Buf& in, ConvLayer* L, const Buf* res, int relu_in, Buf* out) {
+    int Ho, Wo, a, b;
+    L->out_shape(in.H, in.W, &Ho, &Wo, &a, &b);
+    XDET_TRY(new_buf(Ho, Wo, L->cout, out));
+    XDET_REQUIRE(in.ld == L->ld_in() && out->ld == L->ld_out(), "plan: conv channel strides do not match");
+    const Buf i = in, o = *out;
+    const float* rp = res ? res->p : nullptr;
+    if (res) XDET_REQUIRE(res->H == Ho && res->W == Wo && res->ld == o.ld, "plan: residual shape mismatch");
+    ops.push_back({name, stage, L->flops(in.H, in.W), [=](int N, hipStream_t s) {
+                     return L->forward(i.p, N, i.H, i.W, i.ld, o.p, o.ld, rp, relu_in, s);
+                   }});
+    return XDET_OK;
+  }
+  int add_dw(const std::string& name, int stage, const Buf& in, DepthwiseLayer* L, int relu_in, Buf* out) {
+    XDET_TRY(new_buf(in.H, in.W, in.C, out));
+    const Buf i = in, o = *out;
+    ops.push_back({name, stage, 0.0, [=](int N, hipStream_t s) {
+                     return L->forward(i.p, N, i.H, i.W, i.ld, o.p, relu_in, s);
+                   }});
+    return XDET_OK;
+  }
+  int add_pool(const std::string& name, int stage, const Buf& in, const Buf* res, Buf* out) {
+    int Ho, Wo, pt, pl;
+    same_pad(in.H, 3, 2, 1, &pt, &Ho);
+    same_pad(in.W, 3, 2, 1, &pl, &Wo);
+    XDET_TRY(new_buf(Ho, Wo, in.C, out));
+    if (res) XDET_REQUIRE(res->H == Ho && res->W == Wo && res->ld == out->ld, "plan: pool residual shape mismatch");
+    const Buf i = in, o = *out;
+    const float* rp = res ? res->p : nullptr;
+    ops.push_back({name, stage, 0.0, [=](int N, hipStream_t s) {
+                     return launch_maxpool3x3s2_add(i.p, rp, o.p, N, i.H, i.W, i.C, i.ld, Ho, Wo, pt, pl, s);
+                   }});
+    return XDET_OK;
+  }
+  ConvLayer* keep(ConvLayer* L) { layers.emplace_back(L); return L; }
+  DepthwiseLayer* keep(DepthwiseLayer* L) { layers.emplace_back(L); return L; }
+
+  // tf.layers.conv2d(use_bias=False) + BN (+ReLU)
+  int conv_bn(const std::string& name, const std::string& bn, float eps, int stage, const Buf& in, int k, int cout,
+              int stride, int pad_mode, int relu_out, const Buf* res, int relu_in, Buf* out, int pad_expl = 0) {
+    const HostTensor* kt;
+    XDET_TRY(need(name + "/kernel", &kt, {k, k, in.C, cout}));
+    std::vector<float> sc, sh;
+    const float *scp = nullptr, *shp = nullptr;
+    if (!bn.empty()) {
+      XDET_TRY(fold_bn(bn, cout, eps, nullptr, &sc, &sh));
+      scp = sc.data(); shp = sh.data();
+    }
+    ConvLayer* L = keep(new ConvLayer());
+    XDET_TRY(L->init(k, k, in.C, cout, stride, 1, pad_mode, pad_expl, pad_expl, kt->v.data(), scp, shp, relu_out));
+    return add_conv(name, stage, in, L, res, relu_in, out);
+  }
+  // (ReLU ->) separable_conv2d -> BN (-> +residual) (-> ReLU)   net/xception_body.py:220-234
+  int sep_bn(const std::string& name, float eps, int stage, const Buf& in, int cout, int pre_relu, int dilation,
+             int relu_out, const Buf* res, Buf* out) {
+    const HostTensor *dk, *pk;
+    XDET_TRY(need(name + "/depthwise_kernel", &dk, {3, 3, in.C, 1}));
+    XDET_TRY(need(name + "/pointwise_kernel", &pk, {1, 1, in.C, cout}));
+    DepthwiseLayer* D = keep(new DepthwiseLayer());
+    XDET_TRY(D->init(in.C, dilation, dk->v.data()));
+    Buf t;
+    XDET_TRY(add_dw(name + "/depthwise", stage, in, D, pre_relu, &t));
+    std::vector<float> sc, sh;
+    XDET_TRY(fold_bn(name + "_bn", cout, eps, nullptr, &sc, &sh));
+    ConvLayer* L = keep(new ConvLayer());
+    XDET_TRY(L->init(1, 1, in.C, cout, 1, 1, 1, 0, 0, pk->v.data(), sc.data(), sh.data(), relu_out));
+    return add_conv(name + "/pointwise", stage, t, L, res, 0, out);
+  }
+  int run_stage(int stage, int N, hipStream_t s) const {
+    for (const Op& op : ops)
+      if (op.stage == stage) XDET_TRY(op.run(N, s));
+    return XDET_OK;
+  }
+};
+
+enum { ST_BODY = 0, ST_RPN = 1, ST_LSEP = 2, ST_HEAD = 3 };
+
+struct LightHeadNet : Plan {
+  xdet_lighthead_config cfg;
+  bool built = false;
+  Buf in4, mid_x, out, rpn_out, feat, pooled, fc, cls_reg;
+  float *objectness = nullptr, *rpn_boxes = nullptr, *proposals = nullptr, *head_boxes = nullptr;
+  float *anc_yx = nullptr, *anc_hw = nullptr;
+  float* mid_relu = nullptr;   // materialised ReLU(x) ("mid_outputs", xception_body.py:339) for API users
+  void* prop_ws_mem = nullptr;
+  ProposalWorkspace prop_ws;
+  int* def_shapes = nullptr;
+  float* def_bbox = nullptr;
+  int fmap = 0, n_anchor = 0;
+  std::map<int, hipGraphExec_t> graphs;
+  std::map<int, const float*> graph_inputs;
+
+  ~LightHeadNet() {
+    for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+  }
+
+  int build_body() {
+    const float eps = 1e-4f;   // net/xception_body.py:20
+    const int S = cfg.image_size;
+    in4.H = S; in4.W = S; in4.C = 3;
+    XDET_TRY(new_buf(S, S, 3, &in4));
+    Buf x, r, t;
+    XDET_TRY(conv_bn("block1_conv1", "block1_conv1_bn", eps, ST_BODY, in4, 3, 32, 2, 0, 1, nullptr, 0, &x));
+    XDET_TRY(conv_bn("block1_conv2", "block1_conv2_bn", eps, ST_BODY, x, 3, 64, 1, 0, 1, nullptr, 0, &t));
+    x = t;
+    struct Blk { const char* res; const char* bn; const char* s1; const char* s2; int c; int first_relu; };
+    const Blk blks[3] = {{"conv2d_1", "batch_normalization_1", "block2_sepconv1", "block2_sepconv2", 128, 0},
+                         {"conv2d_2", "batch_normalization_2", "block3_sepconv1", "block3_sepconv2", 256, 1},
+                         {"conv2d_3", "batch_normalization_3", "block4_sepconv1", "block4_sepconv2", 728, 1}};
+    for (const Blk& b : blks) {
+      XDET_TRY(conv_bn(b.res, b.bn, eps, ST_BODY, x, 1, b.c, 2, 1, 0, nullptr, 0, &r));
+      Buf a, c2, p;
+      XDET_TRY(sep_bn(b.s1, eps, ST_BODY, x, b.c, b.first_relu, 1, 0, nullptr, &a));
+      XDET_TRY(sep_bn(b.s2, eps, ST_BODY, a, b.c, 1, 1, 0, nullptr, &c2));
+      XDET_TRY(add_pool(std::string(b.s2) + "/pool_add", ST_BODY, c2, &r, &p));
+      x = p;
+    }
+    for (int blk = 5; blk <= 12; ++blk) {
+      const Buf res = x;
+      Buf a, b2, c3;
+      const std::string pre = "block" + std::to_string(blk);
+      XDET_TRY(sep_bn(pre + "_sepconv1", eps, ST_BODY, x, 728, 1, 1, 0, nullptr, &a));
+      XDET_TRY(sep_bn(pre + "_sepconv2", eps, ST_BODY, a, 728, 1, 1, 0, nullptr, &b2));
+      XDET_TRY(sep_bn(pre + "_sepconv3", eps, ST_BODY, b2, 728, 1, 1, 0, &res, &c3));
+      x = c3;
+    }
+    mid_x = x;   // mid_outputs = ReLU(mid_x); consumers apply the ReLU on load
+    XDET_TRY(conv_bn("conv2d_4", "batch_normalization_4", eps, ST_BODY, x, 1, 1024, 1, 1, 0, nullptr, 0, &r));
+    Buf a, b2, c3, d4;
+    XDET_TRY(sep_bn("block13_sepconv1", eps, ST_BODY, x, 728, 1, 1, 0, nullptr, &a));
+    XDET_TRY(sep_bn("block13_sepconv2", eps, ST_BODY, a, 1024, 1, 1, 0, &r, &b2));
+    XDET_TRY(sep_bn("block14_sepconv1", eps, ST_BODY, b2, 1536, 0, 2, 1, nullptr, &c3));   // :354-364
+    XDET_TRY(sep_bn("block14_sepconv2", eps, ST_BODY, c3, 2048, 0, 2, 1, nullptr, &d4));   // :366-376
+    out = d4;
+    fmap = out.H;
+    return XDET_OK;
+  }
+
+  int build_rpn() {
+    const int A = cfg.num_anchors;
+    const HostTensor *k0, *b0, *k1, *b1, *k2, *b2;
+    XDET_TRY(need("rpn_head/conv2d/kernel", &k0, {3, 3, 728, 512}));
+    XDET_TRY(need("rpn_head/conv2d/bias", &b0, {512}));
+    XDET_TRY(need("rpn_head/conv2d_1/kernel", &k1, {1, 1, 512, 2 * A}));
+    XDET_TRY(need("rpn_head/conv2d_1/bias", &b1, {2 * A}));
+    XDET_TRY(need("rpn_head/conv2d_2/kernel", &k2, {1, 1, 512, 4 * A}));
+    XDET_TRY(need("rpn_head/conv2d_2/bias", &b2, {4 * A}));
+    ConvLayer* L0 = keep(new ConvLayer());
+    XDET_TRY(L0->init(3, 3, 728, 512, 1, 1, 1, 0, 0, k0->v.data(), nullptr, b0->v.data(), 1));
+    Buf hid;
+    XDET_TRY(add_conv("rpn_head/conv2d", ST_RPN, mid_x, L0, nullptr, /*relu_in=*/1, &hid));
+    // cls (2A) and box (4A) 1x1 heads share their input: one GEMM over the concatenated filters
+    const int co = 6 * A;
+    std::vector<float> kc((size_t)512 * co), bc(co);
+    for (int ci = 0; ci < 512; ++ci) {
+      for (int j = 0; j < 2 * A; ++j) kc[(size_t)ci * co + j] = k1->v[(size_t)ci * 2 * A + j];
+      for (int j = 0; j < 4 * A; ++j) kc[(size_t)ci * co + 2 * A + j] = k2->v[(size_t)ci * 4 * A + j];
+    }
+    for (int j = 0; j < 2 * A; ++j) bc[j] = b1->v[j];
+    for (int j = 0; j < 4 * A; ++j) bc[2 * A + j] = b2->v[j];
+    ConvLayer* L1 = keep(new ConvLayer());
+    XDET_TRY(L1->init(1, 1, 512, co, 1, 1, 1, 0, 0, kc.data(), nullptr, bc.data(), 0));
+    XDET_TRY(add_conv("rpn_head/conv2d_1+2", ST_RPN, hid, L1, nullptr, 0, &rpn_out));
+    return XDET_OK;
+  }
+
+  int build_large_sep() {
+    const int mid = 256, co = cfg.bank * cfg.grid * cfg.grid;
+    const HostTensor *a0, *a0b, *a1, *a1b, *c0, *c0b, *c1, *c1b;
+    XDET_TRY(need("large_sep_feature/Branch_0/conv2d/kernel", &a0, {15, 1, 2048, mid}));
+    XDET_TRY(need("large_sep_feature/Branch_0/conv2d/bias", &a0b, {mid}));
+    XDET_TRY(need("large_sep_feature/Branch_1/conv2d/kernel", &a1, {15, 1, 2048, mid}));
+    XDET_TRY(need("large_sep_feature/Branch_1/conv2d/bias", &a1b, {mid}));
+    XDET_TRY(need("large_sep_feature/Branch_0/conv2d_1/kernel", &c0, {1, 15, mid, co}));
+    XDET_TRY(need("large_sep_feature/Branch_0/conv2d_1/bias", &c0b, {co}));
+    XDET_TRY(need("large_sep_feature/Branch_1/conv2d_1/kernel", &c1, {1, 15, mid, co}));
+    XDET_TRY(need("large_sep_feature/Branch_1/conv2d_1/bias", &c1b, {co}));
+    // both (15,1) convs read the same input: one conv with the filters concatenated (2*mid outputs)
+    std::vector<float> ka((size_t)15 * 2048 * 2 * mid), ba(2 * mid);
+    for (size_t tc = 0; tc < (size_t)15 * 2048; ++tc) {
+      memcpy(&ka[tc * 2 * mid], &a0->v[tc * mid], mid * sizeof(float));
+      memcpy(&ka[tc * 2 * mid + mid], &a1->v[tc * mid], mid * sizeof(float));
+    }
+    for (int j = 0; j < mid; ++j) { ba[j] = a0b->v[j]; ba[mid + j] = a1b->v[j]; }
+    ConvLayer* LA = keep(new ConvLayer());
+    XDET_TRY(LA->init(15, 1, 2048, 2 * mid, 1, 1, 1, 0, 0, ka.data(), nullptr, ba.data(), 0));
+    Buf t;
+    XDET_TRY(add_conv("large_sep_feature/Branch_0+1/conv2d", ST_LSEP, out, LA, nullptr, 0, &t));
+    // branch_0b + branch_1b = one (1,15) conv over the 2*mid stacked channels; then BN(1e-5)+ReLU
+    std::vector<float> kb((size_t)15 * 2 * mid * co);
+    for (int tap = 0; tap < 15; ++tap)
+      for (int ci = 0; ci < mid; ++ci) {
+        memcpy(&kb[((size_t)tap * 2 * mid + ci) * co], &c0->v[((size_t)tap * mid + ci) * co], co * sizeof(float));
+        memcpy(&kb[((size_t)tap * 2 * mid + mid + ci) * co], &c1->v[((size_t)tap * mid + ci) * co], co * sizeof(float));
+      }
+    std::vector<float> bsum(co), sc, sh;
+    for (int j = 0; j < co; ++j) bsum[j] = c0b->v[j] + c1b->v[j];
+    XDET_TRY(fold_bn("large_sep_feature/batch_normalization", co, 1e-5f, bsum.data(), &sc, &sh));
+    ConvLayer* LB = keep(new ConvLayer());
+    XDET_TRY(LB->init(1, 15, 2 * mid, co, 1, 1, 1, 0, 0, kb.data(), sc.data(), sh.data(), 1));
+    XDET_TRY(add_conv("large_sep_feature/Branch_0+1/conv2d_1", ST_LSEP, t, LB, nullptr, 0, &feat));
+    return XDET_OK;
+  }
+
+  int build_head() {
+    const int R = cfg.rpn_post_nms_top_n, C = cfg.bank * cfg.grid * cfg.grid, nc = cfg.num_classes;
+    const HostTensor *k0, *b0, *k1, *b1, *k2, *b2;
+    XDET_TRY(need("final_head/subnet_fc/kernel", &k0, {C, 2048}));
+    XDET_TRY(need("final_head/subnet_fc/bias", &b0, {2048}));
+    XDET_TRY(need("final_head/fc_cls/kernel", &k1, {2048, nc}));
+    XDET_TRY(need("final_head/fc_cls/bias", &b1, {nc}));
+    XDET_TRY(need("final_head/fc_loc/kernel", &k2, {2048, 4}));
+    XDET_TRY(need("final_head/fc_loc/bias", &b2, {4}));
+    // ROI rows are the GEMM M dimension: treat [N*R, C] as an NHWC tensor with H = R, W = 1
+    XDET_TRY(new_buf(R, 1, C, &pooled));
+    ConvLayer* L0 = keep(new ConvLayer());
+    XDET_TRY(L0->init(1, 1, C, 2048, 1, 1, 0, 0, 0, k0->v.data(), nullptr, b0->v.data(), 1));
+    XDET_TRY(add_conv("final_head/subnet_fc", ST_HEAD, pooled, L0, nullptr, 0, &fc));
+    const int co = nc + 4;
+    std::vector<float> kc((size_t)2048 * co), bc(co);
+    for (int ci = 0; ci < 2048; ++ci) {
+      for (int j = 0; j < nc; ++j) kc[(size_t)ci * co + j] = k1->v[(size_t)ci * nc + j];
+      for (int j = 0; j < 4; ++j) kc[(size_t)ci * co + nc + j] = k2->v[(size_t)ci * 4 + j];
+    }
+    for (int j = 0; j < nc; ++j) bc[j] = b1->v[j];
+    for (int j = 0; j < 4; ++j) bc[nc + j] = b2->v[j];
+    ConvLayer* L1 = keep(new ConvLayer());
+    XDET_TRY(L1->init(1, 1, 2048, co, 1, 1, 0, 0, 0, kc.data(), nullptr, bc.data(), 0));
+    XDET_TRY(add_conv("final_head/fc_cls+fc_loc", ST_HEAD, fc, L1, nullptr, 0, &cls_reg));
+    return XDET_OK;
+  }
+
+  int build() {
+    XDET_REQUIRE(!built, "net already built");
+    XDET_REQUIRE(cfg.max_batch > 0 && cfg.image_size >= 64, "bad max_batch / image_size");
+    XDET_REQUIRE(cfg.num_anchors == 22, "anchor table is the reference's 22-anchor set (1 extra + 7 scales x 3 ratios)");
+    max_batch = cfg.max_batch;
+    XDET_TRY(build_body());
+    XDET_TRY(build_rpn());
+    XDET_TRY(build_large_sep());
+    XDET_TRY(build_head());
+    const int B = max_batch, A = cfg.num_anchors, R = cfg.rpn_post_nms_top_n;
+    n_anchor = fmap * fmap * A;
+    // A5: AnchorCreator.get_layer_anchors (anchor_manipulator.py:698-757), layer_step 16, offset .5
+    std::vector<float> yx((size_t)fmap * fmap * 2), hw((size_t)A * 2);
+    for (int y = 0; y < fmap; ++y)
+      for (int x = 0; x < fmap; ++x) {
+        yx[((size_t)y * fmap + x) * 2 + 0] = ((float)y + 0.5f) * 16.f / (float)cfg.image_size;
+        yx[((size_t)y * fmap + x) * 2 + 1] = ((float)x + 0.5f) * 16.f / (float)cfg.image_size;
+      }
+    {
+      int a = 0;
+      hw[0] = 0.1f; hw[1] = 0.1f; ++a;
+      const double scales[7] = {0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8}, ratios[3] = {1., 2., .5};
+      for (double sc : scales)
+        for (double ra : ratios) {
+          hw[a * 2 + 0] = (float)(sc / std::sqrt(ra));
+          hw[a * 2 + 1] = (float)(sc * std::sqrt(ra));
+          ++a;
+        }
+    }
+    XDET_TRY(alloc_bytes(yx.size() * 4, reinterpret_cast<void**>(&anc_yx)));
+    XDET_TRY(alloc_bytes(hw.size() * 4, reinterpret_cast<void**>(&anc_hw)));
+    XDET_HIP(hipMemcpy(anc_yx, yx.data(), yx.size() * 4, hipMemcpyHostToDevice));
+    XDET_HIP(hipMemcpy(anc_hw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    XDET_TRY(alloc_bytes((size_t)B * n_anchor * 4, reinterpret_cast<void**>(&objectness)));
+    XDET_TRY(alloc_bytes((size_t)B * n_anchor * 16, reinterpret_cast<void**>(&rpn_boxes)));
+    XDET_TRY(alloc_bytes((size_t)B * R * 16, reinterpret_cast<void**>(&proposals)));
+    XDET_TRY(alloc_bytes((size_t)B * R * 16, reinterpret_cast<void**>(&head_boxes)));
+    XDET_TRY(alloc_bytes((size_t)B * mid_x.per_image() * 4, reinterpret_cast<void**>(&mid_relu)));
+    XDET_TRY(alloc_bytes(proposal_workspace_bytes(B, n_anchor, cfg.rpn_pre_nms_top_n, R), &prop_ws_mem));
+    proposal_workspace_carve(prop_ws_mem, B, n_anchor, cfg.rpn_pre_nms_top_n, R, &prop_ws);
+    std::vector<int> shp((size_t)B * 2, cfg.image_size);
+    std::vector<float> bb((size_t)B * 4);
+    for (int i = 0; i < B; ++i) { bb[i * 4] = 0.f; bb[i * 4 + 1] = 0.f; bb[i * 4 + 2] = 1.f; bb[i * 4 + 3] = 1.f; }
+    XDET_TRY(alloc_bytes(shp.size() * 4, reinterpret_cast<void**>(&def_shapes)));
+    XDET_TRY(alloc_bytes(bb.size() * 4, reinterpret_cast<void**>(&def_bbox)));
+    XDET_HIP(hipMemcpy(def_shapes, shp.data(), shp.size() * 4, hipMemcpyHostToDevice));
+    XDET_HIP(hipMemcpy(def_bbox, bb.data(), bb.size() * 4, hipMemcpyHostToDevice));
+    w.clear();   // host copies are no longer needed
+    built = true;
+    return XDET_OK;
+  }
+
+  int check(int N) const {
+    if (!built) {
+      set_last_error("net not built");
+      return XDET_ERR_STATE;
+    }
+    XDET_REQUIRE(N > 0 && N <= max_batch, "batch must be in 1..max_batch");
+    return XDET_OK;
+  }
+  int xception_body(const float* images, int N, hipStream_t s) {
+    XDET_TRY(check(N));
+    XDET_REQUIRE(images != nullptr, "images is NULL");
+    XDET_TRY(launch_nchw_to_nhwc4(images, in4.p, N, 3, cfg.image_size, cfg.image_size, 4, s));
+    return run_stage(ST_BODY, N, s);
+  }
+  int rpn_decode(int N, hipStream_t s) {
+    XDET_TRY(check(N));
+    return launch_rpn_decode(rpn_out.p, rpn_out.ld, 0, 2 * cfg.num_anchors, N, fmap, fmap, cfg.num_anchors, anc_yx,
+                             anc_hw, objectness, rpn_boxes, s);
+  }
+  int get_proposals(int N, hipStream_t s) {
+    XDET_TRY(check(N));
+    return launch_get_proposals(objectness, rpn_boxes, N, n_anchor, cfg.rpn_pre_nms_top_n, cfg.rpn_post_nms_top_n,
+                                cfg.rpn_nms_thres, cfg.rpn_min_size, prop_ws, proposals, s);
+  }
+  int get_head(int N, hipStream_t s) {
+    XDET_TRY(check(N));
+    const int C = cfg.bank * cfg.grid * cfg.grid;
+    XDET_TRY(launch_psroialign(feat.p, proposals, pooled.p, nullptr, N, C, feat.H, feat.W, cfg.rpn_post_nms_top_n,
+                               cfg.grid, cfg.grid, 1, 1, feat.ld, pooled.ld, /*corners=*/1, s));
+    return run_stage(ST_HEAD, N, s);
+  }
+  int head_decode(int N, hipStream_t s) {
+    XDET_TRY(check(N));
+    return launch_ext_decode_rois(proposals, cls_reg.p + cfg.num_classes, cls_reg.ld,
+                                  (int64_t)N * cfg.rpn_post_nms_top_n, head_boxes, s);
+  }
+  int bboxes_eval(int N, const int* shapes, const float* bbox, float* ds, float* db, hipStream_t s) {
+    XDET_TRY(check(N));
+    return launch_bboxes_eval(cls_reg.p, cls_reg.ld, head_boxes, N, cfg.rpn_post_nms_top_n, cfg.num_classes,
+                              shapes ? shapes : def_shapes, bbox ? bbox : def_bbox, cfg.image_size, cfg.image_size,
+                              cfg.select_threshold, cfg.nms_threshold, cfg.nms_topk, ds, db, s);
+  }
+  int forward_eager(const float* images, int N, const int* shapes, const float* bbox, float* ds, float* db,
+                    hipStream_t s) {
+    XDET_TRY(xception_body(images, N, s));
+    XDET_TRY(run_stage(ST_RPN, N, s));
+    XDET_TRY(run_stage(ST_LSEP, N, s));
+    XDET_TRY(rpn_decode(N, s));
+    XDET_TRY(get_proposals(N, s));
+    XDET_TRY(get_head(N, s));
+    XDET_TRY(head_decode(N, s));
+    return bboxes_eval(N, shapes, bbox, ds, db, s);
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// A13: ResNet-50 v2 trunk
+// ---------------------------------------------------------------------------------------
+struct ResNetTrunk : Plan {
+  int image_size = 480;
+  bool built = false;
+  Buf in4, outb;
+  double flops = 0;
+
+  // Pre-activation bottlenecks (net/resnet_v2.py:142-184).  The BN+ReLU that follows the two inner
+  // convs is folded into their epilogues; the one that opens a block cannot be (the raw block input
+  // is also the identity shortcut), so it is its own element-wise pass.
+  int add_bn_relu(const std::string& bn, const Buf& in, Buf* out);
+  int build();
+};
+
+__global__ void bn_relu_kernel(const float* __restrict__ in, const float* __restrict__ scale,
+                               const float* __restrict__ shift, float* __restrict__ out, int64_t npix, int ld) {
+  const int c4n = ld >> 2;
+  const int64_t total = npix * c4n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    float4 v = reinterpret_cast<const float4*>(in)[i];
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+    v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+    v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+
+int ResNetTrunk::add_bn_relu(const std::string& bn, const Buf& in, Buf* out) {
+  std::vector<float> sc, sh;
+  XDET_TRY(fold_bn(bn, in.C, 1e-5f, nullptr, &sc, &sh));
+  sc.resize(in.ld, 0.f);
+  sh.resize(in.ld, 0.f);
+  float *dsc, *dsh;
+  XDET_TRY(alloc_bytes(sc.size() * 4, reinterpret_cast<void**>(&dsc)));
+  XDET_TRY(alloc_bytes(sh.size() * 4, reinterpret_cast<void**>(&dsh)));
+  XDET_HIP(hipMemcpy(dsc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+  XDET_HIP(hipMemcpy(dsh, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
+  XDET_TRY(new_buf(in.H, in.W, in.C, out));
+  const Buf i = in, o = *out;
+  ops.push_back({bn, 0, 0.0, [=](int N, hipStream_t s) {
+                   const int64_t npix = (int64_t)N * i.H * i.W;
+                   const int blocks = (int)std::min<int64_t>(cdiv(npix * (i.ld / 4), 256), 256 * 32);
+                   hipLaunchKernelGGL(bn_relu_kernel, dim3(blocks), dim3(256), 0, s, i.p, dsc, dsh, o.p, npix, i.ld);
+                   XDET_LAUNCH_CHECK();
+                   return (int)XDET_OK;
+                 }});
+  return XDET_OK;
+}
+
+int ResNetTrunk::build() {
+  XDET_REQUIRE(!built, "net already built");
+  int ci = 0, bi = 0;
+  auto cname = [&]() { std::string n = ci == 0 ? "conv2d" : "conv2d_" + std::to_string(ci); ++ci; return n; };
+  auto bname = [&]() { std::string n = bi == 0 ? "batch_normalization" : "batch_normalization_" + std::to_string(bi); ++bi; return n; };
+  XDET_TRY(new_buf(image_size, image_size, 3, &in4));
+  Buf x, t;
+  // conv2d_fixed_padding(7, stride 2): explicit pad 3/3 then VALID (:89-100)
+  XDET_TRY(conv_bn(cname(), "", 0.f, 0, in4, 7, 64, 2, 2, 0, nullptr, 0, &x, 3));
+  XDET_TRY(add_pool("initial_max_pool", 0, x, nullptr, &t));
+  x = t;
+  const int filters[4] = {64, 128, 256, 512}, blocks[4] = {3, 4, 6, 3}, strides[4] = {1, 2, 2, 2};
+  for (int st = 0; st < 4; ++st)
+    for (int b = 0; b < blocks[st]; ++b) {
+      const int f = filters[st], s = b == 0 ? strides[st] : 1;
+      Buf pre, shortcut = x, y1, y2, y3;
+      XDET_TRY(add_bn_relu(bname(), x, &pre));
+      if (b == 0) XDET_TRY(conv_bn(cname(), "", 0.f, 0, pre, 1, 4 * f, s, s > 1 ? 2 : 1, 0, nullptr, 0, &shortcut, 0));
+      const std::string c1 = cname(), b1 = bname(), c2 = cname(), b2 = bname(), c3 = cname();
+      // conv1x1 -> (BN+ReLU fused into its epilogue) -> conv3x3/s -> (BN+ReLU fused) -> conv1x1 + shortcut
+      XDET_TRY(conv_bn(c1, b1, 1e-5f, 0, pre, 1, f, 1, 1, 1, nullptr, 0, &y1));
+      XDET_TRY(conv_bn(c2, b2, 1e-5f, 0, y1, 3, f, s, s > 1 ? 2 : 1, 1, nullptr, 0, &y2, 1));
+      XDET_TRY(conv_bn(c3, "", 0.f, 0, y2, 1, 4 * f, 1, 1, 0, &shortcut, 0, &y3));
+      x = y3;
+    }
+  XDET_TRY(add_bn_relu(bname(), x, &outb));
+  for (const Op& op : ops) flops += op.flops;
+  w.clear();
+  built = true;
+  return XDET_OK;
+}
+
+}  // namespace xdet
+
+// =========================================================================================
+// C-ABI
+// =========================================================================================
+using namespace xdet;
+
+extern "C" {
+
+const char* xdet_last_error(void) { return g_last_error.c_str(); }
+int xdet_version(void) { return 1; }
+int xdet_device_count(int* n) { XDET_HIP(hipGetDeviceCount(n)); return XDET_OK; }
+int xdet_set_device(int dev) { XDET_HIP(hipSetDevice(dev)); return XDET_OK; }
+
+int xdet_malloc(void** dptr, size_t bytes) { XDET_REQUIRE(dptr, "dptr is NULL"); XDET_HIP(hipMalloc(dptr, std::max<size_t>(bytes, 16))); return XDET_OK; }
+int xdet_free(void* dptr) { if (dptr) XDET_HIP(hipFree(dptr)); return XDET_OK; }
+int xdet_memset(void* dptr, int value, size_t bytes, void* stream) { XDET_HIP(hipMemsetAsync(dptr, value, bytes, S(stream))); return XDET_OK; }
+int xdet_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) { XDET_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(stream))); return XDET_OK; }
+int xdet_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) { XDET_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S(stream))); XDET_HIP(hipStreamSynchronize(S(stream))); return XDET_OK; }
+int xdet_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) { XDET_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(stream))); return XDET_OK; }
+int xdet_stream_create(void** stream) { hipStream_t s; XDET_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *stream = s; return XDET_OK; }
+int xdet_stream_destroy(void* stream) { XDET_HIP(hipStreamDestroy(S(stream))); return XDET_OK; }
+int xdet_stream_sync(void* stream) { XDET_HIP(hipStreamSynchronize(S(stream))); return XDET_OK; }
+int xdet_event_create(void** ev) { hipEvent_t e; XDET_HIP(hipEventCreate(&e)); *ev = e; return XDET_OK; }
+int xdet_event_destroy(void* ev) { XDET_HIP(hipEventDestroy(reinterpret_cast<hipEvent_t>(ev))); return XDET_OK; }
+int xdet_event_record(void* ev, void* stream) { XDET_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev), S(stream))); return XDET_OK; }
+int xdet_event_elapsed_ms(void* a, void* b, float* ms) {
+  XDET_HIP(hipEventSynchronize(reinterpret_cast<hipEvent_t>(b)));
+  XDET_HIP(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(a), reinterpret_cast<hipEvent_t>(b)));
+  return XDET_OK;
+}
+
+int xdet_psroialign_fwd(const float* feat, const float* rois, float* pooled, int32_t* index, int N, int C, int H,
+                        int W, int R, int grid_w, int grid_h, int use_max, int feat_layout, int ldc, int out_ld,
+                        int rois_are_corners, void* stream) {
+  XDET_REQUIRE(feat && rois && pooled, "inputs/rois/pooled_features must not be NULL");
+  return launch_psroialign(feat, rois, pooled, index, N, C, H, W, R, grid_w, grid_h, use_max, feat_layout,
+                           feat_layout == 0 ? C : ldc, out_ld, rois_are_corners, S(stream));
+}
+
+int xdet_conv_create(void** layer, int kh, int kw, int cin, int cout, int stride, int dilation, int pad_mode,
+                     int pad_t, int pad_l, const float* k, const float* scale, const float* shift, int relu_out) {
+  XDET_REQUIRE(layer, "layer is NULL");
+  std::unique_ptr<ConvLayer> L(new ConvLayer());
+  XDET_TRY(L->init(kh, kw, cin, cout, stride, dilation, pad_mode, pad_t, pad_l, k, scale, shift, relu_out));
+  *layer = static_cast<LayerBase*>(L.release());
+  return XDET_OK;
+}
+int xdet_conv_forward(void* layer, const float* in, int N, int H, int W, int ld_in, float* out, int ld_out,
+                      const float* residual, int relu_in, void* stream) {
+  LayerBase* b = static_cast<LayerBase*>(layer);
+  XDET_REQUIRE(b && b->kind == 1, "not a conv layer");
+  return static_cast<ConvLayer*>(b)->forward(in, N, H, W, ld_in, out, ld_out, residual, relu_in, S(stream));
+}
+int xdet_conv_out_shape(void* layer, int H, int W, int* Ho, int* Wo) {
+  LayerBase* b = static_cast<LayerBase*>(layer);
+  XDET_REQUIRE(b && b->kind == 1, "not a conv layer");
+  int a, c;
+  static_cast<ConvLayer*>(b)->out_shape(H, W, Ho, Wo, &a, &c);
+  return XDET_OK;
+}
+int xdet_layer_destroy(void* layer) { delete static_cast<LayerBase*>(layer); return XDET_OK; }
+int xdet_depthwise_create(void** layer, int C, int dilation, const float* k) {
+  XDET_REQUIRE(layer, "layer is NULL");
+  std::unique_ptr<DepthwiseLayer> L(new DepthwiseLayer());
+  XDET_TRY(L->init(C, dilation, k));
+  *layer = static_cast<LayerBase*>(L.release());
+  return XDET_OK;
+}
+int xdet_depthwise_forward(void* layer, const float* in, int N, int H, int W, int ld, float* out, int relu_in,
+                           void* stream) {
+  LayerBase* b = static_cast<LayerBase*>(layer);
+  XDET_REQUIRE(b && b->kind == 2, "not a depthwise layer");
+  return static_cast<DepthwiseLayer*>(b)->forward(in, N, H, W, ld, out, relu_in, S(stream));
+}
+int xdet_maxpool3x3s2_add(const float* in, const float* residual, float* out, int N, int H, int W, int C, int ld,
+                          void* stream) {
+  int Ho, Wo, pt, pl;
+  same_pad(H, 3, 2, 1, &pt, &Ho);
+  same_pad(W, 3, 2, 1, &pl, &Wo);
+  return launch_maxpool3x3s2_add(in, residual, out, N, H, W, C, ld, Ho, Wo, pt, pl, S(stream));
+}
+int xdet_nchw_to_nhwc4(const float* in, float* out, int N, int C, int H, int W, void* stream) {
+  return launch_nchw_to_nhwc4(in, out, N, C, H, W, 4, S(stream));
+}
+
+int xdet_rpn_decode(const float* rpn_out, int ld, int cls_off, int box_off, int N, int Hh, int Ww, int A,
+                    const float* anchors_yx, const float* anchors_hw, float* objectness, float* boxes, void* stream) {
+  return launch_rpn_decode(rpn_out, ld, cls_off, box_off, N, Hh, Ww, A, anchors_yx, anchors_hw, objectness, boxes,
+                           S(stream));
+}
+size_t xdet_proposals_workspace_bytes(int N, int n_anchor, int pre_n, int post_n) {
+  return proposal_workspace_bytes(N, n_anchor, pre_n, post_n);
+}
+int xdet_get_proposals(const float* objectness, const float* boxes, int N, int n_anchor, int pre_n, int post_n,
+                       float nms_thr, float min_size, void* workspace, float* rois, int* counts_out, void* stream) {
+  XDET_REQUIRE(objectness && boxes && workspace && rois, "get_proposals: NULL argument");
+  ProposalWorkspace ws;
+  proposal_workspace_carve(workspace, N, n_anchor, pre_n, post_n, &ws);
+  XDET_TRY(launch_get_proposals(objectness, boxes, N, n_anchor, pre_n, post_n, nms_thr, min_size, ws, rois, S(stream)));
+  if (counts_out) XDET_HIP(hipMemcpyAsync(counts_out, ws.counts, (size_t)N * 16, hipMemcpyDeviceToDevice, S(stream)));
+  return XDET_OK;
+}
+int xdet_ext_decode_rois(const float* rois, const float* reg, int ld_reg, int64_t n, float* out, void* stream) {
+  return launch_ext_decode_rois(rois, reg, ld_reg, n, out, S(stream));
+}
+int xdet_bboxes_eval(const float* cls, int ld_cls, const float* boxes, int N, int R, int num_classes,
+                     const int* image_shapes, const float* bbox_img, int net_h, int net_w, float select_thr,
+                     float nms_thr, int nms_topk, float* det_scores, float* det_boxes, void* stream) {
+  XDET_REQUIRE(cls && boxes && image_shapes && bbox_img && det_scores && det_boxes, "bboxes_eval: NULL argument");
+  return launch_bboxes_eval(cls, ld_cls, boxes, N, R, num_classes, image_shapes, bbox_img, net_h, net_w, select_thr,
+                            nms_thr, nms_topk, det_scores, det_boxes, S(stream));
+}
+
+// ---- light-head net ----
+static int set_weight(Plan* p, const char* name, const float* data, int ndim, const int64_t* dims) {
+  XDET_REQUIRE(p && name && data && ndim >= 1 && ndim <= 4 && dims, "set_weight: bad arguments");
+  HostTensor t;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) { t.dims.push_back(dims[i]); n *= (size_t)dims[i]; }
+  t.v.assign(data, data + n);
+  p->w[name] = std::move(t);
+  return XDET_OK;
+}
+
+int xdet_net_create(void** net, const xdet_lighthead_config* cfg) {
+  XDET_REQUIRE(net && cfg, "net/cfg is NULL");
+  LightHeadNet* n = new LightHeadNet();
+  n->cfg = *cfg;
+  *net = n;
+  return XDET_OK;
+}
+int xdet_net_set_weight(void* net, const char* name, const float* data, int ndim, const int64_t* dims) {
+  return set_weight(static_cast<LightHeadNet*>(net), name, data, ndim, dims);
+}
+int xdet_net_build(void* net) { XDET_REQUIRE(net, "net is NULL"); return static_cast<LightHeadNet*>(net)->build(); }
+int xdet_net_destroy(void* net) { delete static_cast<LightHeadNet*>(net); return XDET_OK; }
+
+int xdet_net_buffer(void* net, const char* name, void** dptr, int64_t dims[4], int* ld) {
+  LightHeadNet* n = static_cast<LightHeadNet*>(net);
+  XDET_REQUIRE(n && n->built && name && dptr && dims && ld, "net_buffer: bad arguments");
+  const std::string s(name);
+  const int B = n->max_batch, R = n->cfg.rpn_post_nms_top_n;
+  auto from_buf = [&](const Buf& b) { *dptr = b.p; dims[0] = B; dims[1] = b.H; dims[2] = b.W; dims[3] = b.C; *ld = b.ld; };
+  if (s == "mid_x") from_buf(n->mid_x);
+  else if (s == "mid") { from_buf(n->mid_x); *dptr = n->mid_relu; }
+  else if (s == "out") from_buf(n->out);
+  else if (s == "rpn_out") from_buf(n->rpn_out);
+  else if (s == "feat") from_buf(n->feat);
+  else if (s == "pooled") from_buf(n->pooled);
+  else if (s == "fc") from_buf(n->fc);
+  else if (s == "cls_reg") from_buf(n->cls_reg);
+  else if (s == "objectness") { *dptr = n->objectness; dims[0] = B; dims[1] = n->n_anchor; dims[2] = 1; dims[3] = 1; *ld = 1; }
+  else if (s == "rpn_boxes") { *dptr = n->rpn_boxes; dims[0] = B; dims[1] = n->n_anchor; dims[2] = 1; dims[3] = 4; *ld = 4; }
+  else if (s == "proposals") { *dptr = n->proposals; dims[0] = B; dims[1] = R; dims[2] = 1; dims[3] = 4; *ld = 4; }
+  else if (s == "head_boxes") { *dptr = n->head_boxes; dims[0] = B; dims[1] = R; dims[2] = 1; dims[3] = 4; *ld = 4; }
+  else if (s == "prop_counts") { *dptr = n->prop_ws.counts; dims[0] = B; dims[1] = 4; dims[2] = 1; dims[3] = 1; *ld = 1; }
+  else if (s == "sorted_boxes") { *dptr = n->prop_ws.sboxes; dims[0] = B; dims[1] = n->cfg.rpn_pre_nms_top_n; dims[2] = 1; dims[3] = 4; *ld = 4; }
+  else if (s == "sorted_scores") { *dptr = n->prop_ws.sscores; dims[0] = B; dims[1] = n->cfg.rpn_pre_nms_top_n; dims[2] = 1; dims[3] = 1; *ld = 1; }
+  else {
+    set_last_error("unknown buffer: " + s);
+    return XDET_ERR_INVALID_ARG;
+  }
+  return XDET_OK;
+}
+
+int xdet_net_xception_body(void* net, const float* images, int N, void* stream) {
+  LightHeadNet* n = static_cast<LightHeadNet*>(net);
+  XDET_REQUIRE(n, "net is NULL");
+  XDET_TRY(n->xception_body(images, N, S(stream)));
+  // materialise mid_outputs = ReLU(x) for API users (the fused forward applies it on load instead)
+  return launch_relu_copy(n->mid_x.p, n->mid_relu, (int64_t)N * n->mid_x.per_image(), S(stream));
+}
+int xdet_net_get_rpn(void* net, int N, void* stream) {
+  LightHeadNet* n = static_cast<LightHeadNet*>(net);
+  XDET_REQUIRE(n, "net is NULL");
+  XDET_TRY(n->check(N));
+  return n->run_stage(ST_RPN, N, S(stream));
+}
+int xdet_net_large_sep(void* net, int N, void* stream) {
+  LightHeadNet* n = static_cast<LightHeadNet*>(net);
+  XDET_REQUIRE(n, "net is NULL");
+  XDET_TRY(n->check(N));
+  return n->run_stage(ST_LSEP, N, S(stream));
+}
+int xdet_net_rpn_decode(void* net, int N, void* stream) { XDET_REQUIRE(net, "net is NULL"); return static_cast<LightHeadNet*>(net)->rpn_decode(N, S(stream)); }
+int xdet_net_get_proposals(void* net, int N, void* stream) { XDET_REQUIRE(net, "net is NULL"); return static_cast<LightHeadNet*>(net)->get_proposals(N, S(stream)); }
+int xdet_net_get_head(void* net, int N, void* stream) { XDET_REQUIRE(net, "net is NULL"); return static_cast<LightHeadNet*>(net)->get_head(N, S(stream)); }
+int xdet_net_head_decode(void* net, int N, void* stream) { XDET_REQUIRE(net, "net is NULL"); return static_cast<LightHeadNet*>(net)->head_decode(N, S(stream)); }
+int xdet_net_bboxes_eval(void* net, int N, const int* image_shapes, const float* bbox_img, float* det_scores,
+                         float* det_boxes, void* stream) {
+  XDET_REQUIRE(net && det_scores && det_boxes, "bboxes_eval: NULL argument");
+  return static_cast<LightHeadNet*>(net)->bboxes_eval(N, image_shapes, bbox_img, det_scores, det_boxes, S(stream));
+}
+
+int xdet_net_forward(void* net, const float* images, int N, const int* image_shapes, const float* bbox_img,
+                     float* det_scores, float* det_boxes, int use_graph, void* stream) {
+  LightHeadNet* n = static_cast<LightHeadNet*>(net);
+  XDET_REQUIRE(n && images && det_scores && det_boxes, "forward: NULL argument");
+  XDET_TRY(n->check(N));
+  hipStream_t s = S(stream);
+  if (!use_graph) return n->forward_eager(images, N, image_shapes, bbox_img, det_scores, det_boxes, s);
+  XDET_REQUIRE(s != nullptr, "graph replay needs an explicit (non-default) stream");
+  // a captured graph bakes in its pointers: key on N and require the same buffers on replay
+  auto it = n->graphs.find(N);
+  if (it == n->graphs.end() || n->graph_inputs[N] != images) {
+    if (it != n->graphs.end()) { (void)hipGraphExecDestroy(it->second); n->graphs.erase(it); }
+    hipGraph_t g;
+    XDET_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rc = n->forward_eager(images, N, image_shapes, bbox_img, det_scores, det_boxes, s);
+    hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc != XDET_OK) return rc;
+    XDET_HIP(e);
+    hipGraphExec_t ge;
+    XDET_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    XDET_HIP(hipGraphDestroy(g));
+    n->graphs[N] = ge;
+    n->graph_inputs[N] = images;
+    it = n->graphs.find(N);
+  }
+  XDET_HIP(hipGraphLaunch(it->second, s));
+  return XDET_OK;
+}
+
+int xdet_net_flops_per_image(void* net, double* backbone, double* rpn, double* large_sep, double* head) {
+  LightHeadNet* n = static_cast<LightHeadNet*>(net);
+  XDET_REQUIRE(n && n->built, "net not built");
+  double f[4] = {0, 0, 0, 0};
+  for (const Op& op : n->ops) f[op.stage] += op.flops;
+  if (backbone) *backbone = f[ST_BODY];
+  if (rpn) *rpn = f[ST_RPN];
+  if (large_sep) *large_sep = f[ST_LSEP];
+  if (head) *head = f[ST_HEAD];
+  return XDET_OK;
+}
+
+// ---- resnet trunk ----
+int xdet_resnet_create(void** net, int image_size, int max_batch) {
+  XDET_REQUIRE(net && image_size >= 64 && max_batch > 0, "resnet_create: bad arguments");
+  ResNetTrunk* r = new ResNetTrunk();
+  r->image_size = image_size;
+  r->max_batch = max_batch;
+  *net = r;
+  return XDET_OK;
+}
+int xdet_resnet_set_weight(void* net, const char* name, const float* data, int ndim, const int64_t* dims) {
+  return set_weight(static_cast<ResNetTrunk*>(net), name, data, ndim, dims);
+}
+int xdet_resnet_build(void* net) { XDET_REQUIRE(net, "net is NULL"); return static_cast<ResNetTrunk*>(net)->build(); }
+int xdet_resnet_forward(void* net, const float* images, int N, float* out_nhwc, void* stream) {
+  ResNetTrunk* r = static_cast<ResNetTrunk*>(net);
+  XDET_REQUIRE(r && r->built && images, "resnet_forward: bad arguments");
+  XDET_REQUIRE(N > 0 && N <= r->max_batch, "batch must be in 1..max_batch");
+  hipStream_t s = S(stream);
+  XDET_TRY(launch_nchw_to_nhwc4(images, r->in4.p, N, 3, r->image_size, r->image_size, 4, s));
+  XDET_TRY(r->run_stage(0, N, s));
+  if (out_nhwc)
+    XDET_HIP(hipMemcpyAsync(out_nhwc, r->outb.p, (size_t)N * r->outb.per_image() * 4, hipMemcpyDeviceToDevice, s));
+  return XDET_OK;
+}
+int xdet_resnet_out_shape(void* net, int* Ho, int* Wo, int* C) {
+  ResNetTrunk* r = static_cast<ResNetTrunk*>(net);
+  XDET_REQUIRE(r && r->built, "resnet not built");
+  *Ho = r->outb.H; *Wo = r->outb.W; *C = r->outb.C;
+  return XDET_OK;
+}
+int xdet_resnet_flops_per_image(void* net, double* flops) {
+  ResNetTrunk* r = static_cast<ResNetTrunk*>(net);
+  XDET_REQUIRE(r && r->built && flops, "resnet not built");
+  *flops = r->flops;
+  return XDET_OK;
+}
+int xdet_resnet_destroy(void* net) { delete static_cast<ResNetTrunk*>(net); return XDET_OK; }
+
+}  // extern "C"

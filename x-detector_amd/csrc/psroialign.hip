@@ -1,0 +1,129 @@
+// PsRoiAlign forward for gfx950 -- replaces the reference's TF custom op
+// (cpp/PSROIPooling/ps_roi_align_op.cc:81-201 CPU functor, ps_roi_align_op.cu:36-132 CUDA kernel).
+//
+// THIS FILE IS COMPILED WITH -ffp-contract=off: the reference arithmetic is a fixed sequence
+// of separately rounded f32 operations plus an f64 bilinear blend (the `1.` literals in
+// ps_roi_align_op.cc:171-174), and bin assignment / argmax must be index-exact.
+//
+// Work decomposition (not the reference's one-thread-per-element grid-stride loop): one
+// 64-lane wavefront per (image, roi); the lanes walk the ROI's C = gh*gw*bank output
+// elements, whose flat index equals the input channel (pos*bank + ch), so with the NHWC
+// feature map used by the fused pipeline a lane group reads `bank` consecutive channels of
+// the same pixel (40 contiguous bytes for bank = 10) and the ROI geometry (identical for
+// all elements of an ROI) is computed once per wave from scalar loads.  layout 0 = NCHW (the op's public contract), 1 = NHWC with channel stride ldc.
+#include "common.h"
+#include <cfloat>
+
+namespace xdet {
+
+__device__ __forceinline__ float feat_at(const float* __restrict__ f, int layout, int ldc, int H, int W, int64_t n,
+                                         int c, int y, int x) {
+  if (layout == 0) return f[((n * ldc + c) * H + y) * W + x];
+  return f[((n * H + y) * W + x) * ldc + c];
+}
+
+__global__ __launch_bounds__(256) void psroialign_fwd_kernel(const float* __restrict__ feat,
+                                                             const float* __restrict__ rois,
+                                                             float* __restrict__ pooled, int32_t* __restrict__ index,
+                                                             int N, int C, int H, int W, int R, int gw, int gh,
+                                                             int use_max, int layout, int ldc, int out_ld,
+                                                             int corners) {
+  const int bank = C / (gw * gh);
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)N * R;
+  if (wave_id >= n_waves) return;
+  const int64_t nr = wave_id;          // n*R + r
+  const int64_t n = nr / R;
+  const float* roi = rois + nr * 4;
+  float r0 = roi[0], r1 = roi[1], r2 = roi[2], r3 = roi[3];
+  if (corners) {   // _point2center, net/xception_body.py:215-218
+    const float hh = r2 - r0, ww = r3 - r1;
+    r0 = r0 + hh / 2.f;
+    r1 = r1 + ww / 2.f;
+    r2 = hh;
+    r3 = ww;
+  }
+  float* prow = pooled + nr * out_ld;
+  int32_t* irow = index ? index + nr * out_ld : nullptr;
+
+  if (r2 < FLT_MIN || r3 < FLT_MIN) {   // degenerate ROI: zero (reference leaves the index unwritten)
+    for (int e = lane; e < C; e += 64) {
+      prow[e] = 0.f;
+      if (irow) irow[e] = 0;
+    }
+    return;
+  }
+  const float yc = r0 * (float)H;
+  const float xc = r1 * (float)W;
+  const float rh = fmaxf(r2 * (float)H, 1.f);
+  const float rw = fmaxf(r3 * (float)W, 1.f);
+  const float ymin = fmaxf(yc - rh / 2.f, 0.f);
+  const float xmin = fmaxf(xc - rw / 2.f, 0.f);
+  const float ymax = fminf(yc + rh / 2.f, (float)H - FLT_MIN);
+  const float xmax = fminf(xc + rw / 2.f, (float)W - FLT_MIN);
+  const float bin_w = (xmax - xmin) / (float)gw;
+  const float bin_h = (ymax - ymin) / (float)gh;
+  const int n_w = (int)bin_w + 1;
+  const int n_h = (int)bin_h + 1;
+  const float step_w = bin_w / (float)n_w;
+  const float step_h = bin_h / (float)n_h;
+  const double half_w = (double)step_w / 2.;
+  const double half_h = (double)step_h / 2.;
+
+  for (int e = lane; e < C; e += 64) {
+    const int pos = e / bank;
+    const int row = pos / gw;
+    const int col = pos - row * gw;
+    const int c_in = e;                  // pos*bank + ch
+    const float x0 = xmin + bin_w * (float)col;
+    const float y0 = ymin + bin_h * (float)row;
+    float acc = use_max ? -FLT_MAX : 0.f;
+    int arg = 0;
+    for (int i = 0; i < n_h; ++i) {
+      const float y = (float)((double)(y0 + step_h * (float)i) + half_h);
+      const int iy = (int)y;
+      const float fy = y - (float)iy;
+      const int iy1 = min(iy + 1, H - 1);
+      for (int j = 0; j < n_w; ++j) {
+        const float x = (float)((double)(x0 + step_w * (float)j) + half_w);
+        const int ix = (int)x;
+        const float fx = x - (float)ix;
+        const int ix1 = min(ix + 1, W - 1);
+        const double v = (1. - fx) * (1. - fy) * feat_at(feat, layout, ldc, H, W, n, c_in, iy, ix) +
+                         (1. - fx) * fy * feat_at(feat, layout, ldc, H, W, n, c_in, iy1, ix) +
+                         fx * (1. - fy) * feat_at(feat, layout, ldc, H, W, n, c_in, iy, ix1) +
+                         fx * fy * feat_at(feat, layout, ldc, H, W, n, c_in, iy1, ix1);
+        const float t = (float)v;
+        if (use_max) {
+          if (acc < t) { acc = t; arg = n_w * i + j; }
+        } else {
+          acc += t;
+        }
+      }
+    }
+    if (!use_max) acc /= (float)(n_h * n_w);
+    prow[e] = acc;
+    if (irow) irow[e] = use_max ? arg : 0;
+  }
+}
+
+int launch_psroialign(const float* feat, const float* rois, float* pooled, int32_t* index, int N, int C, int H,
+                      int W, int R, int gw, int gh, int use_max, int layout, int ldc, int out_ld,
+                      int rois_are_corners, hipStream_t s) {
+  // same checks as PSROIAlignOp (ps_roi_align_op.cc:209-226)
+  XDET_REQUIRE(gw > 0 && gh > 0, "Need Attr grid_dim_width/grid_dim_height > 0");
+  XDET_REQUIRE(N >= 0 && C > 0 && H > 0 && W > 0 && R >= 0, "inputs must be in 'NCHW' format.");
+  XDET_REQUIRE(C % (gw * gh) == 0, "channels must be divisible by grid_dim_width * grid_dim_height");
+  XDET_REQUIRE(layout == 0 || layout == 1, "feat_layout must be 0 (NCHW) or 1 (NHWC)");
+  XDET_REQUIRE(ldc >= C && out_ld >= C, "channel strides must be >= C");
+  const int64_t n_waves = (int64_t)N * R;
+  if (n_waves == 0) return XDET_OK;
+  hipLaunchKernelGGL(psroialign_fwd_kernel, dim3((unsigned)cdiv(n_waves, 4)), dim3(256), 0, s, feat, rois, pooled,
+                     index, N, C, H, W, R, gw, gh, use_max, layout, layout == 0 ? C : ldc, out_ld,
+                     rois_are_corners);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
+}  // namespace xdet

@@ -1,0 +1,52 @@
+"""Build libxdet_hip.so for gfx950 with hipcc (in-tree, so the .so travels with gpurun)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), 'csrc')
+LIB = os.path.join(HERE, 'libxdet_hip.so')
+
+# (source, extra flags).  Box/ROI arithmetic must round exactly like the reference's separately
+# rounded f32 operations, so those translation units are compiled without FMA contraction.
+SOURCES = [
+    ('conv_mfma.hip', []),
+    ('elementwise.hip', []),
+    ('psroialign.hip', ['-ffp-contract=off']),
+    ('proposals.hip', ['-ffp-contract=off']),
+    ('detect.hip', ['-ffp-contract=off']),
+    ('net.hip', []),
+]
+COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-result']
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    dirty = force or not os.path.exists(LIB)
+    hdr_m = max(os.path.getmtime(os.path.join(CSRC, 'common.h')),
+                os.path.getmtime(os.path.join(os.path.dirname(os.path.dirname(HERE)), 'include', 'xdet.h')))
+    procs = []
+    for src, extra in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace('.hip', '.o'))
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_m):
+            cmd = [hipcc] + COMMON + extra + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+            dirty = True
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
+    if dirty:
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,236 @@
+"""The Light-Head R-CNN eval graph behind the reference's graph-builder API.
+
+`LightHeadDetector` owns the native net (weights + workspace); the module-level
+functions carry the reference's names and argument order (net/xception_body.py:236,
+381,402,450,477) and operate on the detector that is current (`with det.scope():`,
+the counterpart of `tf.variable_scope(params['model_scope'])`,
+light_head_rfcn_eval.py:382).  Tensors are DeviceTensor views of the net's workspace.
+"""
+import contextlib
+import ctypes
+
+import numpy as np
+
+from ._lib import lib, check, c_void_p, LightHeadConfig, XdetError
+from .runtime import DeviceBuffer, DeviceTensor, Stream, to_device, to_host, synchronize, _host
+
+_current = []
+
+
+class LightHeadDetector(object):
+    def __init__(self, weights, image_size=480, max_batch=1, num_classes=21, rpn_pre_nms_top_n=5000,
+                 rpn_post_nms_top_n=1000, rpn_nms_thres=0.7, rpn_min_size=None, select_threshold=0.01,
+                 nms_threshold=0.3, nms_topk=200, device=None):
+        if device is not None:
+            check(lib().xdet_set_device(int(device)))
+        self.cfg = LightHeadConfig(image_size=image_size, max_batch=max_batch, num_classes=num_classes,
+                                   rpn_pre_nms_top_n=rpn_pre_nms_top_n, rpn_post_nms_top_n=rpn_post_nms_top_n,
+                                   rpn_nms_thres=rpn_nms_thres,
+                                   rpn_min_size=(16. / 480) if rpn_min_size is None else rpn_min_size,   # flag default, eval.py:112
+                                   select_threshold=select_threshold, nms_threshold=nms_threshold, nms_topk=nms_topk)
+        h = c_void_p()
+        check(lib().xdet_net_create(ctypes.byref(h), ctypes.byref(self.cfg)))
+        self.handle = h
+        for name, arr in weights.items():
+            a = np.ascontiguousarray(arr, np.float32)
+            dims = (ctypes.c_int64 * a.ndim)(*a.shape)
+            check(lib().xdet_net_set_weight(self.handle, name.encode(), _host(a), a.ndim, dims))
+        check(lib().xdet_net_build(self.handle))
+        self.max_batch = max_batch
+        self.image_size = image_size
+        self.num_classes = num_classes
+        self.R = rpn_post_nms_top_n
+        self.nms_topk = nms_topk
+        self.stream = Stream()
+        B, nc, k = max_batch, num_classes - 1, nms_topk
+        self._images = DeviceBuffer(B * 3 * image_size * image_size * 4)
+        self._det_scores = DeviceBuffer(B * nc * k * 4)
+        self._det_boxes = DeviceBuffer(B * nc * k * 16)
+        self._N = 0
+
+    # ---- plumbing -------------------------------------------------------------------
+    def buffer(self, name, n=None):
+        p = c_void_p()
+        dims = (ctypes.c_int64 * 4)()
+        ld = ctypes.c_int()
+        check(lib().xdet_net_buffer(self.handle, name.encode(), ctypes.byref(p), ctypes.byref(dims), ctypes.byref(ld)))
+        d = list(dims)
+        d[0] = n or self._N or d[0]
+        return DeviceTensor(p.value, d, ld.value, owner=self)
+
+    def flat(self, name, shape, dtype=np.float32):
+        p = c_void_p()
+        dims = (ctypes.c_int64 * 4)()
+        ld = ctypes.c_int()
+        check(lib().xdet_net_buffer(self.handle, name.encode(), ctypes.byref(p), ctypes.byref(dims), ctypes.byref(ld)))
+        return to_host(p.value, shape, dtype)
+
+    def write(self, name, array):
+        """overwrite a workspace buffer from the host (tests: feed one stage the oracle's tensors)."""
+        t = self.buffer(name, n=array.shape[0])
+        a = np.asarray(array, np.float32)
+        if name in ('objectness', 'rpn_boxes', 'proposals', 'head_boxes'):
+            flat = np.ascontiguousarray(a)
+        else:
+            n, h, w, c = a.shape
+            flat = np.zeros((n, h, w, t.ld), np.float32)
+            flat[..., :c] = a
+        check(lib().xdet_memcpy_h2d(t.ptr, _host(flat), flat.nbytes, None))
+        synchronize()
+        self._N = a.shape[0]
+
+    @contextlib.contextmanager
+    def scope(self):
+        _current.append(self)
+        try:
+            yield self
+        finally:
+            _current.pop()
+
+    def set_images(self, images_nchw):
+        a = np.ascontiguousarray(images_nchw, np.float32)
+        assert a.ndim == 4 and a.shape[1] == 3 and a.shape[2] == a.shape[3] == self.image_size, a.shape
+        assert a.shape[0] <= self.max_batch
+        check(lib().xdet_memcpy_h2d(self._images.ptr, _host(a), a.nbytes, self.stream.handle))
+        self._N = a.shape[0]
+        return self._N
+
+    # ---- the whole forward (lighr_head_model_fn, eval) -----------------------------------
+    def forward_device(self, n=None, use_graph=False, images_ptr=None, image_shapes_ptr=None, bbox_img_ptr=None,
+                       det_scores_ptr=None, det_boxes_ptr=None):
+        """asynchronous: images already resident (set_images or caller-owned device pointer)."""
+        n = n or self._N
+        check(lib().xdet_net_forward(self.handle, images_ptr or self._images.ptr, n, image_shapes_ptr, bbox_img_ptr,
+                                     det_scores_ptr or self._det_scores.ptr, det_boxes_ptr or self._det_boxes.ptr,
+                                     1 if use_graph else 0, self.stream.handle))
+
+    def detections(self, n=None):
+        n = n or self._N
+        nc, k = self.num_classes - 1, self.nms_topk
+        self.stream.synchronize()
+        s = to_host(self._det_scores.ptr, (n, nc, k), np.float32)
+        b = to_host(self._det_boxes.ptr, (n, nc, k, 4), np.float32)
+        return s, b
+
+    def forward(self, images_nchw, use_graph=False):
+        """images [N,3,S,S] whitened f32 -> list of {class: (scores[topk], boxes[topk,4])}, the
+        per-class zero-padded output of bboxes_eval (light_head_rfcn_eval.py:263-287)."""
+        n = self.set_images(images_nchw)
+        self.forward_device(n, use_graph)
+        s, b = self.detections(n)
+        return [{c + 1: (s[i, c], b[i, c]) for c in range(self.num_classes - 1)} for i in range(n)]
+
+    def predictions(self, n=None):
+        """the `predictions` dict of the EstimatorSpec (light_head_rfcn_eval.py:429-433)."""
+        n = n or self._N
+        nc = self.num_classes
+        cr = self.buffer('cls_reg', n).numpy().reshape(n, self.R, -1)
+        logits = cr[..., :nc]
+        e = np.exp(logits - logits.max(-1, keepdims=True))
+        prob = e / e.sum(-1, keepdims=True)
+        hb = self.flat('head_boxes', (n, self.R, 4))
+        return {'classes': prob.argmax(-1), 'probabilities': prob.max(-1), 'bboxes_predict': hb}
+
+    def flops_per_image(self):
+        v = [ctypes.c_double() for _ in range(4)]
+        check(lib().xdet_net_flops_per_image(self.handle, *[ctypes.byref(x) for x in v]))
+        return dict(zip(('backbone', 'rpn', 'large_sep', 'head'), [x.value for x in v]))
+
+    def __del__(self):
+        try:
+            lib().xdet_net_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def _det():
+    if not _current:
+        raise XdetError(-3, 'no current LightHeadDetector: use `with detector.scope():`')
+    return _current[-1]
+
+
+def _sync(d):
+    d.stream.synchronize()
+
+
+def _same(t, view):
+    return isinstance(t, DeviceTensor) and t.ptr == view.ptr
+
+
+def XceptionBody(input_image, num_classes, is_training=False, data_format='channels_last'):
+    """net/xception_body.py:236-379 -> (mid_outputs, outputs) as DeviceTensors (NHWC)."""
+    assert not is_training, 'forward-only path'
+    d = _det()
+    a = np.asarray(input_image, np.float32)
+    if data_format == 'channels_last':
+        a = np.transpose(a, (0, 3, 1, 2))
+    n = d.set_images(a)
+    check(lib().xdet_net_xception_body(d.handle, d._images.ptr, n, d.stream.handle))
+    _sync(d)
+    return d.buffer('mid', n), d.buffer('out', n)
+
+
+def get_rpn(net_input, num_anchors, is_training, data_format, var_scope):
+    """net/xception_body.py:381-400 -> (rpn_cls_score [N,h,w,2A], rpn_bbox_pred [N,h,w,4A])."""
+    d = _det()
+    n = net_input.shape[0]
+    if not _same(net_input, d.buffer('mid', n)):
+        raise XdetError(-1, 'get_rpn expects the mid_outputs tensor returned by XceptionBody')
+    check(lib().xdet_net_get_rpn(d.handle, n, d.stream.handle))
+    _sync(d)
+    out = d.buffer('rpn_out', n)
+    return out.channels(0, 2 * num_anchors), out.channels(2 * num_anchors, 6 * num_anchors)
+
+
+def large_sep_kernel(net_input, depth_mid, depth_output, is_training, data_format, var_scope):
+    """net/xception_body.py:450-475 -> thin feature map [N,h,w,depth_output]."""
+    d = _det()
+    n = net_input.shape[0]
+    view = d.buffer('out', n)
+    if not _same(net_input, view):
+        d.write('out', net_input.numpy() if isinstance(net_input, DeviceTensor) else net_input)
+    check(lib().xdet_net_large_sep(d.handle, n, d.stream.handle))
+    _sync(d)
+    return d.buffer('feat', n)
+
+
+def rpn_decode(rpn_cls_score, rpn_bbox_pred):
+    """light_head_rfcn_eval.py:389-397 + labels['rpn_decode_fn'] -> (objectness [N,HWA], boxes [N,HWA,4])
+    as numpy arrays; the device copies stay in the net for get_proposals."""
+    d = _det()
+    n = rpn_cls_score.shape[0]
+    check(lib().xdet_net_rpn_decode(d.handle, n, d.stream.handle))
+    _sync(d)
+    na = d.buffer('objectness', n).shape[1]
+    return d.flat('objectness', (n, na)), d.flat('rpn_boxes', (n, na, 4))
+
+
+def get_proposals(object_score, bboxes_pred, encode_fn, rpn_pre_nms_top_n, rpn_post_nms_top_n, nms_threshold,
+                  rpn_min_size, is_training, data_format):
+    """net/xception_body.py:402-448 (eval branch) -> proposals [N,post_n,4] numpy."""
+    assert not is_training, 'forward-only path'
+    d = _det()
+    assert (rpn_pre_nms_top_n, rpn_post_nms_top_n) == (d.cfg.rpn_pre_nms_top_n, d.cfg.rpn_post_nms_top_n)
+    n = object_score.shape[0]
+    d.write('objectness', np.asarray(object_score, np.float32))
+    d.write('rpn_boxes', np.asarray(bboxes_pred, np.float32))
+    check(lib().xdet_net_get_proposals(d.handle, n, d.stream.handle))
+    _sync(d)
+    return d.flat('proposals', (n, d.R, 4))
+
+
+def get_head(net_input, pooling_op, grid_width, grid_height, loss_func, proposals_bboxes, num_classes, is_training,
+             using_ohem, ohem_roi_one_image, data_format, var_scope):
+    """net/xception_body.py:477-560 (eval, no OHEM) -> (cls_score [N,R,nc], bboxes_reg [N,R,4]) numpy.
+    `pooling_op` is accepted for signature parity; the fused HIP PsRoiAlign is always used."""
+    assert not is_training and not using_ohem, 'forward-only path'
+    d = _det()
+    n = proposals_bboxes.shape[0]
+    view = d.buffer('feat', n)
+    if not _same(net_input, view):
+        d.write('feat', net_input.numpy() if isinstance(net_input, DeviceTensor) else net_input)
+    d.write('proposals', np.asarray(proposals_bboxes, np.float32))
+    check(lib().xdet_net_get_head(d.handle, n, d.stream.handle))
+    _sync(d)
+    cr = d.buffer('cls_reg', n).numpy().reshape(n, d.R, -1)
+    return cr[..., :num_classes], cr[..., num_classes:num_classes + 4]
