@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the Light-Head R-CNN forward path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--workload lighthead|resnet50]
+
+One "step" = one pass of the whole hot path (backbone + RPN + proposals + PsRoiAlign + light
+head + per-class NMS) over one batch of B synthetic 480x480 images per GPU, inputs already
+resident in HBM.  N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N`
+(one rank per GPU); images are sharded by rank (independent units, weak scaling) and the only
+exchange is one all-gather of the fixed-size padded detections per step over RCCL
+(torch.distributed backend "nccl").  Rank 0 prints ONE JSON line.
+
+Per-step timing: barrier + device sync on both sides of exactly K steps, MAX over ranks.
+roofline: the conv/dense MFMA kernel, bracketed by HIP events on its launch stream inside
+the timed region (xdet_profile_*); achieved = algorithmic dense FLOPs / summed kernel time.
+cpu_baseline: the NumPy/OpenBLAS oracle (a port of the reference graph, not the TF1 runtime,
+which cannot run here) on a bounded sample, rank 0 at N=1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'x-detector_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np   # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
+    ap.add_argument('--workload', default='lighthead', choices=['lighthead', 'resnet50'])
+    ap.add_argument('--proposals', type=int, default=300, help='rpn_post_nms_top_n (BASELINE config 3: 300)')
+    ap.add_argument('--graph', action='store_true', help='replay the forward as a hipGraph (no per-op events)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-images', type=int, default=4)
+    ap.add_argument('--ops', action='store_true', help='also print the per-op table to stderr')
+    return ap.parse_args()
+
+
+def read_profile(handle, kind):
+    from xdet._lib import lib, check
+    maxo = 512
+    n = ctypes.c_int()
+    ms = (ctypes.c_double * maxo)()
+    cnt = (ctypes.c_int * maxo)()
+    fl = (ctypes.c_double * maxo)()
+    check(lib().xdet_profile_read(handle, kind, maxo, ctypes.byref(n), ms, cnt, fl))
+    rows = []
+    buf = ctypes.create_string_buffer(256)
+    for i in range(n.value):
+        check(lib().xdet_profile_op_name(handle, kind, i, buf, 256))
+        rows.append((buf.value.decode(), ms[i], cnt[i], fl[i]))
+    return rows
+
+
+def cpu_baseline(args, weights):
+    """The oracle timed on this box's host cores (kind "port")."""
+    from oracle import lighthead_oracle as O
+    from xdet import weights as W
+    n = args.cpu_images
+    if args.workload == 'lighthead':
+        imgs = W.synthetic_images(1, 480, seed=11)
+        O.lighthead_forward(imgs, weights, rpn_post_nms_top_n=args.proposals)      # warm-up (page-in, BLAS threads)
+        t = time.time()
+        for i in range(n):
+            O.lighthead_forward(W.synthetic_images(1, 480, seed=20 + i), weights, rpn_post_nms_top_n=args.proposals)
+        dt = time.time() - t
+        what = '%d x one 480x480 image through the full forward (R=%d), NumPy fp32 + OpenBLAS' % (n, args.proposals)
+    else:
+        x = np.transpose(W.synthetic_images(1, 480, seed=11), (0, 2, 3, 1))
+        O.resnet50_trunk(x, weights)
+        t = time.time()
+        for i in range(n):
+            O.resnet50_trunk(np.transpose(W.synthetic_images(1, 480, seed=20 + i), (0, 2, 3, 1)), weights)
+        dt = time.time() - t
+        what = '%d x one 480x480 image through the ResNet-50 v2 trunk, NumPy fp32 + OpenBLAS' % n
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([d.get('num_threads', 1) for d in threadpool_info()] or [os.cpu_count()])
+    except Exception:
+        cores = os.cpu_count()
+    return {'value': round(n / dt, 3), 'unit': 'images/sec', 'cores': int(cores), 'kind': 'port', 'sample': what}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    from xdet import weights as W
+    from xdet._lib import lib, check
+    from xdet.runtime import Event
+    check(lib().xdet_set_device(local_rank))
+
+    B, K, Wm = args.batch, args.steps, args.warmup
+    if args.workload == 'lighthead':
+        from xdet.model import LightHeadDetector
+        weights = W.make_lighthead_weights(1234)
+        net = LightHeadDetector(weights, image_size=480, max_batch=B, rpn_post_nms_top_n=args.proposals)
+        kind = 0
+        fl = net.flops_per_image()
+        flops_img = sum(fl.values())
+        net.set_images(W.synthetic_images(B, 480, seed=100 + rank))
+        nc, topk = net.num_classes - 1, net.nms_topk
+        gather = None
+        if world > 1:
+            # detections land in torch-owned device memory so RCCL can gather them in place
+            loc = torch.zeros((B, nc, topk, 5), dtype=torch.float32, device='cuda')     # [score | box]
+            sc = torch.zeros((B, nc, topk), dtype=torch.float32, device='cuda')
+            bx = torch.zeros((B, nc, topk, 4), dtype=torch.float32, device='cuda')
+            allb = torch.zeros((world * B, nc, topk, 5), dtype=torch.float32, device='cuda')
+            gather = (loc, sc, bx, allb)
+
+        def step():
+            if gather is None:
+                net.forward_device(B, use_graph=args.graph)
+            else:
+                loc, sc, bx, allb = gather
+                net.forward_device(B, use_graph=args.graph, det_scores_ptr=sc.data_ptr(), det_boxes_ptr=bx.data_ptr())
+                net.stream.synchronize()
+                loc[..., 0] = sc
+                loc[..., 1:] = bx
+                dist.all_gather_into_tensor(allb, loc)
+    else:
+        from xdet.resnet import ResNet50Trunk
+        weights = W.make_resnet50_weights(4321)
+        net = ResNet50Trunk(weights, image_size=480, max_batch=B)
+        kind = 1
+        flops_img = net.flops_per_image()
+        fl = {'backbone': flops_img}
+        net.set_images(W.synthetic_images(B, 480, seed=100 + rank))
+
+        def step():
+            net.forward_device(B)
+
+    def sync_all():
+        net.stream.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(Wm):
+        step()
+    sync_all()
+    profile = not args.graph
+    if profile:
+        check(lib().xdet_profile_enable(net.handle, kind, 1))
+    ev0, ev1 = Event(), Event()
+    sync_all()
+    t0 = time.perf_counter()
+    ev0.record(net.stream)
+    for _ in range(K):
+        step()
+    ev1.record(net.stream)
+    sync_all()
+    dt = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_ms(ev1)
+    rows = read_profile(net.handle, kind) if profile else []
+    if profile:
+        check(lib().xdet_profile_enable(net.handle, kind, 0))
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / K * 1e3
+        value = world * B * K / dt
+        conv_ms = sum(r[1] for r in rows if r[3] > 0)
+        conv_launches = sum(r[2] for r in rows if r[3] > 0)
+        conv_flops = sum(r[3] * r[2] for r in rows if r[3] > 0) * B     # flops are per image, launches cover B images
+        roof = None
+        if conv_ms > 0:
+            ach = conv_flops / (conv_ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'kernel': 'conv_mfma_f32_kernel', 'achieved': round(ach, 2),
+                    'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                    'traffic': None, 'launches_per_step': conv_launches // K,
+                    'avg_launch_us': round(conv_ms * 1e3 / max(conv_launches, 1), 2),
+                    'kernel_ms_per_step': round(conv_ms / K, 3), 'gflop_per_image': round(flops_img / 1e9, 2),
+                    'how': 'HIP event pair around every conv/dense launch inside the timed region'}
+        out = {
+            'metric': 'images/sec at 480x480 Light-Head R-CNN, 1/2/4/8 MI355X + backbone MFMA util%',
+            'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': K, 'warmup': Wm,
+            'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': ('Full Light-Head R-CNN (Xception backbone + RPN + GPU proposals/NMS + PSROIAlign + '
+                                    'light head + per-class NMS), %d proposals, 480x480' % args.proposals)
+                       if args.workload == 'lighthead' else 'ResNet-50 v2 trunk only (BASELINE config 2), 480x480',
+                       'batch_per_gpu': B, 'global_batch': B * world, 'image_size': 480,
+                       'parallelism': 'image-sharded dp%d, all-gather of detections' % world,
+                       'weights': 'seeded random init (no checkpoint exists)', 'graph_replay': bool(args.graph)},
+            'device_ms_per_step': round(dev_ms / K, 3),
+            'gflop_per_image': {k: round(v / 1e9, 2) for k, v in fl.items()},
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args, weights)
+        else:
+            out['cpu_baseline'] = None
+        if args.ops and rows:
+            tot = sum(r[1] for r in rows)
+            for name, ms, cnt, f in sorted(rows, key=lambda r: -r[1]):
+                tf = (f * B * cnt / (ms * 1e-3) / 1e12) if (ms > 0 and f > 0) else 0
+                sys.stderr.write('%-52s %8.3f ms/step %5.1f%%  %7.1f TFLOP/s\n' % (name, ms / K, 100 * ms / tot, tf))
+            sys.stderr.write('planned ops %.3f ms/step of %.3f ms/step\n' % (tot / K, ms_per_step))
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

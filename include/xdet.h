@@ -158,6 +158,16 @@ int xdet_net_forward(void* net, const float* images_nchw, int N, const int* imag
 /* per-kernel accounting of the last build: total dense FLOPs (2*MAC, unpadded) of one image */
 int xdet_net_flops_per_image(void* net, double* backbone, double* rpn, double* large_sep, double* head);
 
+/* ---- per-op HIP-event timing (bench.py's roofline leg; the reference's counterpart is the
+ * commented-out tf.train.ProfilerHook, light_head_rfcn_train.py:463,522) ---------------------
+ * net_kind 0 = light-head net, 1 = resnet trunk.  While enabled every planned op (conv,
+ * depthwise, pool ...) is bracketed by an event pair on the launch stream; xdet_profile_read
+ * waits for them and returns per-op totals since the last read: ms, launch count and the
+ * algorithmic dense FLOPs of one image (0 for non-MFMA ops). */
+int xdet_profile_enable(void* net, int net_kind, int enable);
+int xdet_profile_read(void* net, int net_kind, int max_ops, int* n_ops, double* ms, int* launches, double* flops);
+int xdet_profile_op_name(void* net, int net_kind, int op, char* buf, int buflen);
+
 /* ---- A13: ResNet-50 v2 trunk (net/resnet_v2.py:311-345), BASELINE config 2 --------------- */
 int xdet_resnet_create(void** net, int image_size, int max_batch);
 int xdet_resnet_set_weight(void* net, const char* name, const float* data_host, int ndim, const int64_t* dims);

@@ -170,8 +170,12 @@ struct Op {
   std::function<int(int, hipStream_t)> run;
 };
 
+struct ProfRec { int op; hipEvent_t a, b; };
+
 struct Plan {
   int max_batch = 1;
+  bool profiling = false;
+  std::vector<ProfRec> prof;
   std::vector<void*> allocs;
   std::vector<std::unique_ptr<LayerBase>> layers;
   std::vector<Op> ops;
@@ -295,9 +299,38 @@ struct Plan {
     XDET_TRY(L->init(1, 1, in.C, cout, 1, 1, 1, 0, 0, pk->v.data(), sc.data(), sh.data(), relu_out));
     return add_conv(name + "/pointwise", stage, t, L, res, 0, out);
   }
-  int run_stage(int stage, int N, hipStream_t s) const {
-    for (const Op& op : ops)
-      if (op.stage == stage) XDET_TRY(op.run(N, s));
+  int run_stage(int stage, int N, hipStream_t s) {
+    for (size_t i = 0; i < ops.size(); ++i) {
+      const Op& op = ops[i];
+      if (op.stage != stage) continue;
+      if (profiling) {
+        ProfRec r;
+        r.op = (int)i;
+        XDET_HIP(hipEventCreate(&r.a));
+        XDET_HIP(hipEventCreate(&r.b));
+        XDET_HIP(hipEventRecord(r.a, s));
+        XDET_TRY(op.run(N, s));
+        XDET_HIP(hipEventRecord(r.b, s));
+        prof.push_back(r);
+      } else {
+        XDET_TRY(op.run(N, s));
+      }
+    }
+    return XDET_OK;
+  }
+  // drain the recorded (start, stop) event pairs into per-op totals; call after a stream sync
+  int profile_read(int max_ops, int* n_ops, double* ms, int* launches, double* flops) {
+    *n_ops = (int)std::min<size_t>(ops.size(), (size_t)max_ops);
+    for (int i = 0; i < *n_ops; ++i) { ms[i] = 0; launches[i] = 0; flops[i] = ops[i].flops; }
+    for (ProfRec& r : prof) {
+      float t = 0.f;
+      XDET_HIP(hipEventSynchronize(r.b));
+      XDET_HIP(hipEventElapsedTime(&t, r.a, r.b));
+      if (r.op < *n_ops) { ms[r.op] += t; launches[r.op] += 1; }
+      (void)hipEventDestroy(r.a);
+      (void)hipEventDestroy(r.b);
+    }
+    prof.clear();
     return XDET_OK;
   }
 };
@@ -883,6 +916,27 @@ int xdet_net_flops_per_image(void* net, double* backbone, double* rpn, double* l
   if (rpn) *rpn = f[ST_RPN];
   if (large_sep) *large_sep = f[ST_LSEP];
   if (head) *head = f[ST_HEAD];
+  return XDET_OK;
+}
+
+// mode 0 = light-head net, 1 = resnet trunk
+static Plan* as_plan(void* net, int kind) {
+  return kind == 0 ? static_cast<Plan*>(static_cast<LightHeadNet*>(net)) : static_cast<Plan*>(static_cast<ResNetTrunk*>(net));
+}
+int xdet_profile_enable(void* net, int kind, int enable) {
+  XDET_REQUIRE(net, "net is NULL");
+  as_plan(net, kind)->profiling = enable != 0;
+  return XDET_OK;
+}
+int xdet_profile_read(void* net, int kind, int max_ops, int* n_ops, double* ms, int* launches, double* flops) {
+  XDET_REQUIRE(net && n_ops && ms && launches && flops, "profile_read: NULL argument");
+  return as_plan(net, kind)->profile_read(max_ops, n_ops, ms, launches, flops);
+}
+int xdet_profile_op_name(void* net, int kind, int op, char* buf, int buflen) {
+  XDET_REQUIRE(net && buf && buflen > 0, "profile_op_name: bad arguments");
+  Plan* p = as_plan(net, kind);
+  XDET_REQUIRE(op >= 0 && op < (int)p->ops.size(), "profile_op_name: op out of range");
+  snprintf(buf, buflen, "%s", p->ops[op].name.c_str());
   return XDET_OK;
 }
 

@@ -97,6 +97,10 @@ SIGNATURES = {
     'xdet_net_bboxes_eval': (c_int, [c_void_p, c_int, PI, PF, PF, PF, c_void_p]),
     'xdet_net_forward': (c_int, [c_void_p, PF, c_int, PI, PF, PF, PF, c_int, c_void_p]),
     'xdet_net_flops_per_image': (c_int, [c_void_p] + [ctypes.POINTER(c_double)] * 4),
+    'xdet_profile_enable': (c_int, [c_void_p, c_int, c_int]),
+    'xdet_profile_read': (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_double),
+                                  ctypes.POINTER(c_int), ctypes.POINTER(c_double)]),
+    'xdet_profile_op_name': (c_int, [c_void_p, c_int, c_int, ctypes.c_char_p, c_int]),
     'xdet_resnet_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int]),
     'xdet_resnet_set_weight': (c_int, [c_void_p, ctypes.c_char_p, PF, c_int, ctypes.POINTER(c_int64)]),
     'xdet_resnet_build': (c_int, [c_void_p]),
