@@ -109,6 +109,7 @@ def main():
                                 device_id=torch.device('cuda', local_rank))
 
     from xdet import weights as W
+    from xdet import dist as xdist
     from xdet._lib import lib, check
     from xdet.runtime import Event
     check(lib().xdet_set_device(local_rank))
@@ -126,22 +127,19 @@ def main():
         gather = None
         if world > 1:
             # detections land in torch-owned device memory so RCCL can gather them in place
-            loc = torch.zeros((B, nc, topk, 5), dtype=torch.float32, device='cuda')     # [score | box]
             sc = torch.zeros((B, nc, topk), dtype=torch.float32, device='cuda')
             bx = torch.zeros((B, nc, topk, 4), dtype=torch.float32, device='cuda')
             allb = torch.zeros((world * B, nc, topk, 5), dtype=torch.float32, device='cuda')
-            gather = (loc, sc, bx, allb)
+            gather = (sc, bx, allb)
 
         def step():
             if gather is None:
                 net.forward_device(B, use_graph=args.graph)
             else:
-                loc, sc, bx, allb = gather
+                sc, bx, allb = gather
                 net.forward_device(B, use_graph=args.graph, det_scores_ptr=sc.data_ptr(), det_boxes_ptr=bx.data_ptr())
                 net.stream.synchronize()
-                loc[..., 0] = sc
-                loc[..., 1:] = bx
-                dist.all_gather_into_tensor(allb, loc)
+                xdist.gather_detections(xdist.pack_detections(sc, bx), world, allb)
     else:
         from xdet.resnet import ResNet50Trunk
         weights = W.make_resnet50_weights(4321)
@@ -182,9 +180,7 @@ def main():
         check(lib().xdet_profile_enable(net.handle, kind, 0))
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = xdist.max_over_ranks(dt, device='cuda')
 
     if rank == 0:
         ms_per_step = dt / K * 1e3

@@ -461,10 +461,14 @@ def ps_roi_align_np(inputs, rois, grid_w, grid_h, pool_method='max'):
                             x = F32(np.float64(F32(x0 + F32(step_w * F32(j)))) + np.float64(step_w) / 2.)
                             y = F32(np.float64(F32(y0 + F32(step_h * F32(i)))) + np.float64(step_h) / 2.)
                             ix, iy = int(x), int(y)
-                            fx = np.float64(F32(x - F32(ix))); fy = np.float64(F32(y - F32(iy)))
+                            fx32 = F32(x - F32(ix)); fy32 = F32(y - F32(iy))
+                            fx = np.float64(fx32); fy = np.float64(fy32)
                             iy1, ix1 = min(iy + 1, H - 1), min(ix + 1, W - 1)
+                            # C typing of ps_roi_align_op.cc:171-174: the first three products contain a
+                            # `1.` literal and are evaluated in double; the fourth (fx*fy*f11) is
+                            # float*float*float, i.e. two f32 roundings, then promoted for the sum.
                             v = (1. - fx) * (1. - fy) * np.float64(plane[iy, ix]) + (1. - fx) * fy * np.float64(plane[iy1, ix]) \
-                                + fx * (1. - fy) * np.float64(plane[iy, ix1]) + fx * fy * np.float64(plane[iy1, ix1])
+                                + fx * (1. - fy) * np.float64(plane[iy, ix1]) + np.float64(F32(F32(fx32 * fy32) * plane[iy1, ix1]))
                             t = F32(v)
                             if use_max:
                                 if acc < t:

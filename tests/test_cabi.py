@@ -1,0 +1,91 @@
+"""The C-ABI boundary without a GPU: libxdet_hip.so loads, exports every symbol include/xdet.h
+declares, the ctypes table covers exactly that set, and nothing falls back to the CPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def built():
+    from xdet import build
+    return build.build()
+
+
+def header_symbols():
+    hdr = open(os.path.join(ROOT, 'include', 'xdet.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    return set(re.findall(r'\b(xdet_[a-z0-9_]+)\s*\(', hdr))
+
+
+def test_header_ctypes_and_exports_agree(built):
+    from xdet import _lib
+    names = header_symbols()
+    assert len(names) >= 50
+    assert names == set(_lib.SIGNATURES), (names ^ set(_lib.SIGNATURES))
+    out = subprocess.check_output(['nm', '-D', '--defined-only', built]).decode()
+    exported = set(re.findall(r'\sT\s+(xdet_[a-z0-9_]+)', out))
+    assert names <= exported, names - exported
+    lib = _lib.lib()          # resolves every symbol, sets argtypes
+    assert lib.xdet_version() == 1
+
+
+def test_library_has_gfx950_code_objects(built):
+    blob = open(built, 'rb').read()
+    assert b'gfx950' in blob
+    for kern in (b'conv_mfma_f32_kernel', b'psroialign_fwd_kernel', b'nms_scan_kernel', b'bboxes_eval_kernel'):
+        assert kern in blob
+
+
+def test_config_struct_layout():
+    from xdet._lib import LightHeadConfig
+    c = LightHeadConfig()
+    assert ctypes.sizeof(c) == 13 * 4
+    assert (c.image_size, c.rpn_pre_nms_top_n, c.rpn_post_nms_top_n, c.nms_topk, c.grid, c.bank) == (480, 5000, 1000, 200, 7, 10)
+    assert abs(c.rpn_min_size - 16. / 480) < 1e-8 and abs(c.rpn_nms_thres - 0.7) < 1e-7
+
+
+def test_argument_errors_are_raised_before_any_gpu_work(built):
+    import xdet
+    feat = np.zeros((1, 8, 4, 4), np.float32)
+    with pytest.raises(xdet.InvalidArgumentError):
+        xdet.ps_roi_align(feat, np.zeros((1, 2, 4), np.float32), 2, 2, 'median')
+    with pytest.raises(xdet.InvalidArgumentError):
+        xdet.ps_roi_align(feat[0], np.zeros((1, 2, 4), np.float32), 2, 2, 'max')
+    assert issubclass(xdet.InvalidArgumentError, ValueError)
+
+
+def test_no_cpu_fallback_without_a_gpu(built):
+    """On a box without a GPU the op must fail loudly (HIP error), never compute on the host."""
+    from xdet import _lib
+    n = ctypes.c_int(0)
+    rc = _lib.lib().xdet_device_count(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip('a GPU is present')
+    import xdet
+    with pytest.raises(xdet.XdetError):
+        xdet.ps_roi_align(np.zeros((1, 4, 2, 2), np.float32), np.zeros((1, 1, 4), np.float32), 2, 2, 'max')
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from xdet import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'libxdet_hip.so'))
+    with pytest.raises(ImportError):
+        _lib.lib()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'x-detector_amd')
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), os.path.join(d, f)
+                assert 'lighthead_oracle' not in src and 'liboracle' not in src and 'psroialign_ref' not in src
+    assert 'import torch' not in open(os.path.join(pkg, 'xdet', 'model.py')).read()
