@@ -1,0 +1,30 @@
+"""ResNet-50 v2 trunk (BASELINE config 2) on the GPU vs the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_resnet50_trunk_matches_oracle(oracle):
+    from xdet import weights as W
+    from xdet.resnet import ResNet50Trunk
+    w = W.make_resnet50_weights(4321)
+    imgs = W.synthetic_images(2, 480, seed=1)
+    net = ResNet50Trunk(w, image_size=480, max_batch=2)
+    y = net.forward(imgs)
+    ref = oracle.resnet50_trunk(np.transpose(imgs, (0, 2, 3, 1)), w)
+    assert y.shape == ref.shape == (2, 15, 15, 2048)          # total stride 32 as written in the file
+    err = float(np.abs(y - ref).max())
+    assert err <= 1e-3 * max(1.0, float(np.abs(ref).max())), err
+    assert abs(net.flops_per_image() - 37.5e9) < 0.6e9
+
+
+def test_resnet50_small_image_and_batch_tail(oracle):
+    from xdet import weights as W
+    from xdet.resnet import ResNet50Trunk
+    w = W.make_resnet50_weights(4321)
+    imgs = W.synthetic_images(3, 96, seed=2)
+    net = ResNet50Trunk(w, image_size=96, max_batch=4)
+    y = net.forward(imgs)                                      # N=3 < max_batch
+    ref = oracle.resnet50_trunk(np.transpose(imgs, (0, 2, 3, 1)), w)
+    assert np.abs(y - ref).max() <= 1e-3 * max(1.0, float(np.abs(ref).max()))
