@@ -31,6 +31,7 @@ for p in (ROOT, os.path.join(ROOT, 'x-detector_amd')):
 import numpy as np   # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense f16/bf16 MFMA (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -42,6 +43,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
     ap.add_argument('--workload', default='lighthead', choices=['lighthead', 'resnet50'])
     ap.add_argument('--proposals', type=int, default=300, help='rpn_post_nms_top_n (BASELINE config 3: 300)')
+    ap.add_argument('--precision', default='f32', choices=['f32', 'f16x3', 'f16'],
+                    help='conv/dense arithmetic: exact f32 MFMA, split-precision f16 MFMA (~f32 accuracy), plain f16')
     ap.add_argument('--graph', action='store_true', help='replay the forward as a hipGraph (no per-op events)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=4)
@@ -113,6 +116,8 @@ def main():
     from xdet._lib import lib, check
     from xdet.runtime import Event
     check(lib().xdet_set_device(local_rank))
+    from xdet.runtime import set_precision
+    set_precision(args.precision)
 
     B, K, Wm = args.batch, args.steps, args.warmup
     if args.workload == 'lighthead':
@@ -191,8 +196,11 @@ def main():
         roof = None
         if conv_ms > 0:
             ach = conv_flops / (conv_ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'conv_mfma_f32_kernel', 'achieved': round(ach, 2),
-                    'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            peak = PEAK_F32_MFMA_TFLOPS if args.precision == 'f32' else PEAK_F16_MFMA_TFLOPS
+            kname = 'conv_mfma_f32_kernel' if args.precision == 'f32' else 'conv_mfma_split_kernel'
+            roof = {'bound': 'mfma', 'kernel': kname, 'achieved': round(ach, 2),
+                    'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                    'mfma_issued_tflops': round(ach * (3 if args.precision == 'f16x3' else 1), 2),
                     'traffic': None, 'launches_per_step': conv_launches // K,
                     'avg_launch_us': round(conv_ms * 1e3 / max(conv_launches, 1), 2),
                     'kernel_ms_per_step': round(conv_ms / K, 3), 'gflop_per_image': round(flops_img / 1e9, 2),
@@ -201,7 +209,8 @@ def main():
             'metric': 'images/sec at 480x480 Light-Head R-CNN, 1/2/4/8 MI355X + backbone MFMA util%',
             'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': K, 'warmup': Wm,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': {'f32': 'f32', 'f16x3': 'f16x3 (split-precision f16 MFMA, f32 accumulate, f32 activations)',
+                      'f16': 'f16'}[args.precision], 'data': 'synthetic',
             'config': {'workload': ('Full Light-Head R-CNN (Xception backbone + RPN + GPU proposals/NMS + PSROIAlign + '
                                     'light head + per-class NMS), %d proposals, 480x480' % args.proposals)
                        if args.workload == 'lighthead' else 'ResNet-50 v2 trunk only (BASELINE config 2), 480x480',

@@ -33,6 +33,13 @@ const char* xdet_last_error(void);
 int xdet_version(void);
 int xdet_device_count(int* n);
 int xdet_set_device(int dev);
+/* Arithmetic of the conv / dense contractions for layers and nets created AFTER the call:
+ *   0 = f32 MFMA (v_mfma_f32_32x32x2_f32, exact f32 FMA chains; default)
+ *   1 = f16x3: operands split into f16 hi+lo parts, three v_mfma_f32_32x32x16_f16 per product
+ *       block, f32 accumulate (~2^-21 relative per product: f32-class accuracy on the 2.5 PFLOP/s pipe)
+ *   2 = plain f16 operands (speed mode; drifts beyond 1e-3 through the 40-layer stack) */
+int xdet_set_default_precision(int mode);
+int xdet_get_default_precision(void);
 
 /* ---- memory / streams (what TF's allocator and stream executor did for the op) ---------- */
 int xdet_malloc(void** dptr, size_t bytes);

@@ -27,8 +27,16 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=['f32', 'f16x3'])
+def precision(request):
+    from xdet.runtime import set_precision
+    set_precision(request.param)
+    yield request.param
+    set_precision('f32')
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv_matches_oracle(case, oracle):
+def test_conv_matches_oracle(case, oracle, precision):
     from xdet.ops import Conv2D
     from xdet.runtime import DeviceTensor
     N, H, W, cin, cout, kh, kw, stride, padding, dil = case
@@ -40,14 +48,35 @@ def test_conv_matches_oracle(case, oracle):
     ref = oracle.conv2d(x, k, stride, padding, dil) * scale + shift
     y = Conv2D(k, stride, padding, dil, scale, shift)(DeviceTensor.from_numpy(x)).numpy()
     assert y.shape == ref.shape
-    close(y, ref)
+    tol = 2e-5 if precision == 'f32' else 3e-5      # f16x3: ~2^-21 per product on top of summation order
+    close(y, ref, tol)
     # fused residual + ReLU, and ReLU applied to the input on load
     res = rng.standard_normal(ref.shape).astype(np.float32)
     ref2 = np.maximum(oracle.conv2d(np.maximum(x, 0), k, stride, padding, dil) * scale + shift + res, 0)
     y2 = Conv2D(k, stride, padding, dil, scale, shift, relu=True)(DeviceTensor.from_numpy(x),
                                                                    residual=DeviceTensor.from_numpy(res),
                                                                    relu_in=True).numpy()
-    close(y2, ref2)
+    close(y2, ref2, tol)
+
+
+def test_plain_f16_mode_is_an_f16_gemm(oracle):
+    """precision 'f16' == f32-accumulated product of f16-rounded operands (speed mode)."""
+    from xdet.ops import Conv2D
+    from xdet.runtime import DeviceTensor, set_precision
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((1, 30, 30, 256)).astype(np.float32)
+    k = (rng.standard_normal((1, 1, 256, 128)) / 16).astype(np.float32)
+    set_precision('f16')
+    try:
+        y = Conv2D(k, 1, 'SAME')(DeviceTensor.from_numpy(x)).numpy()
+    finally:
+        set_precision('f32')
+    rb = lambda a: a.astype(np.float16).astype(np.float32)
+    # weights are pre-scaled per output channel by a power of two before rounding: same rounding as
+    # plain f16 for normal numbers
+    ref = oracle.conv2d(rb(x), rb(k * 1024) / 1024, 1, 'SAME')
+    close(y, ref, 2e-5)
+    assert np.abs(y - oracle.conv2d(x, k, 1, 'SAME')).max() > 1e-4      # and it is NOT f32-accurate
 
 
 def test_conv_explicit_padding_resnet_stem(oracle):

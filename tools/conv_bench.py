@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the conv/dense MFMA kernel on the network's own GEMM shapes (GPU box only).
+    python tools/conv_bench.py --precision f16x3 --batch 8"""
+import argparse
+import os
+import sys
+
+R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R_)
+sys.path.insert(0, os.path.join(R_, 'x-detector_amd'))
+import numpy as np                                        # noqa: E402
+from xdet.ops import Conv2D                               # noqa: E402
+from xdet.runtime import DeviceTensor, Event, Stream, set_precision   # noqa: E402
+
+SHAPES = [  # name, H, W, cin, cout, kh, kw, stride, pad
+    ('block1_conv2 3x3 32->64 @239', 239, 239, 32, 64, 3, 3, 1, 'VALID'),
+    ('block2 pw 128->128 @237', 237, 237, 128, 128, 1, 1, 1, 'SAME'),
+    ('block3 pw 256->256 @119', 119, 119, 256, 256, 1, 1, 1, 'SAME'),
+    ('block4 pw 728->728 @60', 60, 60, 728, 728, 1, 1, 1, 'SAME'),
+    ('mid pw 728->728 @30', 30, 30, 728, 728, 1, 1, 1, 'SAME'),
+    ('b14 pw 1536->2048 @30', 30, 30, 1536, 2048, 1, 1, 1, 'SAME'),
+    ('rpn 3x3 728->512 @30', 30, 30, 728, 512, 3, 3, 1, 'SAME'),
+    ('lsep 15x1 2048->512 @30', 30, 30, 2048, 512, 15, 1, 1, 'SAME'),
+    ('lsep 1x15 512->490 @30', 30, 30, 512, 490, 1, 15, 1, 'SAME'),
+    ('fc 490->2048 (R=300)', 300, 1, 490, 2048, 1, 1, 1, 'VALID'),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--precision', default='f32')
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--iters', type=int, default=20)
+    a = ap.parse_args()
+    set_precision(a.precision)
+    rng = np.random.default_rng(0)
+    st = Stream()
+    tot_f = tot_t = 0
+    for name, H, W, cin, cout, kh, kw, s, pad in SHAPES:
+        x = DeviceTensor.from_numpy(rng.standard_normal((a.batch, H, W, cin)).astype(np.float32))
+        k = (rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)).astype(np.float32)
+        L = Conv2D(k, s, pad)
+        y = L(x, stream=st)
+        st.synchronize()
+        e0, e1 = Event(), Event()
+        from xdet._lib import lib, check
+        e0.record(st)
+        for _ in range(a.iters):
+            check(lib().xdet_conv_forward(L.handle, x.ptr, a.batch, H, W, x.ld, y.ptr, y.ld, None, 0, st.handle))
+        e1.record(st)
+        st.synchronize()
+        ms = e0.elapsed_ms(e1) / a.iters
+        fl = 2.0 * a.batch * y.shape[1] * y.shape[2] * cin * cout * kh * kw
+        tot_f += fl
+        tot_t += ms
+        print('%-34s %8.3f ms  %7.1f TFLOP/s' % (name, ms, fl / ms / 1e9))
+    print('%-34s %8.3f ms  %7.1f TFLOP/s' % ('TOTAL', tot_t, tot_f / tot_t / 1e9))
+
+
+if __name__ == '__main__':
+    main()

@@ -39,7 +39,9 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // ---- implicit-GEMM convolution on the f32 MFMA pipe (conv_mfma.hip) -------------------
 struct ConvParams {
   const float* in;   // NHWC, channel stride ldi (padded channels are zero)
-  const float* wt;   // [Cout_pad][Kp], K contiguous, k = tap*Cin_p + ci
+  const float* wt;   // [Cout_pad][Kp], K contiguous, k = tap*Cin_p + ci   (f32 path)
+  const unsigned short* wt_hi;   // f16 planes of the (per-channel power-of-two scaled) matrix: split path
+  const unsigned short* wt_lo;
   float* out;        // NHWC, channel stride ldo
   const float* scale;   // [Cout_pad] folded BN scale (1 for plain bias)
   const float* shift;   // [Cout_pad] folded BN shift / bias
@@ -54,6 +56,9 @@ struct ConvParams {
   int relu_in, relu_out;
 };
 int launch_conv_mfma_f32(const ConvParams& p, bool small_cin, int n_tile, hipStream_t s);
+// nsplit 3 = f16x3 (hi/lo f16 operands, f32-class accuracy), 1 = plain f16 operands
+int launch_conv_mfma_split(const ConvParams& p, bool small_cin, int n_tile, int nsplit, hipStream_t s);
+enum { PREC_F32 = 0, PREC_F16X3 = 1, PREC_F16 = 2 };
 
 // ---- element-wise / window kernels (elementwise.hip) ---------------------------------
 int launch_nchw_to_nhwc4(const float* in, float* out, int N, int C, int H, int W, int ldo, hipStream_t s);

@@ -1,0 +1,275 @@
+// Implicit-GEMM convolution / dense layer on the gfx950 16-bit MFMA pipe (2.5 PFLOP/s dense) with
+// SPLIT-PRECISION f16 operands ("f16x3"), so the fast matrix pipe can be used without leaving the
+// 1e-3 parity budget of the fp32 reference graph:
+//
+//     a = a_hi + a_lo,  w = w_hi + w_lo     (each part f16, x_lo = f16(x - x_hi))
+//     a*w ~= a_hi*w_hi + a_hi*w_lo + a_lo*w_hi         (dropped a_lo*w_lo <= 2^-22 |a*w|)
+//
+// three v_mfma_f32_32x32x16_f16 per product block, f32 accumulation inside the MFMA.  f16 parts
+// carry 11+11 significant bits, so a product is good to ~2^-21 -- f32-class accuracy (plain f16 or
+// bf16 operands lose 3-4 digits per layer and miss the 1e-3 tolerance after ~40 stacked layers).
+// Range: weights are pre-scaled per output channel by a power of two so that max|w| ~ 2^10 (w_lo
+// then stays a normal f16); the scale is folded back, exactly, into the epilogue scale.
+// Activations must stay below 65504 in magnitude (BN-normalised nets are O(1..100)).
+// NSPLIT = 1 is the plain-f16 speed mode (hi*hi only), kept for drift measurement.
+//
+// Activations stay f32 NHWC in HBM (every other kernel is unchanged): the im2col gather reads f32,
+// splits in registers and stages hi/lo planes in LDS.  Weights are split once on the host into two
+// f16 [Cout_pad][Kp] arrays.  LDS rows are 32 halves + 8 pad (80 B): every MFMA operand is one
+// conflict-free ds_read_b128 (8 consecutive k per lane).  Global tiles are prefetched TWO K-steps
+// ahead in two register sets (the compute of one 32-deep step is too short to cover L2/HBM
+// latency on its own), LDS is double-buffered: one barrier per K-step.
+#include "common.h"
+
+namespace xdet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+constexpr int BKH = 32;      // K step (16-bit elements)
+constexpr int LDH = 40;      // u16 per LDS row: 32 + 8 pad = 80 B
+
+__device__ __forceinline__ void split4(const float4 v, uint2* hi, uint2* lo) {
+  const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y, h2 = (_Float16)v.z, h3 = (_Float16)v.w;
+  f16x4 hv = {h0, h1, h2, h3};
+  f16x4 lv = {(_Float16)(v.x - (float)h0), (_Float16)(v.y - (float)h1), (_Float16)(v.z - (float)h2),
+              (_Float16)(v.w - (float)h3)};
+  *hi = *reinterpret_cast<uint2*>(&hv);
+  *lo = *reinterpret_cast<uint2*>(&lv);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool SMALL_CIN, int NSPLIT>
+__global__ __launch_bounds__(256) void conv_mfma_f16_kernel(ConvParams p) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_IT = BM / 32;        // float4 gathers per thread per K step
+  constexpr int B_IT = BN / 64;        // 16-B weight chunks per thread per K step (per plane)
+  constexpr int STAGE = (2 * BM + 2 * BN) * LDH;   // u16 per stage
+
+  extern __shared__ __attribute__((aligned(16))) u16 smem16[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  const int lrow = tid >> 3, kq = tid & 7;       // A gather: 8 float4 per 32-wide row slice
+  const int brow = tid >> 2, bch = tid & 3;      // B copy: 4 x 16 B per row
+
+  int iy0[A_IT], ix0[A_IT], pbase[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    if (m < p.M) {
+      const int hw = p.Ho * p.Wo;
+      const int n = m / hw;
+      const int rem = m - n * hw;
+      const int oy = rem / p.Wo;
+      const int ox = rem - oy * p.Wo;
+      iy0[i] = oy * p.stride - p.pad_t;
+      ix0[i] = ox * p.stride - p.pad_l;
+      pbase[i] = n * p.H * p.W;
+    } else {
+      iy0[i] = -(1 << 28);
+      ix0[i] = 0;
+      pbase[i] = 0;
+    }
+  }
+
+  struct Regs {
+    float4 a[A_IT];
+    uint4 bh[B_IT], bl[B_IT];
+  };
+  const int nk = p.Kp / BKH;
+
+  auto load_global = [&](int kt, Regs& r) {
+    int dy, dx, coff;
+    bool tap_ok = true;
+    if (SMALL_CIN) {
+      const int tap = kt * 8 + kq;
+      tap_ok = tap < p.KH * p.KW;
+      const int ky = tap / p.KW;
+      dy = ky * p.dil;
+      dx = (tap - ky * p.KW) * p.dil;
+      coff = 0;
+    } else {
+      const int k0 = kt * BKH;
+      const int tap = k0 / p.Cin_p;
+      const int ky = tap / p.KW;
+      dy = ky * p.dil;
+      dx = (tap - ky * p.KW) * p.dil;
+      coff = k0 - tap * p.Cin_p + 4 * kq;
+    }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+        v = *reinterpret_cast<const float4*>(p.in + ((size_t)(pbase[i] + iy * p.W + ix) * p.ldi + coff));
+      r.a[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const size_t off = (size_t)(n0 + brow + 64 * i) * p.Kp + kt * BKH + 8 * bch;
+      r.bh[i] = *reinterpret_cast<const uint4*>(p.wt_hi + off);
+      if (NSPLIT > 1) r.bl[i] = *reinterpret_cast<const uint4*>(p.wt_lo + off);
+    }
+  };
+  auto store_lds = [&](int buf, const Regs& r) {
+    u16* Ah = smem16 + buf * STAGE;
+    u16* Al = Ah + BM * LDH;
+    u16* Bh = Al + BM * LDH;
+    u16* Bl = Bh + BN * LDH;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      float4 v = r.a[i];
+      if (p.relu_in) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      uint2 hi, lo;
+      split4(v, &hi, &lo);
+      const int o = (lrow + 32 * i) * LDH + 4 * kq;
+      *reinterpret_cast<uint2*>(Ah + o) = hi;
+      if (NSPLIT > 1) *reinterpret_cast<uint2*>(Al + o) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int o = (brow + 64 * i) * LDH + 8 * bch;
+      *reinterpret_cast<uint4*>(Bh + o) = r.bh[i];
+      if (NSPLIT > 1) *reinterpret_cast<uint4*>(Bl + o) = r.bl[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31;
+  const int fh = lane >> 5;
+
+  auto compute = [&](int buf) {
+    const u16* Ah = smem16 + buf * STAGE + (wm * WM + frow) * LDH + fh * 8;
+    const u16* Al = Ah + BM * LDH;
+    const u16* Bh = smem16 + buf * STAGE + 2 * BM * LDH + (wn * WN + frow) * LDH + fh * 8;
+    const u16* Bl = Bh + BN * LDH;
+#pragma unroll
+    for (int ks = 0; ks < BKH / 16; ++ks) {
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(Ah + i * 32 * LDH + ks * 16);
+        if (NSPLIT > 1) al[i] = *reinterpret_cast<const f16x8*>(Al + i * 32 * LDH + ks * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const f16x8*>(Bh + j * 32 * LDH + ks * 16);
+        if (NSPLIT > 1) bl[j] = *reinterpret_cast<const f16x8*>(Bl + j * 32 * LDH + ks * 16);
+      }
+      // small cross terms first, the dominant hi*hi term last
+      if (NSPLIT > 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // two register sets: tile kt+2 is requested while tile kt is multiplied and tile kt+1 waits in
+  // the other set for its turn to be split and stored
+  Regs r0, r1;
+  load_global(0, r0);
+  if (nk > 1) load_global(1, r1);
+  store_lds(0, r0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 2 < nk) load_global(kt + 2, r0);
+    compute(0);
+    if (kt + 1 < nk) store_lds(1, r1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    if (kt + 3 < nk) load_global(kt + 3, r1);
+    compute(1);
+    if (kt + 2 < nk) store_lds(0, r0);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + wn * WN + j * 32 + frow;
+    if (co >= p.ldo) continue;
+    const float sc = p.scale[co], sh = p.shift[co];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (m < p.M) {
+          float v = fmaf(acc[i][j][r], sc, sh);
+          if (p.res) v += p.res[(size_t)m * p.ldr + co];
+          if (p.relu_out) v = fmaxf(v, 0.f);
+          p.out[(size_t)m * p.ldo + co] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool SMALL_CIN, int NSPLIT>
+static int launch_b(const ConvParams& p, hipStream_t s) {
+  constexpr size_t lds = (size_t)2 * (2 * BM + 2 * BN) * LDH * sizeof(u16);
+  auto kern = conv_mfma_f16_kernel<BM, BN, WAVES_M, WAVES_N, SMALL_CIN, NSPLIT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    XDET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)cdiv(p.M, BM), (unsigned)(p.Cout_pad / BN));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
+template <int NSPLIT>
+static int dispatch(const ConvParams& p, bool small_cin, int n_tile, hipStream_t s) {
+  if (n_tile == 128)
+    return small_cin ? launch_b<128, 128, 2, 2, true, NSPLIT>(p, s) : launch_b<128, 128, 2, 2, false, NSPLIT>(p, s);
+  if (n_tile == 64)
+    return small_cin ? launch_b<128, 64, 4, 1, true, NSPLIT>(p, s) : launch_b<128, 64, 4, 1, false, NSPLIT>(p, s);
+  set_last_error("conv: unsupported N tile");
+  return XDET_ERR_UNSUPPORTED;
+}
+
+int launch_conv_mfma_split(const ConvParams& p, bool small_cin, int n_tile, int nsplit, hipStream_t s) {
+  XDET_REQUIRE(p.Kp % BKH == 0, "conv: Kp must be a multiple of 32");
+  XDET_REQUIRE(p.Cout_pad % n_tile == 0, "conv: Cout_pad must be a multiple of the N tile");
+  XDET_REQUIRE(small_cin || (p.Cin_p % BKH == 0 && p.ldi >= p.Cin_p), "conv: Cin_p must be a multiple of 32 and <= ldi");
+  XDET_REQUIRE(!small_cin || (p.Cin_p == 4 && p.ldi == 4), "conv: small-cin mode needs 4-channel input");
+  XDET_REQUIRE(p.wt_hi != nullptr && (nsplit == 1 || p.wt_lo != nullptr), "conv: f16 weight planes missing");
+  if (p.M <= 0) return XDET_OK;
+  return nsplit == 1 ? dispatch<1>(p, small_cin, n_tile, s) : dispatch<3>(p, small_cin, n_tile, s);
+}
+
+}  // namespace xdet

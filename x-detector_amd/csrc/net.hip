@@ -41,6 +41,38 @@ static int upload(const std::vector<float>& h, float** d) {
   return XDET_OK;
 }
 
+static int g_default_precision = PREC_F32;
+
+static inline unsigned short f32_to_f16_rne(float f) {
+  unsigned x;
+  memcpy(&x, &f, 4);
+  const unsigned sign = (x >> 16) & 0x8000u;
+  x &= 0x7FFFFFFFu;
+  if (x >= 0x47800000u) return (unsigned short)(sign | (x > 0x7F800000u ? 0x7E00u : 0x7C00u));   // inf / nan
+  if (x < 0x38800000u) {                       // below 2^-14: subnormal half = round(|f| * 2^24)
+    float af;
+    memcpy(&af, &x, 4);
+    return (unsigned short)(sign | (unsigned)lrintf(af * 16777216.0f));
+  }
+  const unsigned mant = x & 0x7FFFFFu, exp = (x >> 23) - 127 + 15;
+  unsigned h = (exp << 10) | (mant >> 13);
+  const unsigned rem = mant & 0x1FFFu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;      // round to nearest even (may carry to inf)
+  return (unsigned short)(sign | h);
+}
+static inline float f16_to_f32(unsigned short h) {
+  const unsigned sign = (unsigned)(h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+  float v;
+  if (e == 0) v = ldexpf((float)m, -24);
+  else if (e == 31) v = m ? NAN : INFINITY;
+  else v = ldexpf((float)(m | 0x400u), (int)e - 25);
+  unsigned u;
+  memcpy(&u, &v, 4);
+  u |= sign;
+  memcpy(&v, &u, 4);
+  return v;
+}
+
 static void same_pad(int n, int k, int s, int d, int* before, int* out) {
   const int k_eff = (k - 1) * d + 1;
   *out = (n + s - 1) / s;
@@ -60,9 +92,13 @@ struct ConvLayer : LayerBase {
   int kh, kw, cin, cout, stride, dil, pad_mode, pad_t, pad_l, relu_out;
   int cin_p, kp, cout_pad, n_tile;
   bool small_cin;
+  int precision = PREC_F32;
   float *d_wt = nullptr, *d_scale = nullptr, *d_shift = nullptr;
+  unsigned short *d_wt_hi = nullptr, *d_wt_lo = nullptr;
 
   ~ConvLayer() override {
+    if (d_wt_hi) (void)hipFree(d_wt_hi);
+    if (d_wt_lo) (void)hipFree(d_wt_lo);
     if (d_wt) (void)hipFree(d_wt);
     if (d_scale) (void)hipFree(d_scale);
     if (d_shift) (void)hipFree(d_shift);
@@ -91,7 +127,34 @@ struct ConvLayer : LayerBase {
       sc[co] = scale ? scale[co] : 1.f;
       sh[co] = shift ? shift[co] : 0.f;
     }
-    XDET_TRY(upload(wt, &d_wt));
+    precision = g_default_precision;
+    if (precision == PREC_F32) {
+      XDET_TRY(upload(wt, &d_wt));
+    } else {
+      // per-output-channel power-of-two pre-scale so that max|w| lands in [512, 1024): w_hi cannot
+      // overflow f16 and w_lo (~2^-11 |w|) stays a normal f16; undone exactly in the epilogue scale
+      std::vector<unsigned short> hi(wt.size()), lo(wt.size());
+      for (int co = 0; co < cout_pad; ++co) {
+        float mx = 0.f;
+        for (int k = 0; k < kp; ++k) mx = std::max(mx, std::fabs(wt[(size_t)co * kp + k]));
+        int e = 0;
+        if (mx > 0.f) (void)frexpf(mx, &e);
+        const int sh_k = mx > 0.f ? 10 - e : 0;
+        for (int k = 0; k < kp; ++k) {
+          const float wv = ldexpf(wt[(size_t)co * kp + k], sh_k);
+          const unsigned short h = f32_to_f16_rne(wv);
+          hi[(size_t)co * kp + k] = h;
+          lo[(size_t)co * kp + k] = f32_to_f16_rne(wv - f16_to_f32(h));
+        }
+        sc[co] = ldexpf(sc[co], -sh_k);
+      }
+      XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_wt_hi), hi.size() * 2));
+      XDET_HIP(hipMemcpy(d_wt_hi, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
+      if (precision == PREC_F16X3) {
+        XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_wt_lo), lo.size() * 2));
+        XDET_HIP(hipMemcpy(d_wt_lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+      }
+    }
     XDET_TRY(upload(sc, &d_scale));
     XDET_TRY(upload(sh, &d_shift));
     return XDET_OK;
@@ -123,7 +186,7 @@ struct ConvLayer : LayerBase {
     XDET_REQUIRE(ldi == ld_in(), "conv: ld_in must be round_up(cin,32) (4 for cin<=4)");
     XDET_REQUIRE(ldo == ld_out(), "conv: ld_out must be round_up(cout,32)");
     ConvParams p;
-    p.in = in; p.wt = d_wt; p.out = out; p.scale = d_scale; p.shift = d_shift; p.res = res;
+    p.in = in; p.wt = d_wt; p.wt_hi = d_wt_hi; p.wt_lo = d_wt_lo; p.out = out; p.scale = d_scale; p.shift = d_shift; p.res = res;
     p.N = N; p.H = H; p.W = W; p.ldi = ldi; p.ldo = ldo; p.ldr = ldo;
     out_shape(H, W, &p.Ho, &p.Wo, &p.pad_t, &p.pad_l);
     XDET_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv: empty output");
@@ -131,7 +194,8 @@ struct ConvLayer : LayerBase {
     p.KH = kh; p.KW = kw; p.stride = stride; p.dil = dil;
     p.M = N * p.Ho * p.Wo;
     p.relu_in = relu_in; p.relu_out = relu_out;
-    return launch_conv_mfma_f32(p, small_cin, n_tile, s);
+    if (precision == PREC_F32) return launch_conv_mfma_f32(p, small_cin, n_tile, s);
+    return launch_conv_mfma_split(p, small_cin, n_tile, precision == PREC_F16X3 ? 3 : 1, s);
   }
 };
 
@@ -696,6 +760,12 @@ const char* xdet_last_error(void) { return g_last_error.c_str(); }
 int xdet_version(void) { return 1; }
 int xdet_device_count(int* n) { XDET_HIP(hipGetDeviceCount(n)); return XDET_OK; }
 int xdet_set_device(int dev) { XDET_HIP(hipSetDevice(dev)); return XDET_OK; }
+int xdet_set_default_precision(int mode) {
+  XDET_REQUIRE(mode == PREC_F32 || mode == PREC_F16X3 || mode == PREC_F16, "precision must be 0 (f32), 1 (f16x3) or 2 (f16)");
+  g_default_precision = mode;
+  return XDET_OK;
+}
+int xdet_get_default_precision(void) { return g_default_precision; }
 
 int xdet_malloc(void** dptr, size_t bytes) { XDET_REQUIRE(dptr, "dptr is NULL"); XDET_HIP(hipMalloc(dptr, std::max<size_t>(bytes, 16))); return XDET_OK; }
 int xdet_free(void* dptr) { if (dptr) XDET_HIP(hipFree(dptr)); return XDET_OK; }

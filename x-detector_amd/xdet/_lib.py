@@ -53,6 +53,8 @@ SIGNATURES = {
     'xdet_version': (c_int, []),
     'xdet_device_count': (c_int, [ctypes.POINTER(c_int)]),
     'xdet_set_device': (c_int, [c_int]),
+    'xdet_set_default_precision': (c_int, [c_int]),
+    'xdet_get_default_precision': (c_int, []),
     'xdet_malloc': (c_int, [ctypes.POINTER(c_void_p), c_size_t]),
     'xdet_free': (c_int, [c_void_p]),
     'xdet_memset': (c_int, [c_void_p, c_int, c_size_t, c_void_p]),

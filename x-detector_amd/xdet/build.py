@@ -11,6 +11,7 @@ LIB = os.path.join(HERE, 'libxdet_hip.so')
 # rounded f32 operations, so those translation units are compiled without FMA contraction.
 SOURCES = [
     ('conv_mfma.hip', []),
+    ('conv_mfma_split.hip', []),
     ('elementwise.hip', []),
     ('psroialign.hip', ['-ffp-contract=off']),
     ('proposals.hip', ['-ffp-contract=off']),

@@ -33,6 +33,21 @@ def channel_ld(c):
     return 4 if c <= 4 else round_up(c, 32)
 
 
+PRECISIONS = {'f32': 0, 'f16x3': 1, 'f16': 2}
+
+
+def set_precision(mode):
+    """arithmetic of the conv/dense contractions for layers and nets created afterwards:
+    'f32' (exact f32 MFMA, default), 'f16x3' (split-precision f16 MFMA, ~f32 accuracy) or
+    'f16' (plain f16 operands: speed mode, outside the 1e-3 parity budget)."""
+    check(lib().xdet_set_default_precision(PRECISIONS[mode]))
+
+
+def get_precision():
+    v = lib().xdet_get_default_precision()
+    return [k for k, x in PRECISIONS.items() if x == v][0]
+
+
 class Stream(object):
     def __init__(self):
         h = c_void_p()
