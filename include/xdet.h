@@ -85,6 +85,14 @@ int xdet_conv_create(void** layer, int kh, int kw, int cin, int cout, int stride
 int xdet_conv_forward(void* layer, const float* in, int N, int H, int W, int ld_in, float* out, int ld_out,
                       const float* residual, int relu_in, void* stream);
 int xdet_conv_out_shape(void* layer, int H, int W, int* Ho, int* Wo);
+/* Split-precision operand planes (modes 1/2): x = hi + lo, both f16, same NHWC layout / ld as x.
+ * xdet_split_f32 writes them element-wise (optionally through a ReLU); xdet_conv_forward_planes runs a
+ * layer whose A operand already lives as planes (LDS-DMA kernel, no register staging).  Inside a
+ * net the depthwise kernels and split passes produce the planes; these two entry points expose the
+ * same kernels for tests. */
+int xdet_split_f32(const float* in, uint16_t* hi, uint16_t* lo, int64_t n, int relu, void* stream);
+int xdet_conv_forward_planes(void* layer, const uint16_t* in_hi, const uint16_t* in_lo, int N, int H, int W,
+                             int ld_in, float* out, int ld_out, const float* residual, void* stream);
 int xdet_layer_destroy(void* layer);
 /* depthwise 3x3 SAME stride 1 (the depthwise half of tf.layers.separable_conv2d,
  * net/xception_body.py:224-231); dw_kernel_host f32 [3,3,C,1]; in/out NHWC with stride ld. */

@@ -57,6 +57,14 @@ def test_conv_matches_oracle(case, oracle, precision):
                                                                    residual=DeviceTensor.from_numpy(res),
                                                                    relu_in=True).numpy()
     close(y2, ref2, tol)
+    if precision != 'f32' and cin >= 32 and stride == 1:
+        # the same layer through pre-split f16 planes + LDS DMA (what a net uses for big contractions)
+        y3 = Conv2D(k, stride, padding, dil, scale, shift, relu=True)(DeviceTensor.from_numpy(x),
+                                                                       residual=DeviceTensor.from_numpy(res),
+                                                                       relu_in=True, planes=True).numpy()
+        close(y3, ref2, tol)
+        y4 = Conv2D(k, stride, padding, dil, scale, shift)(DeviceTensor.from_numpy(x), planes=True).numpy()
+        close(y4, ref, tol)
 
 
 def test_plain_f16_mode_is_an_f16_gemm(oracle):

@@ -31,12 +31,15 @@ def main():
     ap.add_argument('--precision', default='f32')
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--only', default='')
     a = ap.parse_args()
     set_precision(a.precision)
     rng = np.random.default_rng(0)
     st = Stream()
     tot_f = tot_t = 0
     for name, H, W, cin, cout, kh, kw, s, pad in SHAPES:
+        if a.only and a.only not in name:
+            continue
         x = DeviceTensor.from_numpy(rng.standard_normal((a.batch, H, W, cin)).astype(np.float32))
         k = (rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)).astype(np.float32)
         L = Conv2D(k, s, pad)

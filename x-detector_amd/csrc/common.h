@@ -42,6 +42,9 @@ struct ConvParams {
   const float* wt;   // [Cout_pad][Kp], K contiguous, k = tap*Cin_p + ci   (f32 path)
   const unsigned short* wt_hi;   // f16 planes of the (per-channel power-of-two scaled) matrix: split path
   const unsigned short* wt_lo;
+  const unsigned short* in_hi;   // A operand already split into f16 planes (conv_mfma_dma.hip), same NHWC/ldi
+  const unsigned short* in_lo;
+  const unsigned short* zeros;   // >= 16 B of zeros: the source of out-of-image taps for the LDS DMA
   float* out;        // NHWC, channel stride ldo
   const float* scale;   // [Cout_pad] folded BN scale (1 for plain bias)
   const float* shift;   // [Cout_pad] folded BN shift / bias
@@ -58,6 +61,7 @@ struct ConvParams {
 int launch_conv_mfma_f32(const ConvParams& p, bool small_cin, int n_tile, hipStream_t s);
 // nsplit 3 = f16x3 (hi/lo f16 operands, f32-class accuracy), 1 = plain f16 operands
 int launch_conv_mfma_split(const ConvParams& p, bool small_cin, int n_tile, int nsplit, hipStream_t s);
+int launch_conv_mfma_dma(const ConvParams& p, int n_tile, int nsplit, hipStream_t s);
 enum { PREC_F32 = 0, PREC_F16X3 = 1, PREC_F16 = 2 };
 
 // ---- element-wise / window kernels (elementwise.hip) ---------------------------------
@@ -67,6 +71,9 @@ int launch_depthwise3x3(const float* in, const float* w9c, float* out, int N, in
 int launch_maxpool3x3s2_add(const float* in, const float* res, float* out, int N, int H, int W, int C, int ld,
                             int Ho, int Wo, int pad_t, int pad_l, hipStream_t s);
 int launch_relu_copy(const float* in, float* out, int64_t n, hipStream_t s);
+int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, int64_t n, int relu, hipStream_t s);
+int launch_depthwise3x3_split(const float* in, const float* w9c, unsigned short* hi, unsigned short* lo, int N,
+                              int H, int W, int C, int ld, int dil, int relu_in, hipStream_t s);
 
 // ---- PsRoiAlign (psroialign.hip) -------------------------------------------------------
 int launch_psroialign(const float* feat, const float* rois, float* pooled, int32_t* index, int N, int C, int H,

@@ -1,0 +1,229 @@
+// Implicit-GEMM convolution / dense layer, split-precision f16x3 on the 16-bit MFMA pipe, for
+// activations that ALREADY live in HBM as two f16 planes (hi, lo) -- written that way by the
+// producing kernel (depthwise conv, split pass) so that the split costs VALU work once per
+// element instead of once per N-tile, and the im2col gather needs no registers at all:
+//
+//   * every operand tile goes HBM/L2 -> LDS by `global_load_lds_dwordx4` (16 B per lane, no VGPR
+//     round trip); out-of-image taps and the M tail read a zero page instead of branching;
+//   * LDS tiles are dense [row][32 halves] (the DMA destination is lane-linear), made
+//     conflict-free for the MFMA operand reads by permuting the 16-B chunks of a row with
+//     (row>>2)&3 on the SOURCE address and undoing it on the ds_read_b128 address;
+//   * two LDS stages (64 KB for a 128x128 tile -> two workgroups per CU), one barrier per
+//     32-deep K step: the DMA of step k+1 flies while step k is multiplied.
+//
+// Arithmetic is identical to conv_mfma_split.hip (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, f32
+// accumulate, per-channel power-of-two weight pre-scale folded into the epilogue).
+#include "common.h"
+
+namespace xdet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+#define XDET_GLDS16(gptr, lptr)                                                                        \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),              \
+                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT>
+__global__ __launch_bounds__(256) void conv_dma_f16_kernel(ConvParams p) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_IT = BM / 64;                  // DMA instructions per wave per plane per K step
+  constexpr int B_IT = BN / 64;
+  constexpr int ROWB = 32;                       // halves per LDS row (64 B)
+  constexpr int STAGE = (2 * BM + 2 * BN) * ROWB;   // halves per stage
+
+  extern __shared__ __attribute__((aligned(16))) u16 smem16[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- per-lane DMA descriptors ----
+  const int lr = lane >> 2;                      // row within a 16-row DMA slab
+  const int pos = lane & 3;                      // 16-B slot within the 64-B LDS row
+  int iy0[A_IT], ix0[A_IT], pbase[A_IT], achunk[A_IT];
+#pragma unroll
+  for (int q = 0; q < A_IT; ++q) {
+    const int rt = (wave * A_IT + q) * 16 + lr;  // tile row
+    achunk[q] = (pos ^ ((rt >> 2) & 3)) * 8;     // which 8-half chunk of the row this lane fetches
+    const int m = m0 + rt;
+    if (m < p.M) {
+      const int hw = p.Ho * p.Wo;
+      const int n = m / hw;
+      const int rem = m - n * hw;
+      const int oy = rem / p.Wo;
+      const int ox = rem - oy * p.Wo;
+      iy0[q] = oy * p.stride - p.pad_t;
+      ix0[q] = ox * p.stride - p.pad_l;
+      pbase[q] = n * p.H * p.W;
+    } else {
+      iy0[q] = -(1 << 20);
+      ix0[q] = 0;
+      pbase[q] = 0;
+    }
+  }
+  size_t boff[B_IT];
+#pragma unroll
+  for (int q = 0; q < B_IT; ++q) {
+    const int rt = (wave * B_IT + q) * 16 + lr;
+    boff[q] = (size_t)(n0 + rt) * p.Kp + (pos ^ ((rt >> 2) & 3)) * 8;
+  }
+  const int nk = p.Kp / 32;
+
+  auto issue = [&](int kt, int buf) {
+    u16* Ah = smem16 + buf * STAGE;
+    u16* Al = Ah + BM * ROWB;
+    u16* Bh = Al + BM * ROWB;
+    u16* Bl = Bh + BN * ROWB;
+    const int k0 = kt * 32;
+    const int tap = k0 / p.Cin_p;                // block-uniform
+    const int ky = tap / p.KW;
+    const int dy = ky * p.dil, dx = (tap - ky * p.KW) * p.dil;
+    const int coff = k0 - tap * p.Cin_p;
+#pragma unroll
+    for (int q = 0; q < A_IT; ++q) {
+      const int iy = iy0[q] + dy, ix = ix0[q] + dx;
+      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const size_t off = (size_t)(pbase[q] + iy * p.W + ix) * p.ldi + coff + achunk[q];
+      const u16* sh = ok ? p.in_hi + off : p.zeros;
+      XDET_GLDS16(sh, Ah + (wave * A_IT + q) * 16 * ROWB);
+      if (NSPLIT > 1) {
+        const u16* sl = ok ? p.in_lo + off : p.zeros;
+        XDET_GLDS16(sl, Al + (wave * A_IT + q) * 16 * ROWB);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < B_IT; ++q) {
+      XDET_GLDS16(p.wt_hi + boff[q] + k0, Bh + (wave * B_IT + q) * 16 * ROWB);
+      if (NSPLIT > 1) XDET_GLDS16(p.wt_lo + boff[q] + k0, Bl + (wave * B_IT + q) * 16 * ROWB);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31;
+  const int fh = lane >> 5;
+  // operand rows of this lane and their chunk permutation (tile-row bits 2..3)
+  int aoff[TM], boffs[TN], asw[TM], bsw[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int rt = wm * WM + i * 32 + frow;
+    aoff[i] = rt * ROWB;
+    asw[i] = (rt >> 2) & 3;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int rt = wn * WN + j * 32 + frow;
+    boffs[j] = rt * ROWB;
+    bsw[j] = (rt >> 2) & 3;
+  }
+
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    __syncthreads();                             // DMA(kt) landed for every wave; stage buf^1 is free
+    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+    const u16* Ah = smem16 + buf * STAGE;
+    const u16* Al = Ah + BM * ROWB;
+    const u16* Bh = Al + BM * ROWB;
+    const u16* Bl = Bh + BN * ROWB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = ks * 2 + fh;                 // logical 8-half chunk of the 32-deep step
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int o = aoff[i] + ((c ^ asw[i]) << 3);
+        ah[i] = *reinterpret_cast<const f16x8*>(Ah + o);
+        if (NSPLIT > 1) al[i] = *reinterpret_cast<const f16x8*>(Al + o);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int o = boffs[j] + ((c ^ bsw[j]) << 3);
+        bh[j] = *reinterpret_cast<const f16x8*>(Bh + o);
+        if (NSPLIT > 1) bl[j] = *reinterpret_cast<const f16x8*>(Bl + o);
+      }
+      if (NSPLIT > 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + wn * WN + j * 32 + frow;
+    if (co >= p.ldo) continue;
+    const float sc = p.scale[co], sh = p.shift[co];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (m < p.M) {
+          float v = fmaf(acc[i][j][r], sc, sh);
+          if (p.res) v += p.res[(size_t)m * p.ldr + co];
+          if (p.relu_out) v = fmaxf(v, 0.f);
+          p.out[(size_t)m * p.ldo + co] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT>
+static int launch_d(const ConvParams& p, hipStream_t s) {
+  constexpr size_t lds = (size_t)2 * (2 * BM + 2 * BN) * 32 * sizeof(u16);
+  auto kern = conv_dma_f16_kernel<BM, BN, WAVES_M, WAVES_N, NSPLIT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    XDET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)cdiv(p.M, BM), (unsigned)(p.Cout_pad / BN));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
+int launch_conv_mfma_dma(const ConvParams& p, int n_tile, int nsplit, hipStream_t s) {
+  XDET_REQUIRE(p.Kp % 32 == 0 && p.Cin_p % 32 == 0 && p.ldi >= p.Cin_p && p.ldi % 8 == 0,
+               "conv(dma): channel counts must be padded to 32");
+  XDET_REQUIRE(p.Cout_pad % n_tile == 0, "conv(dma): Cout_pad must be a multiple of the N tile");
+  XDET_REQUIRE(p.in_hi && (nsplit == 1 || p.in_lo) && p.wt_hi && (nsplit == 1 || p.wt_lo) && p.zeros,
+               "conv(dma): split planes missing");
+  if (p.M <= 0) return XDET_OK;
+  if (n_tile == 128)
+    return nsplit == 1 ? launch_d<128, 128, 2, 2, 1>(p, s) : launch_d<128, 128, 2, 2, 3>(p, s);
+  if (n_tile == 64) return nsplit == 1 ? launch_d<128, 64, 4, 1, 1>(p, s) : launch_d<128, 64, 4, 1, 3>(p, s);
+  set_last_error("conv(dma): unsupported N tile");
+  return XDET_ERR_UNSUPPORTED;
+}
+
+}  // namespace xdet

@@ -182,7 +182,8 @@ struct ConvLayer : LayerBase {
   }
 
   int forward(const float* in, int N, int H, int W, int ldi, float* out, int ldo, const float* res, int relu_in,
-              hipStream_t s) const {
+              hipStream_t s, const unsigned short* in_hi = nullptr, const unsigned short* in_lo = nullptr,
+              const unsigned short* zeros = nullptr) const {
     XDET_REQUIRE(ldi == ld_in(), "conv: ld_in must be round_up(cin,32) (4 for cin<=4)");
     XDET_REQUIRE(ldo == ld_out(), "conv: ld_out must be round_up(cout,32)");
     ConvParams p;
@@ -194,9 +195,16 @@ struct ConvLayer : LayerBase {
     p.KH = kh; p.KW = kw; p.stride = stride; p.dil = dil;
     p.M = N * p.Ho * p.Wo;
     p.relu_in = relu_in; p.relu_out = relu_out;
+    p.in_hi = in_hi; p.in_lo = in_lo; p.zeros = zeros;
     if (precision == PREC_F32) return launch_conv_mfma_f32(p, small_cin, n_tile, s);
+    if (in_hi) {   // A operand already split into f16 planes by its producer: LDS-DMA kernel
+      XDET_REQUIRE(!small_cin && relu_in == 0, "conv(dma): needs >= 32 input channels and no ReLU-on-load");
+      return launch_conv_mfma_dma(p, n_tile, precision == PREC_F16X3 ? 3 : 1, s);
+    }
     return launch_conv_mfma_split(p, small_cin, n_tile, precision == PREC_F16X3 ? 3 : 1, s);
   }
+  // can this layer consume pre-split f16 planes (conv_mfma_dma.hip)?
+  bool dma_capable() const { return precision != PREC_F32 && !small_cin; }
 };
 
 struct DepthwiseLayer : LayerBase {
@@ -223,6 +231,7 @@ struct DepthwiseLayer : LayerBase {
 // ---------------------------------------------------------------------------------------
 struct Buf {
   float* p = nullptr;
+  unsigned short *hi = nullptr, *lo = nullptr;   // optional split-precision f16 planes of the same tensor
   int H = 0, W = 0, C = 0, ld = 0;
   size_t per_image() const { return (size_t)H * W * ld; }
 };
@@ -294,21 +303,73 @@ struct Plan {
     return XDET_OK;
   }
 
+  // ---- split-precision planes ----
+  unsigned short* zeros = nullptr;
+  int get_zeros() {
+    if (!zeros) XDET_TRY(alloc_bytes(256, reinterpret_cast<void**>(&zeros)));
+    return XDET_OK;
+  }
+  int new_planes(Buf* b) {
+    const size_t bytes = ((size_t)max_batch * b->per_image() + 256) * sizeof(unsigned short);
+    XDET_TRY(alloc_bytes(bytes, reinterpret_cast<void**>(&b->hi)));
+    XDET_TRY(alloc_bytes(bytes, reinterpret_cast<void**>(&b->lo)));
+    return get_zeros();
+  }
+  // element-wise f32 -> (hi, lo) f16 planes (optionally through a ReLU) for a tensor whose producer
+  // only wrote f32; returns a Buf that aliases `in` and carries the planes
+  int add_split(const std::string& name, int stage, const Buf& in, int relu, Buf* out) {
+    *out = in;
+    out->hi = out->lo = nullptr;
+    XDET_TRY(new_planes(out));
+    const Buf i = in, o = *out;
+    ops.push_back({name, stage, 0.0, [=](int N, hipStream_t s) {
+                     return launch_split_f32(i.p, o.hi, o.lo, (int64_t)N * i.per_image(), relu, s);
+                   }});
+    return XDET_OK;
+  }
+
   // ---- op builders ----
-  int add_conv(const std::string& name, int stage, const Buf& in, ConvLayer* L, const Buf* res, int relu_in, Buf* out) {
+  int add_conv(const std::string& name, int stage, const Buf& in_, ConvLayer* L, const Buf* res, int relu_in, Buf* out) {
+    Buf in = in_;
+    // split path: big stride-1 contractions take their A operand as f16 planes through the LDS DMA;
+    // if the producer did not emit planes, one cheap element-wise pass makes them (ReLU folded in)
+    if (L->dma_capable() && L->stride == 1) {
+      if (!in.hi || relu_in) {
+        Buf sp;
+        XDET_TRY(add_split(name + "/split_in", stage, in_, relu_in, &sp));
+        in = sp;
+        relu_in = 0;
+      }
+    } else {
+      in.hi = in.lo = nullptr;
+    }
     int Ho, Wo, a, b;
     L->out_shape(in.H, in.W, &Ho, &Wo, &a, &b);
     XDET_TRY(new_buf(Ho, Wo, L->cout, out));
     XDET_REQUIRE(in.ld == L->ld_in() && out->ld == L->ld_out(), "plan: conv channel strides do not match");
     const Buf i = in, o = *out;
     const float* rp = res ? res->p : nullptr;
+    const unsigned short* z = zeros;
     if (res) XDET_REQUIRE(res->H == Ho && res->W == Wo && res->ld == o.ld, "plan: residual shape mismatch");
     ops.push_back({name, stage, L->flops(in.H, in.W), [=](int N, hipStream_t s) {
-                     return L->forward(i.p, N, i.H, i.W, i.ld, o.p, o.ld, rp, relu_in, s);
+                     return L->forward(i.p, N, i.H, i.W, i.ld, o.p, o.ld, rp, relu_in, s, i.hi, i.lo, z);
                    }});
     return XDET_OK;
   }
-  int add_dw(const std::string& name, int stage, const Buf& in, DepthwiseLayer* L, int relu_in, Buf* out) {
+  // `planes_only`: the single consumer is a pointwise conv on the split path -> write f16 planes, no f32
+  int add_dw(const std::string& name, int stage, const Buf& in, DepthwiseLayer* L, int relu_in, Buf* out,
+             bool planes_only = false) {
+    if (planes_only) {
+      *out = Buf();
+      out->H = in.H; out->W = in.W; out->C = in.C; out->ld = in.ld;
+      XDET_TRY(new_planes(out));
+      const Buf i = in, o = *out;
+      ops.push_back({name, stage, 0.0, [=](int N, hipStream_t s) {
+                       return launch_depthwise3x3_split(i.p, L->d_w, o.hi, o.lo, N, i.H, i.W, i.C, i.ld, L->dil,
+                                                        relu_in, s);
+                     }});
+      return XDET_OK;
+    }
     XDET_TRY(new_buf(in.H, in.W, in.C, out));
     const Buf i = in, o = *out;
     ops.push_back({name, stage, 0.0, [=](int N, hipStream_t s) {
@@ -355,12 +416,12 @@ struct Plan {
     XDET_TRY(need(name + "/pointwise_kernel", &pk, {1, 1, in.C, cout}));
     DepthwiseLayer* D = keep(new DepthwiseLayer());
     XDET_TRY(D->init(in.C, dilation, dk->v.data()));
-    Buf t;
-    XDET_TRY(add_dw(name + "/depthwise", stage, in, D, pre_relu, &t));
     std::vector<float> sc, sh;
     XDET_TRY(fold_bn(name + "_bn", cout, eps, nullptr, &sc, &sh));
     ConvLayer* L = keep(new ConvLayer());
     XDET_TRY(L->init(1, 1, in.C, cout, 1, 1, 1, 0, 0, pk->v.data(), sc.data(), sh.data(), relu_out));
+    Buf t;
+    XDET_TRY(add_dw(name + "/depthwise", stage, in, D, pre_relu, &t, /*planes_only=*/L->dma_capable()));
     return add_conv(name + "/pointwise", stage, t, L, res, 0, out);
   }
   int run_stage(int stage, int N, hipStream_t s) {
@@ -806,6 +867,24 @@ int xdet_conv_forward(void* layer, const float* in, int N, int H, int W, int ld_
   LayerBase* b = static_cast<LayerBase*>(layer);
   XDET_REQUIRE(b && b->kind == 1, "not a conv layer");
   return static_cast<ConvLayer*>(b)->forward(in, N, H, W, ld_in, out, ld_out, residual, relu_in, S(stream));
+}
+int xdet_split_f32(const float* in, uint16_t* hi, uint16_t* lo, int64_t n, int relu, void* stream) {
+  XDET_REQUIRE(in && hi && lo, "split: NULL argument");
+  return launch_split_f32(in, hi, lo, n, relu, S(stream));
+}
+int xdet_conv_forward_planes(void* layer, const uint16_t* in_hi, const uint16_t* in_lo, int N, int H, int W,
+                             int ld_in, float* out, int ld_out, const float* residual, void* stream) {
+  LayerBase* b = static_cast<LayerBase*>(layer);
+  XDET_REQUIRE(b && b->kind == 1, "not a conv layer");
+  ConvLayer* L = static_cast<ConvLayer*>(b);
+  XDET_REQUIRE(L->dma_capable(), "layer was not created in a split-precision mode (or has < 32 input channels)");
+  XDET_REQUIRE(in_hi && (in_lo || L->precision == PREC_F16), "conv(planes): NULL planes");
+  static unsigned short* zeros = nullptr;
+  if (!zeros) {
+    XDET_HIP(hipMalloc(reinterpret_cast<void**>(&zeros), 256));
+    XDET_HIP(hipMemset(zeros, 0, 256));
+  }
+  return L->forward(nullptr, N, H, W, ld_in, out, ld_out, residual, 0, S(stream), in_hi, in_lo, zeros);
 }
 int xdet_conv_out_shape(void* layer, int H, int W, int* Ho, int* Wo) {
   LayerBase* b = static_cast<LayerBase*>(layer);

@@ -12,6 +12,7 @@ LIB = os.path.join(HERE, 'libxdet_hip.so')
 SOURCES = [
     ('conv_mfma.hip', []),
     ('conv_mfma_split.hip', []),
+    ('conv_mfma_dma.hip', []),
     ('elementwise.hip', []),
     ('psroialign.hip', ['-ffp-contract=off']),
     ('proposals.hip', ['-ffp-contract=off']),

@@ -65,12 +65,23 @@ class Conv2D(object):
                                      _host(sh) if sh is not None else None, 1 if relu else 0))
         self.handle = h
 
-    def __call__(self, x, residual=None, relu_in=False, stream=None):
+    def __call__(self, x, residual=None, relu_in=False, stream=None, planes=False):
+        """planes=True (split-precision modes only): split x into f16 hi/lo planes first and run the
+        LDS-DMA kernel -- the path every big contraction takes inside a net."""
         N, H, W, C = x.shape
         assert C == self.cin, (C, self.cin)
         ho, wo = ctypes.c_int(), ctypes.c_int()
         check(lib().xdet_conv_out_shape(self.handle, H, W, ctypes.byref(ho), ctypes.byref(wo)))
         out = DeviceTensor.empty((N, ho.value, wo.value, self.cout))
+        if planes:
+            n = N * H * W * x.ld
+            hi, lo = DeviceBuffer(n * 2 + 512, zero=True), DeviceBuffer(n * 2 + 512, zero=True)
+            st = stream.handle if stream else None
+            check(lib().xdet_split_f32(x.ptr, hi.ptr, lo.ptr, n, 1 if relu_in else 0, st))
+            check(lib().xdet_conv_forward_planes(self.handle, hi.ptr, lo.ptr, N, H, W, x.ld, out.ptr, out.ld,
+                                                 residual.ptr if residual is not None else None, st))
+            synchronize(stream)
+            return out
         check(lib().xdet_conv_forward(self.handle, x.ptr, N, H, W, x.ld, out.ptr, out.ld,
                                       residual.ptr if residual is not None else None, 1 if relu_in else 0,
                                       stream.handle if stream else None))
