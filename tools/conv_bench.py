@@ -32,6 +32,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--only', default='')
+    ap.add_argument('--planes', action='store_true', help='A operand pre-split into f16 planes (LDS-DMA kernel)')
     a = ap.parse_args()
     set_precision(a.precision)
     rng = np.random.default_rng(0)
@@ -47,9 +48,19 @@ def main():
         st.synchronize()
         e0, e1 = Event(), Event()
         from xdet._lib import lib, check
+        if a.planes:
+            from xdet.runtime import DeviceBuffer
+            n = a.batch * H * W * x.ld
+            hi, lo = DeviceBuffer(n * 2 + 512, zero=True), DeviceBuffer(n * 2 + 512, zero=True)
+            check(lib().xdet_split_f32(x.ptr, hi.ptr, lo.ptr, n, 0, st.handle))
+            check(lib().xdet_conv_forward_planes(L.handle, hi.ptr, lo.ptr, a.batch, H, W, x.ld, y.ptr, y.ld, None, st.handle))
+            st.synchronize()
         e0.record(st)
         for _ in range(a.iters):
-            check(lib().xdet_conv_forward(L.handle, x.ptr, a.batch, H, W, x.ld, y.ptr, y.ld, None, 0, st.handle))
+            if a.planes:
+                check(lib().xdet_conv_forward_planes(L.handle, hi.ptr, lo.ptr, a.batch, H, W, x.ld, y.ptr, y.ld, None, st.handle))
+            else:
+                check(lib().xdet_conv_forward(L.handle, x.ptr, a.batch, H, W, x.ld, y.ptr, y.ld, None, 0, st.handle))
         e1.record(st)
         st.synchronize()
         ms = e0.elapsed_ms(e1) / a.iters

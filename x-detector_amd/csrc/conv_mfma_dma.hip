@@ -14,6 +14,8 @@
 // Arithmetic is identical to conv_mfma_split.hip (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, f32
 // accumulate, per-channel power-of-two weight pre-scale folded into the epilogue).
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace xdet {
 
@@ -26,12 +28,13 @@ typedef unsigned short u16;
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT>
-__global__ __launch_bounds__(256) void conv_dma_f16_kernel(ConvParams p) {
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(ConvParams p) {
+  constexpr int NW = WAVES_M * WAVES_N;          // waves per workgroup (4 or 8)
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int A_IT = BM / 64;                  // DMA instructions per wave per plane per K step
-  constexpr int B_IT = BN / 64;
+  constexpr int A_IT = BM / (16 * NW);           // DMA instructions per wave per plane per K step
+  constexpr int B_IT = BN / (16 * NW);
+  static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for the wave count");
   constexpr int ROWB = 32;                       // halves per LDS row (64 B)
   constexpr int STAGE = (2 * BM + 2 * BN) * ROWB;   // halves per stage
 
@@ -207,7 +210,7 @@ static int launch_d(const ConvParams& p, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid((unsigned)cdiv(p.M, BM), (unsigned)(p.Cout_pad / BN));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, p);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }
@@ -219,6 +222,21 @@ int launch_conv_mfma_dma(const ConvParams& p, int n_tile, int nsplit, hipStream_
   XDET_REQUIRE(p.in_hi && (nsplit == 1 || p.in_lo) && p.wt_hi && (nsplit == 1 || p.wt_lo) && p.zeros,
                "conv(dma): split planes missing");
   if (p.M <= 0) return XDET_OK;
+  if (n_tile == 128 && nsplit == 3) {
+    // Tile choice.  The kernel is bound by L2->LDS operand traffic, so the biggest tile wins as long
+    // as the grid still covers the 256 CUs (measured on MI355X, tools/conv_bench.py --planes):
+    // 256x256 once there are >= 2 workgroups per CU, or ~1 per CU with a long K loop to amortise its
+    // prologue/epilogue; 256x128 from ~2/3 workgroup per CU; else 128x128 (two workgroups share a CU).
+    static const char* tile_env = getenv("XDET_TILE");   // experiment override: 128x128 | 256x128 | 256x256
+    const int64_t b256 = cdiv(p.M, 256) * (p.Cout_pad / 256), b128n = cdiv(p.M, 256) * (p.Cout_pad / 128);
+    const int nk = p.Kp / 32;
+    int tile = 0;
+    if (p.Cout_pad % 256 == 0 && (b256 >= 512 || (b256 >= 200 && nk >= 40))) tile = 2;
+    else if (b128n >= 170) tile = 1;
+    if (tile_env) tile = !strcmp(tile_env, "256x256") ? (p.Cout_pad % 256 == 0 ? 2 : 1) : !strcmp(tile_env, "256x128") ? 1 : 0;
+    if (tile == 2) return launch_d<256, 256, 2, 4, 3>(p, s);
+    if (tile == 1) return launch_d<256, 128, 4, 2, 3>(p, s);
+  }
   if (n_tile == 128)
     return nsplit == 1 ? launch_d<128, 128, 2, 2, 1>(p, s) : launch_d<128, 128, 2, 2, 3>(p, s);
   if (n_tile == 64) return nsplit == 1 ? launch_d<128, 64, 4, 1, 1>(p, s) : launch_d<128, 64, 4, 1, 3>(p, s);

@@ -28,50 +28,14 @@ int launch_nchw_to_nhwc4(const float* in, float* out, int N, int C, int H, int W
   return XDET_OK;
 }
 
-// one thread = 4 channels of one output pixel; w9c is [9][ld] (tap-major, zero in padded channels)
-__global__ void depthwise3x3_kernel(const float* __restrict__ in, const float* __restrict__ w9c,
-                                    float* __restrict__ out, int N, int H, int W, int ld, int dil, int relu_in) {
-  const int c4n = ld >> 2;
-  const int64_t total = (int64_t)N * H * W * c4n;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % c4n);
-    const int64_t px = i / c4n;
-    const int x = (int)(px % W);
-    const int y = (int)((px / W) % H);
-    const int64_t nb = (px / ((int64_t)W * H)) * H * W;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = y + (ky - 1) * dil;
-      if ((unsigned)iy >= (unsigned)H) continue;
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = x + (kx - 1) * dil;
-        if ((unsigned)ix >= (unsigned)W) continue;
-        float4 v = *reinterpret_cast<const float4*>(in + (nb + (int64_t)iy * W + ix) * ld + c4 * 4);
-        if (relu_in) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        }
-        const float4 w = *reinterpret_cast<const float4*>(w9c + (ky * 3 + kx) * ld + c4 * 4);
-        acc.x = fmaf(v.x, w.x, acc.x); acc.y = fmaf(v.y, w.y, acc.y);
-        acc.z = fmaf(v.z, w.z, acc.z); acc.w = fmaf(v.w, w.w, acc.w);
-      }
-    }
-    *reinterpret_cast<float4*>(out + px * ld + c4 * 4) = acc;
-  }
-}
+// Depthwise 3x3, stride 1, SAME, dilation DIL.  One thread = 4 channels x a strip of SX consecutive
+// output pixels of one row: the 3 x (SX + 2*DIL) input columns are loaded once and reused by the SX
+// outputs (3-4.5 loads per output instead of 9); lanes run along channels (16 B each, coalesced).
+// grid.x = N*H rows, grid.y covers ceil(W/SX) * ld/4 items; all index math is 32-bit.
+// SPLIT: write the result as f16 hi/lo planes (its only consumer is a pointwise conv on the
+// split-precision path) instead of f32.
+constexpr int DW_SX = 4;
 
-int launch_depthwise3x3(const float* in, const float* w9c, float* out, int N, int H, int W, int C, int ld, int dil,
-                        int relu_in, hipStream_t s) {
-  XDET_REQUIRE(ld % 4 == 0 && ld >= C, "depthwise: channel stride must be a multiple of 4");
-  const int64_t total = (int64_t)N * H * W * (ld / 4);
-  const int blocks = (int)std::min<int64_t>(cdiv(total, 256), 256 * 32);
-  hipLaunchKernelGGL(depthwise3x3_kernel, dim3(blocks), dim3(256), 0, s, in, w9c, out, N, H, W, ld, dil, relu_in);
-  XDET_LAUNCH_CHECK();
-  return XDET_OK;
-}
-
-// ---- split-precision planes: x = hi + lo, both f16 (the A operand format of conv_mfma_dma.hip) ----
 typedef _Float16 f16x4e __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split_store(const float4 v, unsigned short* hi, unsigned short* lo, int64_t o) {
@@ -83,6 +47,92 @@ __device__ __forceinline__ void split_store(const float4 v, unsigned short* hi, 
   *reinterpret_cast<uint2*>(lo + o) = *reinterpret_cast<uint2*>(&lv);
 }
 
+template <int DIL, bool SPLIT>
+__global__ __launch_bounds__(256) void depthwise3x3_kernel(const float* __restrict__ in, const float* __restrict__ w9c,
+                                                           float* __restrict__ out, unsigned short* __restrict__ hi,
+                                                           unsigned short* __restrict__ lo, int H, int W, int ld,
+                                                           int relu_in) {
+  constexpr int NC = DW_SX + 2 * DIL;
+  const int c4n = ld >> 2;
+  const int nstrip = (W + DW_SX - 1) / DW_SX;
+  const int item = blockIdx.y * 256 + threadIdx.x;
+  if (item >= nstrip * c4n) return;
+  const int strip = item / c4n;
+  const int c = (item - strip * c4n) * 4;
+  const int row = blockIdx.x;                  // n*H + y
+  const int y = row % H;
+  const int x0 = strip * DW_SX;
+  const float* base = in + (size_t)(row - y) * W * ld + c;       // image origin + channel offset
+  float4 acc[DW_SX];
+#pragma unroll
+  for (int k = 0; k < DW_SX; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = y + (ky - 1) * DIL;
+    if ((unsigned)iy >= (unsigned)H) continue;
+    const float* rp = base + (size_t)iy * W * ld;
+    float4 col[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const int ix = x0 - DIL + k;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)ix < (unsigned)W) {
+        v = *reinterpret_cast<const float4*>(rp + (size_t)ix * ld);
+        if (relu_in) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+      }
+      col[k] = v;
+    }
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const float4 w = *reinterpret_cast<const float4*>(w9c + (ky * 3 + kx) * ld + c);
+#pragma unroll
+      for (int k = 0; k < DW_SX; ++k) {
+        const float4 v = col[k + kx * DIL];
+        acc[k].x = fmaf(v.x, w.x, acc[k].x); acc[k].y = fmaf(v.y, w.y, acc[k].y);
+        acc[k].z = fmaf(v.z, w.z, acc[k].z); acc[k].w = fmaf(v.w, w.w, acc[k].w);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < DW_SX; ++k) {
+    const int x = x0 + k;
+    if (x >= W) break;
+    const size_t o = ((size_t)row * W + x) * ld + c;
+    if (SPLIT) split_store(acc[k], hi, lo, (int64_t)o);
+    else *reinterpret_cast<float4*>(out + o) = acc[k];
+  }
+}
+
+static int launch_dw(const float* in, const float* w9c, float* out, unsigned short* hi, unsigned short* lo, int N,
+                     int H, int W, int C, int ld, int dil, int relu_in, hipStream_t s) {
+  XDET_REQUIRE(ld % 4 == 0 && ld >= C, "depthwise: channel stride must be a multiple of 4");
+  XDET_REQUIRE(dil == 1 || dil == 2, "depthwise: dilation must be 1 or 2");
+  if ((int64_t)N * H == 0) return XDET_OK;
+  const int items = ((W + DW_SX - 1) / DW_SX) * (ld / 4);
+  const dim3 grid((unsigned)(N * H), (unsigned)cdiv(items, 256));
+  const bool split = hi != nullptr;
+  if (dil == 1 && !split) hipLaunchKernelGGL((depthwise3x3_kernel<1, false>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in);
+  else if (dil == 1) hipLaunchKernelGGL((depthwise3x3_kernel<1, true>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in);
+  else if (!split) hipLaunchKernelGGL((depthwise3x3_kernel<2, false>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in);
+  else hipLaunchKernelGGL((depthwise3x3_kernel<2, true>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
+int launch_depthwise3x3(const float* in, const float* w9c, float* out, int N, int H, int W, int C, int ld, int dil,
+                        int relu_in, hipStream_t s) {
+  return launch_dw(in, w9c, out, nullptr, nullptr, N, H, W, C, ld, dil, relu_in, s);
+}
+
+int launch_depthwise3x3_split(const float* in, const float* w9c, unsigned short* hi, unsigned short* lo, int N,
+                              int H, int W, int C, int ld, int dil, int relu_in, hipStream_t s) {
+  XDET_REQUIRE(hi && lo, "depthwise(split): NULL planes");
+  return launch_dw(in, w9c, nullptr, hi, lo, N, H, W, C, ld, dil, relu_in, s);
+}
+
+// ---- split-precision planes: x = hi + lo, both f16 (the A operand format of conv_mfma_dma.hip) ----
 __global__ void split_f32_kernel(const float4* __restrict__ in, unsigned short* __restrict__ hi,
                                  unsigned short* __restrict__ lo, int64_t n4, int relu) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -104,90 +154,47 @@ int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, in
   return XDET_OK;
 }
 
-// depthwise 3x3 whose only consumer is a pointwise conv on the split path: emit the planes directly
-__global__ void depthwise3x3_split_kernel(const float* __restrict__ in, const float* __restrict__ w9c,
-                                          unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, int N,
-                                          int H, int W, int ld, int dil, int relu_in) {
+// grid.x = N*Ho output rows, grid.y covers Wo * ld/4 items; one thread = 4 channels of one output pixel
+__global__ __launch_bounds__(256) void maxpool3x3s2_add_kernel(const float* __restrict__ in,
+                                                               const float* __restrict__ res,
+                                                               float* __restrict__ out, int H, int W, int ld, int Ho,
+                                                               int Wo, int pad_t, int pad_l) {
   const int c4n = ld >> 2;
-  const int64_t total = (int64_t)N * H * W * c4n;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % c4n);
-    const int64_t px = i / c4n;
-    const int x = (int)(px % W);
-    const int y = (int)((px / W) % H);
-    const int64_t nb = (px / ((int64_t)W * H)) * H * W;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int item = blockIdx.y * 256 + threadIdx.x;
+  if (item >= Wo * c4n) return;
+  const int ox = item / c4n;
+  const int c = (item - ox * c4n) * 4;
+  const int orow = blockIdx.x;                 // n*Ho + oy
+  const int n = orow / Ho;
+  const int oy = orow - n * Ho;
+  const float* base = in + (size_t)n * H * W * ld + c;
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = y + (ky - 1) * dil;
-      if ((unsigned)iy >= (unsigned)H) continue;
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * 2 - pad_t + ky;
+    if ((unsigned)iy >= (unsigned)H) continue;
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = x + (kx - 1) * dil;
-        if ((unsigned)ix >= (unsigned)W) continue;
-        float4 v = *reinterpret_cast<const float4*>(in + (nb + (int64_t)iy * W + ix) * ld + c4 * 4);
-        if (relu_in) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        }
-        const float4 w = *reinterpret_cast<const float4*>(w9c + (ky * 3 + kx) * ld + c4 * 4);
-        acc.x = fmaf(v.x, w.x, acc.x); acc.y = fmaf(v.y, w.y, acc.y);
-        acc.z = fmaf(v.z, w.z, acc.z); acc.w = fmaf(v.w, w.w, acc.w);
-      }
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox * 2 - pad_l + kx;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)iy * W + ix) * ld);
+      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
     }
-    split_store(acc, hi, lo, px * ld + c4 * 4);
   }
-}
-
-int launch_depthwise3x3_split(const float* in, const float* w9c, unsigned short* hi, unsigned short* lo, int N,
-                              int H, int W, int C, int ld, int dil, int relu_in, hipStream_t s) {
-  XDET_REQUIRE(ld % 4 == 0 && ld >= C, "depthwise: channel stride must be a multiple of 4");
-  const int64_t total = (int64_t)N * H * W * (ld / 4);
-  const int blocks = (int)std::min<int64_t>(cdiv(total, 256), 256 * 32);
-  hipLaunchKernelGGL(depthwise3x3_split_kernel, dim3(blocks), dim3(256), 0, s, in, w9c, hi, lo, N, H, W, ld, dil,
-                     relu_in);
-  XDET_LAUNCH_CHECK();
-  return XDET_OK;
-}
-
-__global__ void maxpool3x3s2_add_kernel(const float* __restrict__ in, const float* __restrict__ res,
-                                        float* __restrict__ out, int N, int H, int W, int ld, int Ho, int Wo,
-                                        int pad_t, int pad_l) {
-  const int c4n = ld >> 2;
-  const int64_t total = (int64_t)N * Ho * Wo * c4n;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % c4n);
-    const int64_t px = i / c4n;
-    const int ox = (int)(px % Wo);
-    const int oy = (int)((px / Wo) % Ho);
-    const int64_t n = px / ((int64_t)Wo * Ho);
-    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = oy * 2 - pad_t + ky;
-      if ((unsigned)iy >= (unsigned)H) continue;
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = ox * 2 - pad_l + kx;
-        if ((unsigned)ix >= (unsigned)W) continue;
-        const float4 v = *reinterpret_cast<const float4*>(in + ((n * H + iy) * W + ix) * ld + c4 * 4);
-        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
-      }
-    }
-    if (res) {
-      const float4 r = *reinterpret_cast<const float4*>(res + px * ld + c4 * 4);
-      m.x += r.x; m.y += r.y; m.z += r.z; m.w += r.w;
-    }
-    *reinterpret_cast<float4*>(out + px * ld + c4 * 4) = m;
+  const size_t o = ((size_t)orow * Wo + ox) * ld + c;
+  if (res) {
+    const float4 r = *reinterpret_cast<const float4*>(res + o);
+    m.x += r.x; m.y += r.y; m.z += r.z; m.w += r.w;
   }
+  *reinterpret_cast<float4*>(out + o) = m;
 }
 
 int launch_maxpool3x3s2_add(const float* in, const float* res, float* out, int N, int H, int W, int C, int ld,
                             int Ho, int Wo, int pad_t, int pad_l, hipStream_t s) {
   XDET_REQUIRE(ld % 4 == 0 && ld >= C, "maxpool: channel stride must be a multiple of 4");
-  const int64_t total = (int64_t)N * Ho * Wo * (ld / 4);
-  const int blocks = (int)std::min<int64_t>(cdiv(total, 256), 256 * 32);
-  hipLaunchKernelGGL(maxpool3x3s2_add_kernel, dim3(blocks), dim3(256), 0, s, in, res, out, N, H, W, ld, Ho, Wo,
-                     pad_t, pad_l);
+  if ((int64_t)N * Ho == 0) return XDET_OK;
+  const dim3 grid((unsigned)(N * Ho), (unsigned)cdiv((int64_t)Wo * (ld / 4), 256));
+  hipLaunchKernelGGL(maxpool3x3s2_add_kernel, grid, dim3(256), 0, s, in, res, out, H, W, ld, Ho, Wo, pad_t, pad_l);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }
