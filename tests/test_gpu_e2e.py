@@ -33,12 +33,12 @@ def test_dense_stages(run):
     det, got, ref, tr, _ = run
     n = 2
     mid_x = det.buffer('mid_x', n).numpy()
-    assert rel_err(np.maximum(mid_x, 0), tr['mid']) < 3e-4
-    assert rel_err(det.buffer('out', n).numpy(), tr['out']) < 3e-4
+    assert rel_err(np.maximum(mid_x, 0), tr['mid']) < 1e-4
+    assert rel_err(det.buffer('out', n).numpy(), tr['out']) < 1e-4
     rpn = det.buffer('rpn_out', n).numpy()
-    assert rel_err(rpn[..., :44], tr['rpn_cls']) < 3e-4
-    assert rel_err(rpn[..., 44:132], tr['rpn_box']) < 3e-4
-    assert rel_err(det.buffer('feat', n).numpy(), tr['feat']) < 3e-4
+    assert rel_err(rpn[..., :44], tr['rpn_cls']) < 1e-4
+    assert rel_err(rpn[..., 44:132], tr['rpn_box']) < 1e-4
+    assert rel_err(det.buffer('feat', n).numpy(), tr['feat']) < 1e-4
     na = 30 * 30 * 22
     assert np.abs(det.flat('objectness', (n, na)) - tr['objectness']).max() < 1e-4
     assert np.abs(det.flat('rpn_boxes', (n, na, 4)) - tr['rpn_boxes']).max() < 1e-4
@@ -113,10 +113,10 @@ def test_graph_builder_api_mirrors_reference(run, oracle, lh_weights):
     det, _, _, tr, imgs = run
     with det.scope():
         mid, out = M.XceptionBody(imgs, 21, is_training=False, data_format='channels_first')
-        assert rel_err(mid.numpy(), tr['mid']) < 3e-4
+        assert rel_err(mid.numpy(), tr['mid']) < 1e-4
         cls, box = M.get_rpn(mid, 22, False, 'channels_first', 'rpn_head')
         assert cls.shape[1:] == (30, 30, 44) and box.shape[1:] == (30, 30, 88)
-        assert rel_err(box.numpy(), tr['rpn_box']) < 3e-4
+        assert rel_err(box.numpy(), tr['rpn_box']) < 1e-4
         feat = M.large_sep_kernel(out, 256, 490, False, 'channels_first', 'large_sep_feature')
         # feed the oracle's scores/boxes: the discrete stage must then agree exactly
         props = M.get_proposals(tr['objectness'], tr['rpn_boxes'], None, 5000, 300, 0.7, 16. / 480, False,

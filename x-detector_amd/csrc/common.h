@@ -86,10 +86,13 @@ struct ProposalWorkspace {
   unsigned long long* keys;   // [N][n_anchor]
   float* cboxes;              // [N][n_anchor][4] clipped boxes
   int* ranks;                 // [N][n_anchor]
-  int* counts;                // [N][4]: n_valid, n_cand, n_keep, pad
+  int* counts;                // [N][4]: n_valid, n_cand, n_keep, candidate-list length
   float* sboxes;              // [N][pre_n][4]
   float* sscores;             // [N][pre_n]
-  unsigned long long* mask;   // [N][pre_n][W64]
+  unsigned long long* cand;   // [N][n_anchor] keys that can still reach the top pre_n
+  int* hist;                  // [N][16384] histogram of the keys' top 16 bits
+  int* tbin;                  // [N] threshold bin
+  unsigned long long* mask;   // [N][pre_n][W64] IoU>thr bit rows (upper triangle)
   int* kept;                  // [N][post_n]
 };
 size_t proposal_workspace_bytes(int N, int n_anchor, int pre_n, int post_n);

@@ -8,21 +8,26 @@
 //
 // No host round trip and no data-dependent launch shape: every buffer is fixed-size and
 // the counts live in device memory, so the whole stage is hipGraph-capturable.
-//   1. prepare : clipped box + 64-bit sort key (score bits << 32 | ~index), 0 = filtered
-//   2. rank    : rank_i = #{j : key_j > key_i}  (all keys distinct -> a permutation; equals
-//                tf.nn.top_k order: descending score, ties -> lower index)
-//   3. scatter : sorted_boxes[rank] = box  for rank < pre_n
-//   4. mask    : bit (i,j) = IoU(i,j) > thr for j > i, 64x64 tiles
-//   5. scan    : one wavefront walks the candidates in score order, 64 at a time
-//   6. gather  : rois[j] = kept[j mod n_keep]  (tile + identity "shuffle" of :196-213)
+//   1. prepare : clipped box + 64-bit sort key (score bits << 32 | ~index), 0 = filtered;
+//                histogram of the keys' top 16 bits
+//   2. select  : threshold bin T = the lowest bin that is still needed to cover pre_n keys
+//   3. compact : keys with bin >= T (>= pre_n of them, typically barely more) -> candidate list
+//   4. rank    : rank_i = #{j : key_j > key_i} among the candidates (all keys distinct -> a
+//                permutation; equals tf.nn.top_k order: descending score, ties -> lower index)
+//   5. scatter : sorted_boxes[rank] = box  for rank < pre_n
+//   6. mask    : bit (i,j) = IoU(i,j) > thr for j > i, 64x64 tiles of the upper triangle, chip-wide
+//      scan    : one workgroup per image walks the candidates in score order 64 at a time (bit rows
+//                staged in LDS, diagonal block resolved by one wavefront); stops at post_n
+//   7. gather  : rois[j] = kept[j mod n_keep]  (tile + identity "shuffle" of :196-213)
 #include "common.h"
 
 namespace xdet {
 
 typedef unsigned long long u64;
 
+constexpr int HIST_BINS = 16384;     // key >> 48 = score float bits >> 16 (scores are in (0, 1])
+
 size_t proposal_workspace_bytes(int N, int n_anchor, int pre_n, int post_n) {
-  const size_t w64 = (size_t)cdiv(pre_n, 64);
   size_t b = 0;
   auto add = [&](size_t x) { b += (x + 255) / 256 * 256; };
   add((size_t)N * n_anchor * 8);
@@ -31,13 +36,15 @@ size_t proposal_workspace_bytes(int N, int n_anchor, int pre_n, int post_n) {
   add((size_t)N * 16);
   add((size_t)N * pre_n * 16);
   add((size_t)N * pre_n * 4);
-  add((size_t)N * pre_n * w64 * 8);
+  add((size_t)N * n_anchor * 8);
+  add((size_t)N * HIST_BINS * 4);
+  add((size_t)N * 4);
+  add((size_t)N * pre_n * cdiv(pre_n, 64) * 8);
   add((size_t)N * post_n * 4);
   return b;
 }
 
 void proposal_workspace_carve(void* base, int N, int n_anchor, int pre_n, int post_n, ProposalWorkspace* ws) {
-  const size_t w64 = (size_t)cdiv(pre_n, 64);
   char* p = static_cast<char*>(base);
   auto take = [&](size_t x) { char* r = p; p += (x + 255) / 256 * 256; return r; };
   ws->keys = reinterpret_cast<u64*>(take((size_t)N * n_anchor * 8));
@@ -46,7 +53,10 @@ void proposal_workspace_carve(void* base, int N, int n_anchor, int pre_n, int po
   ws->counts = reinterpret_cast<int*>(take((size_t)N * 16));
   ws->sboxes = reinterpret_cast<float*>(take((size_t)N * pre_n * 16));
   ws->sscores = reinterpret_cast<float*>(take((size_t)N * pre_n * 4));
-  ws->mask = reinterpret_cast<u64*>(take((size_t)N * pre_n * w64 * 8));
+  ws->cand = reinterpret_cast<u64*>(take((size_t)N * n_anchor * 8));
+  ws->hist = reinterpret_cast<int*>(take((size_t)N * HIST_BINS * 4));
+  ws->tbin = reinterpret_cast<int*>(take((size_t)N * 4));
+  ws->mask = reinterpret_cast<u64*>(take((size_t)N * pre_n * cdiv(pre_n, 64) * 8));
   ws->kept = reinterpret_cast<int*>(take((size_t)N * post_n * 4));
 }
 
@@ -96,89 +106,137 @@ int launch_rpn_decode(const float* rpn_out, int ld, int cls_off, int box_off, in
 // ---------------------------------------------------------------------------------------
 __global__ void prop_prepare_kernel(const float* __restrict__ score, const float* __restrict__ boxes, int n_anchor,
                                     float min_size, u64* __restrict__ keys, float* __restrict__ cboxes,
-                                    int* __restrict__ ranks, int* __restrict__ counts) {
+                                    int* __restrict__ hist) {
   const int n = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool valid = false;
-  if (i < n_anchor) {
-    const int64_t g = (int64_t)n * n_anchor + i;
-    const float4 b = *reinterpret_cast<const float4*>(boxes + g * 4);
-    // _bboxes_clip to [0,0,1,1]  (:173-194)
-    float ymin = fmaxf(b.x, 0.f), xmin = fmaxf(b.y, 0.f);
-    const float ymax = fminf(b.z, 1.f), xmax = fminf(b.w, 1.f);
-    ymin = fminf(ymin, ymax);
-    xmin = fminf(xmin, xmax);
-    *reinterpret_cast<float4*>(cboxes + g * 4) = make_float4(ymin, xmin, ymax, xmax);
-    // _filter_and_sort_boxes (:133-158)
-    const float ws = xmax - xmin, hs = ymax - ymin;
-    const float xc = xmin + ws / 2.f, yc = ymin + hs / 2.f;
-    const float sc = score[g];
-    // a score <= 0 survives top_k in the reference but is dropped as padding by
-    // _upsample_rois (:199-200); such entries sort last, so excluding them here is equivalent.
-    valid = ws > min_size && hs > min_size && xc > 0.f && yc > 0.f && xc < 1.f && yc < 1.f && sc > 0.f;
-    keys[g] = valid ? (((u64)__float_as_uint(sc) << 32) | (u64)(0xFFFFFFFFu - (unsigned)i)) : 0ull;
-    ranks[g] = 0;
+  if (i >= n_anchor) return;
+  const int64_t g = (int64_t)n * n_anchor + i;
+  const float4 b = *reinterpret_cast<const float4*>(boxes + g * 4);
+  // _bboxes_clip to [0,0,1,1]  (:173-194)
+  float ymin = fmaxf(b.x, 0.f), xmin = fmaxf(b.y, 0.f);
+  const float ymax = fminf(b.z, 1.f), xmax = fminf(b.w, 1.f);
+  ymin = fminf(ymin, ymax);
+  xmin = fminf(xmin, xmax);
+  *reinterpret_cast<float4*>(cboxes + g * 4) = make_float4(ymin, xmin, ymax, xmax);
+  // _filter_and_sort_boxes (:133-158)
+  const float ws = xmax - xmin, hs = ymax - ymin;
+  const float xc = xmin + ws / 2.f, yc = ymin + hs / 2.f;
+  const float sc = score[g];
+  // a score <= 0 survives top_k in the reference but is dropped as padding by
+  // _upsample_rois (:199-200); such entries sort last, so excluding them here is equivalent.
+  const bool valid = ws > min_size && hs > min_size && xc > 0.f && yc > 0.f && xc < 1.f && yc < 1.f && sc > 0.f;
+  const u64 key = valid ? (((u64)__float_as_uint(sc) << 32) | (u64)(0xFFFFFFFFu - (unsigned)i)) : 0ull;
+  keys[g] = key;
+  if (valid) atomicAdd(&hist[n * HIST_BINS + min((int)(key >> 48), HIST_BINS - 1)], 1);
+}
+
+// one 1024-thread workgroup per image: lowest histogram bin still needed to cover pre_n keys
+__global__ __launch_bounds__(1024) void prop_select_kernel(const int* __restrict__ hist, int pre_n,
+                                                           int* __restrict__ tbin, int* __restrict__ counts) {
+  __shared__ int part[1024];
+  const int n = blockIdx.x, t = threadIdx.x;
+  const int* h = hist + n * HIST_BINS;
+  constexpr int PER = HIST_BINS / 1024;
+  int s = 0;
+  for (int b = 0; b < PER; ++b) s += h[t * PER + b];
+  part[t] = s;
+  __syncthreads();
+  int above = 0;                                   // keys in bins owned by threads > t
+  for (int u = t + 1; u < 1024; ++u) above += part[u];
+  if (t == 0) {
+    const int n_valid = above + s;
+    counts[n * 4 + 0] = n_valid;
+    counts[n * 4 + 1] = min(n_valid, pre_n);       // n_cand
+    counts[n * 4 + 2] = 0;
+    counts[n * 4 + 3] = 0;                         // candidate-list length, filled by compact
+    if (n_valid < pre_n) tbin[n] = 0;
   }
-  const u64 ball = __ballot(valid);
-  if ((threadIdx.x & 63) == 0 && ball) atomicAdd(&counts[n * 4 + 0], __popcll(ball));
+  if (above < pre_n && above + s >= pre_n) {       // the crossing lies in this thread's bins
+    int acc = above;
+    for (int b = PER - 1; b >= 0; --b) {
+      acc += h[t * PER + b];
+      if (acc >= pre_n) { tbin[n] = t * PER + b; break; }
+    }
+  }
+}
+
+__global__ void prop_compact_kernel(const u64* __restrict__ keys, int n_anchor, const int* __restrict__ tbin,
+                                    u64* __restrict__ cand, int* __restrict__ ranks, int* __restrict__ counts) {
+  const int n = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 key = i < n_anchor ? keys[(int64_t)n * n_anchor + i] : 0ull;
+  const bool take = key != 0ull && min((int)(key >> 48), HIST_BINS - 1) >= tbin[n];
+  const u64 ball = __ballot(take);
+  if (!ball) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == (__ffsll((long long)ball) - 1)) base = atomicAdd(&counts[n * 4 + 3], __popcll(ball));
+  base = __shfl(base, __ffsll((long long)ball) - 1);
+  if (take) {
+    const int slot = base + __popcll(ball & ((1ull << lane) - 1ull));
+    cand[(int64_t)n * n_anchor + slot] = key;
+    ranks[(int64_t)n * n_anchor + slot] = 0;
+  }
 }
 
 constexpr int RANK_TILE = 1024;
 constexpr int RANK_IPT = 4;      // keys owned per thread (amortises the LDS broadcast reads)
+constexpr int RANK_SPLITS = 8;
 
-// grid (ceil(n/1024), J splits, N): each thread owns 4 keys and counts larger keys in its j slice
-__global__ __launch_bounds__(256) void prop_rank_kernel(const u64* __restrict__ keys, int n_anchor, int j_per_split,
-                                                        int* __restrict__ ranks) {
+// grid (ceil(n_anchor/1024), RANK_SPLITS, N): each thread owns 4 candidate keys and counts larger
+// keys in its slice of the candidate list; workgroups beyond the list length exit at once
+__global__ __launch_bounds__(256) void prop_rank_kernel(const u64* __restrict__ cand, int n_anchor,
+                                                        const int* __restrict__ counts, int* __restrict__ ranks) {
   __shared__ u64 tile[RANK_TILE];
   const int n = blockIdx.z;
-  const u64* k = keys + (int64_t)n * n_anchor;
+  const int c = counts[n * 4 + 3];
+  const int i0 = blockIdx.x * (256 * RANK_IPT);
+  const int jps = ((c + RANK_SPLITS - 1) / RANK_SPLITS + RANK_TILE - 1) / RANK_TILE * RANK_TILE;
+  const int j0 = blockIdx.y * jps;
+  if (i0 >= c || j0 >= c) return;
+  const int j1 = min(j0 + jps, c);
+  const u64* k = cand + (int64_t)n * n_anchor;
   u64 mine[RANK_IPT];
   int cnt[RANK_IPT];
-  bool any = false;
 #pragma unroll
   for (int q = 0; q < RANK_IPT; ++q) {
-    const int i = blockIdx.x * (256 * RANK_IPT) + q * 256 + threadIdx.x;
-    mine[q] = i < n_anchor ? k[i] : 0ull;
+    const int i = i0 + q * 256 + threadIdx.x;
+    mine[q] = i < c ? k[i] : ~0ull;
     cnt[q] = 0;
-    any |= mine[q] != 0ull;
   }
-  const int j0 = blockIdx.y * j_per_split;
-  const int j1 = min(j0 + j_per_split, n_anchor);
   for (int jb = j0; jb < j1; jb += RANK_TILE) {
     __syncthreads();
     for (int t = threadIdx.x; t < RANK_TILE; t += 256) tile[t] = (jb + t < j1) ? k[jb + t] : 0ull;
     __syncthreads();
-    if (any) {
 #pragma unroll 4
-      for (int t = 0; t < RANK_TILE; ++t) {
-        const u64 o = tile[t];
+    for (int t = 0; t < RANK_TILE; ++t) {
+      const u64 o = tile[t];
 #pragma unroll
-        for (int q = 0; q < RANK_IPT; ++q) cnt[q] += o > mine[q];
-      }
+      for (int q = 0; q < RANK_IPT; ++q) cnt[q] += o > mine[q];
     }
   }
 #pragma unroll
   for (int q = 0; q < RANK_IPT; ++q) {
-    const int i = blockIdx.x * (256 * RANK_IPT) + q * 256 + threadIdx.x;
-    if (mine[q] != 0ull && cnt[q]) atomicAdd(&ranks[(int64_t)n * n_anchor + i], cnt[q]);
+    const int i = i0 + q * 256 + threadIdx.x;
+    if (i < c && cnt[q]) atomicAdd(&ranks[(int64_t)n * n_anchor + i], cnt[q]);
   }
 }
 
-__global__ void prop_scatter_kernel(const u64* __restrict__ keys, const int* __restrict__ ranks,
+__global__ void prop_scatter_kernel(const u64* __restrict__ cand, const int* __restrict__ ranks,
                                     const float* __restrict__ cboxes, int n_anchor, int pre_n,
-                                    float* __restrict__ sboxes, float* __restrict__ sscores, int* __restrict__ counts) {
+                                    const int* __restrict__ counts, float* __restrict__ sboxes,
+                                    float* __restrict__ sscores) {
   const int n = blockIdx.y;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) counts[n * 4 + 1] = min(counts[n * 4 + 0], pre_n);   // n_cand
-  if (i >= n_anchor) return;
-  const int64_t g = (int64_t)n * n_anchor + i;
-  const u64 key = keys[g];
-  if (key == 0ull) return;
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= counts[n * 4 + 3]) return;
+  const int64_t g = (int64_t)n * n_anchor + slot;
   const int r = ranks[g];
-  if (r < pre_n) {
-    *reinterpret_cast<float4*>(sboxes + ((int64_t)n * pre_n + r) * 4) = *reinterpret_cast<const float4*>(cboxes + g * 4);
-    sscores[(int64_t)n * pre_n + r] = __uint_as_float((unsigned)(key >> 32));
-  }
+  if (r >= pre_n) return;
+  const u64 key = cand[g];
+  const unsigned idx = 0xFFFFFFFFu - (unsigned)key;
+  *reinterpret_cast<float4*>(sboxes + ((int64_t)n * pre_n + r) * 4) =
+      *reinterpret_cast<const float4*>(cboxes + ((int64_t)n * n_anchor + idx) * 4);
+  sscores[(int64_t)n * pre_n + r] = __uint_as_float((unsigned)(key >> 32));
 }
 
 // IoU as tf.image.non_max_suppression computes it (NonMaxSuppressionV2): corners min/max
@@ -195,84 +253,120 @@ __device__ __forceinline__ bool iou_gt(const float4 a, const float4 b, float thr
   return inter / ((aa + ab) - inter) > thr;
 }
 
-// grid (W64 col blocks, W64 row blocks, N), 64 threads: thread t = row rb*64+t against 64 columns
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ sboxes, const int* __restrict__ counts,
-                                                      int pre_n, int w64, float thr, u64* __restrict__ mask) {
-  const int n = blockIdx.z;
-  const int cb = blockIdx.x, rb = blockIdx.y;
-  const int n_cand = counts[n * 4 + 1];
-  const int row = rb * 64 + threadIdx.x;
-  if (rb * 64 >= n_cand) return;                 // rows never visited by the scan
-  u64 bits = 0ull;
-  if (cb >= rb && cb * 64 < n_cand) {
-    __shared__ float4 cbox[64];
-    const int col = cb * 64 + threadIdx.x;
-    cbox[threadIdx.x] = col < n_cand ? *reinterpret_cast<const float4*>(sboxes + ((int64_t)n * pre_n + col) * 4)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-    if (row < n_cand) {
-      const float4 me = *reinterpret_cast<const float4*>(sboxes + ((int64_t)n * pre_n + row) * 4);
-      const int jstart = (cb == rb) ? threadIdx.x + 1 : 0;
-      for (int j = jstart; j < 64; ++j) {
-        if (cb * 64 + j < n_cand && iou_gt(me, cbox[j], thr)) bits |= 1ull << j;
-      }
-    }
-  }
-  if (row < pre_n) mask[((int64_t)n * pre_n + row) * w64 + cb] = bits;
-}
-
 __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
   const unsigned lo = __shfl((unsigned)v, src), hi = __shfl((unsigned)(v >> 32), src);
   return ((u64)hi << 32) | lo;
 }
 
-// one wavefront per image; MAXW = max mask words per lane (w64 <= 64*MAXW)
-template <int MAXW>
-__global__ __launch_bounds__(64) void nms_scan_kernel(const u64* __restrict__ mask, int* __restrict__ counts,
-                                                      int pre_n, int w64, int post_n, int* __restrict__ kept) {
+constexpr int NMS_MAXW = 256;        // 64-bit words per bit row: pre_n <= 16384
+
+// IoU(a,b) > thr with the reference's rounding, but without a division on the fast path: the
+// correctly rounded quotient can only disagree with a product test inside a 1e-5 relative band
+// around the threshold; only there is the division actually evaluated.
+__device__ __forceinline__ bool iou_gt_fast(const float4 a, const float4 b, float thr) {
+  const float ay0 = fminf(a.x, a.z), ay1 = fmaxf(a.x, a.z), ax0 = fminf(a.y, a.w), ax1 = fmaxf(a.y, a.w);
+  const float by0 = fminf(b.x, b.z), by1 = fmaxf(b.x, b.z), bx0 = fminf(b.y, b.w), bx1 = fmaxf(b.y, b.w);
+  const float ih = fminf(ay1, by1) - fmaxf(ay0, by0);
+  const float iw = fminf(ax1, bx1) - fmaxf(ax0, bx0);
+  if (ih <= 0.f || iw <= 0.f) return false;          // no overlap: IoU = 0 <= thr (thr >= 0)
+  const float aa = (ay1 - ay0) * (ax1 - ax0);
+  const float ab = (by1 - by0) * (bx1 - bx0);
+  if (aa <= 0.f || ab <= 0.f) return false;
+  const float inter = ih * iw;
+  const float uni = (aa + ab) - inter;
+  const float t = thr * uni;
+  if (inter > t * 1.00001f) return true;
+  if (inter < t * 0.99999f) return false;
+  return inter / uni > thr;
+}
+
+// bit (i,j) = IoU(i,j) > thr for j > i, 64x64 tiles, upper triangle only (the scan never reads
+// words left of the diagonal).  grid (ceil(w64/4), w64, N): wave w of a workgroup = column block
+// blockIdx.x*4 + w, lane = row of row block blockIdx.y.
+__global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ sboxes, const int* __restrict__ counts,
+                                                       int pre_n, int w64, float thr, u64* __restrict__ mask) {
+  __shared__ float4 cbox[4][64];
+  const int n = blockIdx.z;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int rb = blockIdx.y, cb = blockIdx.x * 4 + wv;
+  const int n_cand = counts[n * 4 + 1];
+  if (rb * 64 >= n_cand) return;                 // rows never visited by the scan (workgroup-uniform)
+  const bool active = cb >= rb && cb < w64 && cb * 64 < n_cand;
+  const float4* B = reinterpret_cast<const float4*>(sboxes) + (int64_t)n * pre_n;
+  if (active) {
+    const int col = cb * 64 + lane;
+    cbox[wv][lane] = col < n_cand ? B[col] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  if (!active) return;
+  const int row = rb * 64 + lane;
+  u64 bits = 0ull;
+  if (row < n_cand) {
+    const float4 me = B[row];
+    const int jstart = (cb == rb) ? lane + 1 : 0;
+    const int jend = min(64, n_cand - cb * 64);
+    for (int j = jstart; j < jend; ++j)
+      if (iou_gt_fast(me, cbox[wv][j], thr)) bits |= 1ull << j;
+  }
+  mask[((int64_t)n * pre_n + row) * w64 + cb] = bits;
+}
+
+// Greedy scan in score order, one 256-thread workgroup per image, 64 candidates per round: the
+// round's bit rows (words right of the diagonal) are staged in LDS by all threads, wave 0 resolves
+// the 64x64 diagonal block serially (wave-uniform), records the kept candidates and ORs their rows
+// into the removed set.  Stops as soon as post_n candidates are kept.
+__global__ __launch_bounds__(256) void nms_scan_kernel(const u64* __restrict__ mask, int* __restrict__ counts,
+                                                       int pre_n, int w64, int post_n, int* __restrict__ kept) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
+  u64* Mr = reinterpret_cast<u64*>(nms_smem);             // [64][w64] staged rows of the round
+  u64* removed = Mr + 64 * w64;                          // [w64]
+  __shared__ int s_keep;
   const int n = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_cand = counts[n * 4 + 1];
   const u64* M = mask + (int64_t)n * pre_n * w64;
   int* K = kept + (int64_t)n * post_n;
-  u64 removed[MAXW];
-#pragma unroll
-  for (int q = 0; q < MAXW; ++q) removed[q] = 0ull;
-  int n_keep = 0;
+  for (int w = tid; w < w64; w += 256) removed[w] = 0ull;
+  if (tid == 0) s_keep = 0;
+  __syncthreads();
   const int n_chunk = (n_cand + 63) / 64;
-  for (int c = 0; c < n_chunk && n_keep < post_n; ++c) {
-    const int i = c * 64 + lane;
-    const u64 diag = i < n_cand ? M[(int64_t)i * w64 + c] : 0ull;
-    u64 cur = 0ull;
-#pragma unroll
-    for (int q = 0; q < MAXW; ++q)
-      if ((c >> 6) == q) cur = shfl_u64(removed[q], c & 63);
-    const int lim = min(64, n_cand - c * 64);
-    u64 keepmask = 0ull;
-    int kcount = n_keep;
-    for (int b = 0; b < lim && kcount < post_n; ++b) {     // wave-uniform serial resolve of the 64x64 diagonal tile
-      const u64 d = shfl_u64(diag, b);
-      if (!((cur >> b) & 1ull)) {
-        keepmask |= 1ull << b;
-        cur |= d;
-        ++kcount;
+  for (int c = 0; c < n_chunk; ++c) {
+    if (s_keep >= post_n) break;                         // uniform: s_keep only changes between barriers
+    const int rows = min(64, n_cand - c * 64), nw = n_chunk - c;
+    for (int e = tid; e < rows * nw; e += 256) {
+      const int r = e / nw, k = e - r * nw;
+      Mr[r * w64 + c + k] = M[(int64_t)(c * 64 + r) * w64 + c + k];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int i = c * 64 + lane;
+      const u64 diag = lane < rows ? Mr[lane * w64 + c] : 0ull;
+      u64 cur = removed[c];
+      u64 keepmask = 0ull;
+      const int n_keep = s_keep;
+      int kc = n_keep;
+      for (int b = 0; b < rows && kc < post_n; ++b) {
+        const u64 d = shfl_u64(diag, b);
+        if (!((cur >> b) & 1ull)) { keepmask |= 1ull << b; cur |= d; ++kc; }
       }
+      if ((keepmask >> lane) & 1ull) K[n_keep + __popcll(keepmask & ((1ull << lane) - 1ull))] = i;
+      if (kc < post_n) {
+        for (int w = c + 1 + lane; w < n_chunk; w += 64) {
+          u64 acc = removed[w];
+          u64 km = keepmask;
+          while (km) {
+            const int b = __ffsll((long long)km) - 1;
+            km &= km - 1ull;
+            acc |= Mr[b * w64 + w];
+          }
+          removed[w] = acc;
+        }
+      }
+      if (lane == 0) s_keep = kc;
     }
-    if ((keepmask >> lane) & 1ull) K[n_keep + __popcll(keepmask & ((1ull << lane) - 1ull))] = i;
-    n_keep = kcount;
-    if (n_keep >= post_n) break;
-    // fold the kept rows into the removed set (independent loads, no serial dependency)
-    u64 km = keepmask;
-    while (km) {
-      const int b = __ffsll((long long)km) - 1;
-      km &= km - 1ull;
-      const u64* rowp = M + (int64_t)(c * 64 + b) * w64;
-#pragma unroll
-      for (int q = 0; q < MAXW; ++q)
-        if (q * 64 + lane < w64) removed[q] |= rowp[q * 64 + lane];
-    }
+    __syncthreads();
   }
-  if (lane == 0) counts[n * 4 + 2] = n_keep;
+  if (tid == 0) counts[n * 4 + 2] = s_keep;
 }
 
 __global__ void prop_gather_kernel(const float* __restrict__ sboxes, const int* __restrict__ kept,
@@ -293,33 +387,36 @@ int launch_get_proposals(const float* objectness, const float* boxes, int N, int
                          float nms_thr, float min_size, const ProposalWorkspace& ws, float* rois, hipStream_t s) {
   XDET_REQUIRE(N > 0 && n_anchor > 0 && pre_n > 0 && post_n > 0, "get_proposals: sizes must be positive");
   const int w64 = (int)cdiv(pre_n, 64);
-  XDET_REQUIRE(w64 <= 64 * 4, "get_proposals: rpn_pre_nms_top_n too large (max 16384)");
-  XDET_HIP(hipMemsetAsync(ws.counts, 0, (size_t)N * 16, s));
+  XDET_REQUIRE(w64 <= NMS_MAXW, "get_proposals: rpn_pre_nms_top_n too large (max 16384)");
+  XDET_HIP(hipMemsetAsync(ws.hist, 0, (size_t)N * HIST_BINS * 4, s));
   XDET_HIP(hipMemsetAsync(ws.sboxes, 0, (size_t)N * pre_n * 16, s));
   XDET_HIP(hipMemsetAsync(ws.sscores, 0, (size_t)N * pre_n * 4, s));
   const unsigned gb = (unsigned)cdiv(n_anchor, 256);
   hipLaunchKernelGGL(prop_prepare_kernel, dim3(gb, N), dim3(256), 0, s, objectness, boxes, n_anchor, min_size,
-                     ws.keys, ws.cboxes, ws.ranks, ws.counts);
+                     ws.keys, ws.cboxes, ws.hist);
   XDET_LAUNCH_CHECK();
-  const unsigned gr = (unsigned)cdiv(n_anchor, 256 * RANK_IPT);
-  const int splits = std::max(1, std::min<int>((int)cdiv(n_anchor, RANK_TILE), 2048 / (int)(gr * N) + 1));
-  const int j_per_split = (int)cdiv(cdiv(n_anchor, splits), RANK_TILE) * RANK_TILE;
-  hipLaunchKernelGGL(prop_rank_kernel, dim3(gr, (unsigned)cdiv(n_anchor, j_per_split), N), dim3(256), 0, s, ws.keys,
-                     n_anchor, j_per_split, ws.ranks);
+  hipLaunchKernelGGL(prop_select_kernel, dim3(N), dim3(1024), 0, s, ws.hist, pre_n, ws.tbin, ws.counts);
   XDET_LAUNCH_CHECK();
-  hipLaunchKernelGGL(prop_scatter_kernel, dim3(gb, N), dim3(256), 0, s, ws.keys, ws.ranks, ws.cboxes, n_anchor, pre_n,
-                     ws.sboxes, ws.sscores, ws.counts);
+  hipLaunchKernelGGL(prop_compact_kernel, dim3(gb, N), dim3(256), 0, s, ws.keys, n_anchor, ws.tbin, ws.cand, ws.ranks,
+                     ws.counts);
   XDET_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(w64, w64, N), dim3(64), 0, s, ws.sboxes, ws.counts, pre_n, w64, nms_thr,
-                     ws.mask);
+  hipLaunchKernelGGL(prop_rank_kernel, dim3((unsigned)cdiv(n_anchor, 256 * RANK_IPT), RANK_SPLITS, N), dim3(256), 0, s,
+                     ws.cand, n_anchor, ws.counts, ws.ranks);
   XDET_LAUNCH_CHECK();
-  if (w64 <= 64) {
-    hipLaunchKernelGGL(nms_scan_kernel<1>, dim3(N), dim3(64), 0, s, ws.mask, ws.counts, pre_n, w64, post_n, ws.kept);
-  } else if (w64 <= 128) {
-    hipLaunchKernelGGL(nms_scan_kernel<2>, dim3(N), dim3(64), 0, s, ws.mask, ws.counts, pre_n, w64, post_n, ws.kept);
-  } else {
-    hipLaunchKernelGGL(nms_scan_kernel<4>, dim3(N), dim3(64), 0, s, ws.mask, ws.counts, pre_n, w64, post_n, ws.kept);
+  hipLaunchKernelGGL(prop_scatter_kernel, dim3(gb, N), dim3(256), 0, s, ws.cand, ws.ranks, ws.cboxes, n_anchor, pre_n,
+                     ws.counts, ws.sboxes, ws.sscores);
+  XDET_LAUNCH_CHECK();
+  hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)cdiv(w64, 4), w64, N), dim3(256), 0, s, ws.sboxes, ws.counts, pre_n,
+                     w64, nms_thr, ws.mask);
+  XDET_LAUNCH_CHECK();
+  const size_t lds = (size_t)(64 * w64 + w64) * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    XDET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (64 * NMS_MAXW + NMS_MAXW) * 8));
+    attr_set = true;
   }
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(256), lds, s, ws.mask, ws.counts, pre_n, w64, post_n, ws.kept);
   XDET_LAUNCH_CHECK();
   hipLaunchKernelGGL(prop_gather_kernel, dim3((unsigned)cdiv(post_n, 256), N), dim3(256), 0, s, ws.sboxes, ws.kept,
                      ws.counts, pre_n, post_n, rois);
