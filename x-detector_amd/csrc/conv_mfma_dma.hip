@@ -27,8 +27,9 @@ typedef unsigned short u16;
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),              \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(ConvParams p) {
+  static_assert(NSTAGE == 2 || NSTAGE == 3, "2 or 3 LDS stages");
   constexpr int NW = WAVES_M * WAVES_N;          // waves per workgroup (4 or 8)
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -44,8 +45,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (private L2s): give every
+  // XCD whole M-tiles, all N-tiles of one M-tile back to back, so an activation tile is pulled over
+  // the fabric once and then re-read from that XCD's L2 (the weights are small and shared by all).
+  const int nby = p.Cout_pad / BN;
+  const int slot = blockIdx.x >> 3;
+  const int bx = (slot / nby) * 8 + (blockIdx.x & 7);
+  if (bx * BM >= p.M) return;
+  const int m0 = bx * BM;
+  const int n0 = (slot % nby) * BN;
 
   // ---- per-lane DMA descriptors ----
   const int lr = lane >> 2;                      // row within a 16-row DMA slab
@@ -133,11 +141,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
     bsw[j] = (rt >> 2) & 3;
   }
 
+  // DMA instructions one wave issues per stage: the counted wait below leaves exactly the newest
+  // stage in flight (LDS-DMA completions retire in order on vmcnt)
+  constexpr int PER_STAGE = (A_IT + B_IT) * (NSPLIT > 1 ? 2 : 1);
   issue(0, 0);
+  if (NSTAGE == 3 && nk > 1) issue(1, 1);
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    __syncthreads();                             // DMA(kt) landed for every wave; stage buf^1 is free
-    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+    const int buf = kt % NSTAGE;
+    if (NSTAGE == 2) {
+      __syncthreads();                           // DMA(kt) landed for every wave; the other stage is free
+      if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+    } else {
+      // stage kt must have landed, stage kt+1 may still be in flight; raw barrier so that nothing
+      // drains the DMA queue; after it every wave has finished reading stage kt-1 == (kt+2)%3
+      if (kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F70 | (PER_STAGE & 15) | ((PER_STAGE >> 4) << 14));
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < nk) issue(kt + 2, (kt + 2) % NSTAGE);
+    }
     const u16* Ah = smem16 + buf * STAGE;
     const u16* Al = Ah + BM * ROWB;
     const u16* Bh = Al + BM * ROWB;
@@ -199,17 +220,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE = 2>
 static int launch_d(const ConvParams& p, hipStream_t s) {
-  constexpr size_t lds = (size_t)2 * (2 * BM + 2 * BN) * 32 * sizeof(u16);
-  auto kern = conv_dma_f16_kernel<BM, BN, WAVES_M, WAVES_N, NSPLIT>;
+  constexpr size_t lds = (size_t)NSTAGE * (2 * BM + 2 * BN) * 32 * sizeof(u16);
+  auto kern = conv_dma_f16_kernel<BM, BN, WAVES_M, WAVES_N, NSPLIT, NSTAGE>;
   static bool attr_set = false;
   if (!attr_set) {
     XDET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
     attr_set = true;
   }
-  dim3 grid((unsigned)cdiv(p.M, BM), (unsigned)(p.Cout_pad / BN));
+  dim3 grid((unsigned)(cdiv(cdiv(p.M, BM), 8) * 8 * (p.Cout_pad / BN)));
   hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, p);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
@@ -235,7 +256,10 @@ int launch_conv_mfma_dma(const ConvParams& p, int n_tile, int nsplit, hipStream_
     else if (b128n >= 170) tile = 1;
     if (tile_env) tile = !strcmp(tile_env, "256x256") ? (p.Cout_pad % 256 == 0 ? 2 : 1) : !strcmp(tile_env, "256x128") ? 1 : 0;
     if (tile == 2) return launch_d<256, 256, 2, 4, 3>(p, s);
-    if (tile == 1) return launch_d<256, 128, 4, 2, 3>(p, s);
+    static const char* st_env = getenv("XDET_STAGES");
+    const bool s3 = st_env && st_env[0] == '3';
+    if (tile == 1) return s3 ? launch_d<256, 128, 4, 2, 3, 3>(p, s) : launch_d<256, 128, 4, 2, 3>(p, s);
+    if (s3) return launch_d<128, 128, 2, 2, 3, 3>(p, s);
   }
   if (n_tile == 128)
     return nsplit == 1 ? launch_d<128, 128, 2, 2, 1>(p, s) : launch_d<128, 128, 2, 2, 3>(p, s);
