@@ -40,15 +40,16 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
     ap.add_argument('--workload', default='lighthead', choices=['lighthead', 'resnet50'])
     ap.add_argument('--proposals', type=int, default=300, help='rpn_post_nms_top_n (BASELINE config 3: 300)')
-    ap.add_argument('--precision', default='f32', choices=['f32', 'f16x3', 'f16'],
+    ap.add_argument('--precision', default='f16x3', choices=['f32', 'f16x3', 'f16'],
                     help='conv/dense arithmetic: exact f32 MFMA, split-precision f16 MFMA (~f32 accuracy), plain f16')
     ap.add_argument('--graph', action='store_true', help='replay the forward as a hipGraph (no per-op events)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=4)
     ap.add_argument('--ops', action='store_true', help='also print the per-op table to stderr')
+    ap.add_argument('--no-parity', action='store_true', help='skip the live f16x3-vs-f32 GPU cross-check')
     return ap.parse_args()
 
 
@@ -97,6 +98,30 @@ def cpu_baseline(args, weights):
     return {'value': round(n / dt, 3), 'unit': 'images/sec', 'cores': int(cores), 'kind': 'port', 'sample': what}
 
 
+def live_parity(weights, proposals):
+    """Cross-check of the split-precision path against the exact-f32 MFMA path of the same library on
+    2 seeded images (both are product code; the CPU oracle comparison lives in tests/)."""
+    from xdet import weights as W
+    from xdet.model import LightHeadDetector
+    from xdet.runtime import set_precision, get_precision
+    imgs = W.synthetic_images(2, 480, seed=7)
+    cur = get_precision()
+    res = {}
+    for mode in (cur, 'f32'):
+        set_precision(mode)
+        det = LightHeadDetector(weights, image_size=480, max_batch=2, rpn_post_nms_top_n=proposals)
+        det.forward(imgs)
+        res[mode] = (det.buffer('feat', 2).numpy(), det.detections(2))
+        del det
+    set_precision(cur)
+    fa, (sa, ba) = res[cur]
+    fb, (sb, bb) = res['f32']
+    nd = int((sb > 0).sum())
+    same = int(((np.abs(sa - sb) < 1e-3) & (np.abs(ba - bb).max(-1) < 1e-3) & (sb > 0)).sum())
+    return {'vs': 'f32 MFMA path, same inputs', 'feat_max_abs_err': float(np.abs(fa - fb).max()),
+            'feat_absmax': float(np.abs(fb).max()), 'detections': nd, 'same_slot_within_1e-3': same}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', '0'))
@@ -104,7 +129,9 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     dist = None
     torch = None
-    if world > 1:
+    # under torch.distributed.run (RANK set) the collective path is exercised even for one rank
+    use_dist = world > 1 or ('RANK' in os.environ and os.environ.get('XDET_BENCH_NO_DIST') != '1')
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -130,7 +157,7 @@ def main():
         net.set_images(W.synthetic_images(B, 480, seed=100 + rank))
         nc, topk = net.num_classes - 1, net.nms_topk
         gather = None
-        if world > 1:
+        if use_dist:
             # detections land in torch-owned device memory so RCCL can gather them in place
             sc = torch.zeros((B, nc, topk), dtype=torch.float32, device='cuda')
             bx = torch.zeros((B, nc, topk, 4), dtype=torch.float32, device='cuda')
@@ -159,7 +186,7 @@ def main():
 
     def sync_all():
         net.stream.synchronize()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -184,7 +211,7 @@ def main():
     if profile:
         check(lib().xdet_profile_enable(net.handle, kind, 0))
 
-    if world > 1:
+    if use_dist:
         dt = xdist.max_over_ranks(dt, device='cuda')
 
     if rank == 0:
@@ -197,10 +224,11 @@ def main():
         if conv_ms > 0:
             ach = conv_flops / (conv_ms * 1e-3) / 1e12
             peak = PEAK_F32_MFMA_TFLOPS if args.precision == 'f32' else PEAK_F16_MFMA_TFLOPS
-            kname = 'conv_mfma_f32_kernel' if args.precision == 'f32' else 'conv_mfma_split_kernel'
+            kname = 'conv_mfma_f32_kernel' if args.precision == 'f32' else 'conv_dma_f16_kernel (+conv_mfma_f16_kernel for the 5 small/strided convs)'
             roof = {'bound': 'mfma', 'kernel': kname, 'achieved': round(ach, 2),
                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                     'mfma_issued_tflops': round(ach * (3 if args.precision == 'f16x3' else 1), 2),
+                    'mfma_util': round(ach * (3 if args.precision == 'f16x3' else 1) / peak, 4),
                     'traffic': None, 'launches_per_step': conv_launches // K,
                     'avg_launch_us': round(conv_ms * 1e3 / max(conv_launches, 1), 2),
                     'kernel_ms_per_step': round(conv_ms / K, 3), 'gflop_per_image': round(flops_img / 1e9, 2),
@@ -221,6 +249,8 @@ def main():
             'gflop_per_image': {k: round(v / 1e9, 2) for k, v in fl.items()},
             'roofline': roof,
         }
+        if args.workload == 'lighthead' and args.precision != 'f32' and not args.no_parity:
+            out['parity'] = live_parity(weights, args.proposals)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, weights)
         else:
@@ -232,7 +262,7 @@ def main():
                 sys.stderr.write('%-52s %8.3f ms/step %5.1f%%  %7.1f TFLOP/s\n' % (name, ms / K, 100 * ms / tot, tf))
             sys.stderr.write('planned ops %.3f ms/step of %.3f ms/step\n' % (tot / K, ms_per_step))
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

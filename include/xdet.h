@@ -103,6 +103,10 @@ int xdet_depthwise_forward(void* layer, const float* in, int N, int H, int W, in
 int xdet_maxpool3x3s2_add(const float* in, const float* residual, float* out, int N, int H, int W, int C, int ld,
                           void* stream);
 int xdet_nchw_to_nhwc4(const float* in_nchw, float* out_nhwc4, int N, int C, int H, int W, void* stream);
+/* F1: light_head_preprocess_for_eval / _for_test (preprocessing/common_preprocessing.py:383-458), fused:
+ * uint8 [H,W,3] (device) -> whitened f32, TF-legacy bilinear warp to out_size x out_size, CHW
+ * (one image of the [N,3,S,S] network input); bbox_img is the constant [0,0,1,1]. */
+int xdet_preprocess_eval(const uint8_t* image_hwc, int H, int W, float* out_chw, int out_size, void* stream);
 
 /* ---- A4+A6: RPN glue + AnchorEncoder.decode_all_anchors ----------------------------------
  * (light_head_rfcn_eval.py:389-397; preprocessing/anchor_manipulator.py:641-669,698-757)

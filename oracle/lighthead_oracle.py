@@ -622,3 +622,31 @@ def resnet50_trunk(x, w, taps=None):
             y = conv(y, 1, 1)
             x = y + shortcut
     return bn_relu(x)
+
+
+# ----------------------------------------------------------------------------------------
+# F1  light_head_preprocess_for_eval / _for_test (preprocessing/common_preprocessing.py:383-458,
+#     tf_image.resize_image :307-319); TF1 legacy bilinear restated from TF's published kernel
+#     (src = dst*in/out, no half-pixel centre) -- parity unpinned like the other TF kernels.
+# ----------------------------------------------------------------------------------------
+
+def preprocess_for_eval(image_u8, out_size=480):
+    """uint8 [H,W,3] -> f32 [3,S,S] (data_format 'NCHW')."""
+    img = np.asarray(image_u8, np.uint8)
+    H, W = img.shape[:2]
+    S = out_size
+    means = np.array([123.68 / 127.5, 116.78 / 127.5, 103.94 / 127.5]).astype(F32)
+    x = ((img.astype(F32) * F32(1.0 / 255.0)) * F32(2.0) - means).astype(F32)
+    hs, ws = F32(F32(H) / F32(S)), F32(F32(W) / F32(S))
+    fy = (np.arange(S, dtype=F32) * hs).astype(F32)
+    fx = (np.arange(S, dtype=F32) * ws).astype(F32)
+    y0, x0 = fy.astype(np.int64), fx.astype(np.int64)
+    y1, x1 = np.minimum(y0 + 1, H - 1), np.minimum(x0 + 1, W - 1)
+    ly = (fy - y0.astype(F32)).astype(F32)[:, None, None]
+    lx = (fx - x0.astype(F32)).astype(F32)[None, :, None]
+    tl, tr = x[y0][:, x0], x[y0][:, x1]
+    bl, br = x[y1][:, x0], x[y1][:, x1]
+    top = (tl + ((tr - tl) * lx).astype(F32)).astype(F32)
+    bot = (bl + ((br - bl) * lx).astype(F32)).astype(F32)
+    out = (top + ((bot - top) * ly).astype(F32)).astype(F32)
+    return np.ascontiguousarray(out.transpose(2, 0, 1))

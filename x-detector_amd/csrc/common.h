@@ -75,6 +75,9 @@ int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, in
 int launch_depthwise3x3_split(const float* in, const float* w9c, unsigned short* hi, unsigned short* lo, int N,
                               int H, int W, int C, int ld, int dil, int relu_in, hipStream_t s);
 
+// ---- F1 pre-processing (preprocess.hip) ----------------------------------------------
+int launch_preprocess_eval(const unsigned char* img, int H, int W, float* out_chw, int S, hipStream_t s);
+
 // ---- PsRoiAlign (psroialign.hip) -------------------------------------------------------
 int launch_psroialign(const float* feat, const float* rois, float* pooled, int32_t* index, int N, int C, int H,
                       int W, int R, int gw, int gh, int use_max, int layout, int ldc, int out_ld,

@@ -914,6 +914,9 @@ int xdet_maxpool3x3s2_add(const float* in, const float* residual, float* out, in
   same_pad(W, 3, 2, 1, &pl, &Wo);
   return launch_maxpool3x3s2_add(in, residual, out, N, H, W, C, ld, Ho, Wo, pt, pl, S(stream));
 }
+int xdet_preprocess_eval(const uint8_t* image_hwc, int H, int W, float* out_chw, int out_size, void* stream) {
+  return launch_preprocess_eval(image_hwc, H, W, out_chw, out_size, S(stream));
+}
 int xdet_nchw_to_nhwc4(const float* in, float* out, int N, int C, int H, int W, void* stream) {
   return launch_nchw_to_nhwc4(in, out, N, C, H, W, 4, S(stream));
 }

@@ -17,6 +17,7 @@ SOURCES = [
     ('psroialign.hip', ['-ffp-contract=off']),
     ('proposals.hip', ['-ffp-contract=off']),
     ('detect.hip', ['-ffp-contract=off']),
+    ('preprocess.hip', ['-ffp-contract=off']),
     ('net.hip', []),
 ]
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-result']

@@ -38,7 +38,7 @@ def gather_detections(local_packed, world, out=None):
     if out is None:
         out = torch.empty((world * local_packed.shape[0],) + tuple(local_packed.shape[1:]),
                           dtype=local_packed.dtype, device=local_packed.device)
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         out.copy_(local_packed)
         return out
     if dist.get_backend() == 'nccl':

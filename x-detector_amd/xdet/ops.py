@@ -232,3 +232,26 @@ def bboxes_eval(cls_pred_logits, bboxes_pred, image_shape=(480, 480), bbox_img=(
     bx = to_host(d_ob.ptr, (N, nc - 1, nms_topk, 4), np.float32, stream)
     out = [{k + 1: (sc[n, k], bx[n, k]) for k in range(nc - 1)} for n in range(N)]
     return out[0] if single else out
+
+
+def light_head_preprocess_for_eval(image, labels=None, bboxes=None, out_shape=(480, 480), data_format='NHWC',
+                                   difficults=None, stream=None):
+    """preprocessing/common_preprocessing.py:383-440 (Resize.WARP_RESIZE, the eval default):
+    uint8 [H,W,3] -> (image f32 [S,S,3] or [3,S,S], labels, bboxes, bbox_img=[0,0,1,1])."""
+    img = np.ascontiguousarray(image, np.uint8)
+    if img.ndim != 3 or img.shape[2] != 3:
+        raise ValueError('Input must be of size [height, width, C>0]')
+    assert out_shape[0] == out_shape[1], 'square network input'
+    S = int(out_shape[0])
+    d_in = to_device(img)
+    d_out = DeviceBuffer(3 * S * S * 4)
+    check(lib().xdet_preprocess_eval(d_in.ptr, img.shape[0], img.shape[1], d_out.ptr, S,
+                                     stream.handle if stream else None))
+    chw = to_host(d_out.ptr, (3, S, S), np.float32, stream)
+    out = chw if data_format == 'NCHW' else np.ascontiguousarray(chw.transpose(1, 2, 0))
+    return out, labels, bboxes, np.array([0., 0., 1., 1.], np.float32)
+
+
+def light_head_preprocess_for_test(image, out_shape, data_format='NHWC', stream=None):
+    """preprocessing/common_preprocessing.py:442-458."""
+    return light_head_preprocess_for_eval(image, None, None, out_shape, data_format, stream=stream)[0]
