@@ -45,7 +45,8 @@ def parse():
     ap.add_argument('--proposals', type=int, default=300, help='rpn_post_nms_top_n (BASELINE config 3: 300)')
     ap.add_argument('--precision', default='f16x3', choices=['f32', 'f16x3', 'f16'],
                     help='conv/dense arithmetic: exact f32 MFMA, split-precision f16 MFMA (~f32 accuracy), plain f16')
-    ap.add_argument('--graph', action='store_true', help='replay the forward as a hipGraph (no per-op events)')
+    ap.add_argument('--eager', action='store_true',
+                    help='launch kernel by kernel in the timed region (default: replay the captured hipGraph)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=4)
     ap.add_argument('--ops', action='store_true', help='also print the per-op table to stderr')
@@ -96,6 +97,27 @@ def cpu_baseline(args, weights):
     except Exception:
         cores = os.cpu_count()
     return {'value': round(n / dt, 3), 'unit': 'images/sec', 'cores': int(cores), 'kind': 'port', 'sample': what}
+
+
+def traffic_from_profiles(precision):
+    """HBM bytes per conv launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (profiles/<tag>_summary.json, written by tools/summarize_profile.py with the gfx950 x2 read
+    correction); PMC collection cannot run inside the bench itself."""
+    import glob
+    want = 'conv_mfma_f32' if precision == 'f32' else 'conv_dma_f16'
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_summary.json')), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        tot = cnt = 0
+        for k, e in d.get('kernels', {}).items():
+            if want in k and 'hbm_bytes_per_launch' in e:
+                tot += e['hbm_bytes_per_launch'] * e['calls']
+                cnt += e['calls']
+        if cnt:
+            return int(tot / cnt), os.path.relpath(path, ROOT)
+    return None, None
 
 
 def live_parity(weights, proposals):
@@ -164,12 +186,15 @@ def main():
             allb = torch.zeros((world * B, nc, topk, 5), dtype=torch.float32, device='cuda')
             gather = (sc, bx, allb)
 
-        def step():
+        use_graph = not args.eager
+
+        def step(graph=None):
+            g = use_graph if graph is None else graph
             if gather is None:
-                net.forward_device(B, use_graph=args.graph)
+                net.forward_device(B, use_graph=g)
             else:
                 sc, bx, allb = gather
-                net.forward_device(B, use_graph=args.graph, det_scores_ptr=sc.data_ptr(), det_boxes_ptr=bx.data_ptr())
+                net.forward_device(B, use_graph=g, det_scores_ptr=sc.data_ptr(), det_boxes_ptr=bx.data_ptr())
                 net.stream.synchronize()
                 xdist.gather_detections(xdist.pack_detections(sc, bx), world, allb)
     else:
@@ -181,7 +206,9 @@ def main():
         fl = {'backbone': flops_img}
         net.set_images(W.synthetic_images(B, 480, seed=100 + rank))
 
-        def step():
+        use_graph = False
+
+        def step(graph=None):
             net.forward_device(B)
 
     def sync_all():
@@ -194,7 +221,9 @@ def main():
     for _ in range(Wm):
         step()
     sync_all()
-    profile = not args.graph
+    # per-op HIP events cannot be recorded into a captured graph: with graph replay the roofline leg
+    # is an eager, instrumented repeat of the same K steps right after the timed region
+    profile = not use_graph
     if profile:
         check(lib().xdet_profile_enable(net.handle, kind, 1))
     ev0, ev1 = Event(), Event()
@@ -207,9 +236,15 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     dev_ms = ev0.elapsed_ms(ev1)
-    rows = read_profile(net.handle, kind) if profile else []
-    if profile:
-        check(lib().xdet_profile_enable(net.handle, kind, 0))
+    if not profile:
+        step(graph=False)
+        sync_all()
+        check(lib().xdet_profile_enable(net.handle, kind, 1))
+        for _ in range(K):
+            step(graph=False)
+        sync_all()
+    rows = read_profile(net.handle, kind)
+    check(lib().xdet_profile_enable(net.handle, kind, 0))
 
     if use_dist:
         dt = xdist.max_over_ranks(dt, device='cuda')
@@ -229,10 +264,14 @@ def main():
                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                     'mfma_issued_tflops': round(ach * (3 if args.precision == 'f16x3' else 1), 2),
                     'mfma_util': round(ach * (3 if args.precision == 'f16x3' else 1) / peak, 4),
-                    'traffic': None, 'launches_per_step': conv_launches // K,
+                    'traffic': traffic_from_profiles(args.precision)[0],
+                    'traffic_unit': 'HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE), from ' + str(traffic_from_profiles(args.precision)[1]),
+                    'launches_per_step': conv_launches // K,
                     'avg_launch_us': round(conv_ms * 1e3 / max(conv_launches, 1), 2),
                     'kernel_ms_per_step': round(conv_ms / K, 3), 'gflop_per_image': round(flops_img / 1e9, 2),
-                    'how': 'HIP event pair around every conv/dense launch inside the timed region'}
+                    'how': ('HIP event pair around every conv/dense launch on its launch stream, ' +
+                            ('in an eager repeat of the same K steps right after the graph-replayed timed region'
+                             if use_graph else 'inside the timed region'))}
         out = {
             'metric': 'images/sec at 480x480 Light-Head R-CNN, 1/2/4/8 MI355X + backbone MFMA util%',
             'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': K, 'warmup': Wm,
@@ -244,7 +283,7 @@ def main():
                        if args.workload == 'lighthead' else 'ResNet-50 v2 trunk only (BASELINE config 2), 480x480',
                        'batch_per_gpu': B, 'global_batch': B * world, 'image_size': 480,
                        'parallelism': 'image-sharded dp%d, all-gather of detections' % world,
-                       'weights': 'seeded random init (no checkpoint exists)', 'graph_replay': bool(args.graph)},
+                       'weights': 'seeded random init (no checkpoint exists)', 'graph_replay': bool(use_graph)},
             'device_ms_per_step': round(dev_ms / K, 3),
             'gflop_per_image': {k: round(v / 1e9, 2) for k, v in fl.items()},
             'roofline': roof,

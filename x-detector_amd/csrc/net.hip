@@ -474,6 +474,8 @@ struct LightHeadNet : Plan {
   int* def_shapes = nullptr;
   float* def_bbox = nullptr;
   int fmap = 0, n_anchor = 0;
+  hipStream_t aux = nullptr;            // side stream of the RPN/proposal branch
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::map<int, hipGraphExec_t> graphs;
   std::map<int, const float*> graph_inputs;
 
@@ -714,10 +716,21 @@ struct LightHeadNet : Plan {
   int forward_eager(const float* images, int N, const int* shapes, const float* bbox, float* ds, float* db,
                     hipStream_t s) {
     XDET_TRY(xception_body(images, N, s));
-    XDET_TRY(run_stage(ST_RPN, N, s));
+    // fork: the RPN branch (3x3 conv, 1x1 heads, decode, top-k, NMS -- mostly small latency-bound
+    // launches) runs on a side stream under the large-separable convs, which depend only on `out`
+    if (!aux) {
+      XDET_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+      XDET_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+      XDET_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+    XDET_HIP(hipEventRecord(ev_fork, s));
+    XDET_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+    XDET_TRY(run_stage(ST_RPN, N, aux));
+    XDET_TRY(rpn_decode(N, aux));
+    XDET_TRY(get_proposals(N, aux));
+    XDET_HIP(hipEventRecord(ev_join, aux));
     XDET_TRY(run_stage(ST_LSEP, N, s));
-    XDET_TRY(rpn_decode(N, s));
-    XDET_TRY(get_proposals(N, s));
+    XDET_HIP(hipStreamWaitEvent(s, ev_join, 0));   // join before the head consumes the proposals
     XDET_TRY(get_head(N, s));
     XDET_TRY(head_decode(N, s));
     return bboxes_eval(N, shapes, bbox, ds, db, s);
