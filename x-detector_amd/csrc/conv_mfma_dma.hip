@@ -199,22 +199,46 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
     }
   }
 
+  // Epilogue.  The MFMA accumulator layout gives each lane one column and 16 scattered rows, i.e.
+  // 4-byte global stores (and residual loads).  Bounce each 32-row slab of the wave tile through
+  // the (now idle) operand LDS so a lane owns 4 consecutive channels of a row: 16-B coalesced
+  // residual loads and stores, 4x fewer memory instructions.
+  constexpr int EP_LD = WN + 4;                  // floats per staged row (+4: keeps float4 rows 16-B aligned)
+  constexpr int C4N = WN / 4;                    // float4 columns per row
+  static_assert(NW * 32 * EP_LD * 4 <= NSTAGE * STAGE * 2, "epilogue staging must fit the operand LDS");
+  __syncthreads();                               // every wave is done reading its operands
+  float* ep = reinterpret_cast<float*>(smem16) + wave * (32 * EP_LD);
+  const int c4 = lane % C4N;                     // fixed per lane: its 4 output channels
+  const int co4 = n0 + wn * WN + c4 * 4;
+  const bool col_ok = co4 < p.ldo;
+  float4 sc4 = make_float4(0.f, 0.f, 0.f, 0.f), sh4 = sc4;
+  if (col_ok) {
+    sc4 = *reinterpret_cast<const float4*>(p.scale + co4);
+    sh4 = *reinterpret_cast<const float4*>(p.shift + co4);
+  }
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int co = n0 + wn * WN + j * 32 + frow;
-    if (co >= p.ldo) continue;
-    const float sc = p.scale[co], sh = p.shift[co];
+  for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (m < p.M) {
-          float v = fmaf(acc[i][j][r], sc, sh);
-          if (p.res) v += p.res[(size_t)m * p.ldr + co];
-          if (p.relu_out) v = fmaxf(v, 0.f);
-          p.out[(size_t)m * p.ldo + co] = v;
+      for (int r = 0; r < 16; ++r)
+        ep[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP_LD + j * 32 + frow] = acc[i][j][r];
+#pragma unroll
+    for (int q = 0; q < (32 * C4N) / 64; ++q) {
+      const int row = (q * 64 + lane) / C4N;
+      const float4 a = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4 * 4);
+      const int m = m0 + wm * WM + i * 32 + row;
+      if (col_ok && m < p.M) {
+        float4 v = make_float4(fmaf(a.x, sc4.x, sh4.x), fmaf(a.y, sc4.y, sh4.y), fmaf(a.z, sc4.z, sh4.z),
+                               fmaf(a.w, sc4.w, sh4.w));
+        if (p.res) {
+          const float4 rr = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldr + co4);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
+        if (p.relu_out) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + co4) = v;
       }
     }
   }
