@@ -5,12 +5,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_resnet50_trunk_matches_oracle(oracle):
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_resnet50_trunk_matches_oracle(oracle, precision):
     from xdet import weights as W
     from xdet.resnet import ResNet50Trunk
+    from xdet.runtime import set_precision
     w = W.make_resnet50_weights(4321)
     imgs = W.synthetic_images(2, 480, seed=1)
-    net = ResNet50Trunk(w, image_size=480, max_batch=2)
+    set_precision(precision)
+    try:
+        net = ResNet50Trunk(w, image_size=480, max_batch=2)
+    finally:
+        set_precision('f32')
     y = net.forward(imgs)
     ref = oracle.resnet50_trunk(np.transpose(imgs, (0, 2, 3, 1)), w)
     assert y.shape == ref.shape == (2, 15, 15, 2048)          # total stride 32 as written in the file
