@@ -125,3 +125,35 @@ def test_graph_builder_api_mirrors_reference(run, oracle, lh_weights):
         c, r = M.get_head(tr['feat'], None, 7, 7, None, tr['proposals'], 21, False, False, 0, 'channels_first',
                           'final_head')
         assert np.abs(c - tr['cls']).max() < 2e-4 and np.abs(r - tr['reg']).max() < 2e-4
+
+
+@pytest.mark.parametrize('size,R', [(800, 300), (480, 1000)])
+def test_other_baseline_configs(size, R, oracle, lh_weights):
+    """BASELINE config 5 shape (800x800 -> 50x50 map, 55,000 anchors) and the reference's default
+    rpn_post_nms_top_n=1000 (light_head_rfcn_eval.py:111), default product arithmetic (f16x3)."""
+    from xdet import weights as W
+    from xdet.model import LightHeadDetector
+    from xdet.runtime import set_precision
+    imgs = W.synthetic_images(1, size, seed=size)
+    set_precision('f16x3')
+    try:
+        det = LightHeadDetector(lh_weights, image_size=size, max_batch=1, rpn_post_nms_top_n=R)
+    finally:
+        set_precision('f32')
+    got = det.forward(imgs)
+    tr = {}
+    ref = oracle.lighthead_forward(imgs, lh_weights, rpn_post_nms_top_n=R, trace=tr)
+    fm = size // 16
+    assert tr['feat'].shape == (1, fm, fm, 490)
+    assert rel_err(det.buffer('feat', 1).numpy(), tr['feat']) < 1e-4
+    props = det.flat('proposals', (1, R, 4))
+    # proposals as sets: with up to 5000 candidates walked, an IoU that sits within float noise of the
+    # 0.7 threshold may legitimately flip one NMS decision; count instead of demanding identity
+    d = np.abs(props[0][:, None, :] - tr['proposals'][0][None, :, :]).max(-1)
+    n_same = int((d.min(1) < TOL).sum())
+    print('size %d R %d: proposals with a match in the oracle set: %d / %d' % (size, R, n_same, R))
+    assert n_same >= R - max(2, R // 100)
+    total, matched, extra = match_detections(got[0], ref[0])
+    print('size %d R %d: oracle detections %d matched %d extra %d' % (size, R, total, matched, extra))
+    assert total > 20
+    assert matched >= total - max(2, total // 50) and extra <= max(2, total // 50)
