@@ -40,7 +40,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=64, help='images per GPU per step')
     ap.add_argument('--workload', default='lighthead', choices=['lighthead', 'resnet50'])
     ap.add_argument('--proposals', type=int, default=300, help='rpn_post_nms_top_n (BASELINE config 3: 300)')
     ap.add_argument('--precision', default='f16x3', choices=['f32', 'f16x3', 'f16'],

@@ -276,7 +276,11 @@ int launch_conv_mfma_dma(const ConvParams& p, int n_tile, int nsplit, hipStream_
     const int64_t b256 = cdiv(p.M, 256) * (p.Cout_pad / 256), b128n = cdiv(p.M, 256) * (p.Cout_pad / 128);
     const int nk = p.Kp / 32;
     int tile = 0;
-    if (p.Cout_pad % 256 == 0 && (b256 >= 512 || (b256 >= 200 && nk >= 40))) tile = 2;
+    static const char* t256 = getenv("XDET_T256");
+    const int64_t thr256 = t256 ? atoi(t256) : 512;
+    // ...or when the 256x256 grid fills whole rounds of the 256 CUs (within 6 %)
+    const bool full_rounds = b256 >= 240 && (b256 % 256 == 0 || b256 % 256 >= 240);
+    if (p.Cout_pad % 256 == 0 && (b256 >= thr256 || full_rounds || (b256 >= 200 && nk >= 40))) tile = 2;
     else if (b128n >= 170) tile = 1;
     if (tile_env) tile = !strcmp(tile_env, "256x256") ? (p.Cout_pad % 256 == 0 ? 2 : 1) : !strcmp(tile_env, "256x128") ? 1 : 0;
     if (tile == 2) return launch_d<256, 256, 2, 4, 3>(p, s);

@@ -51,7 +51,7 @@ template <int DIL, bool SPLIT>
 __global__ __launch_bounds__(256) void depthwise3x3_kernel(const float* __restrict__ in, const float* __restrict__ w9c,
                                                            float* __restrict__ out, unsigned short* __restrict__ hi,
                                                            unsigned short* __restrict__ lo, int H, int W, int ld,
-                                                           int relu_in) {
+                                                           int relu_in, int nrows) {
   constexpr int NC = DW_SX + 2 * DIL;
   const int c4n = ld >> 2;
   const int nstrip = (W + DW_SX - 1) / DW_SX;
@@ -59,7 +59,11 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const float* __restri
   if (item >= nstrip * c4n) return;
   const int strip = item / c4n;
   const int c = (item - strip * c4n) * 4;
-  const int row = blockIdx.x;                  // n*H + y
+  // XCD-aware row order: workgroups go round-robin to the 8 XCDs; give each XCD a contiguous band of
+  // rows so the two halo rows a row shares with its neighbours are re-read from that XCD's L2
+  const int per_xcd = gridDim.x >> 3;
+  const int row = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // n*H + y
+  if (row >= nrows) return;
   const int y = row % H;
   const int x0 = strip * DW_SX;
   const float* base = in + (size_t)(row - y) * W * ld + c;       // image origin + channel offset
@@ -111,12 +115,13 @@ static int launch_dw(const float* in, const float* w9c, float* out, unsigned sho
   XDET_REQUIRE(dil == 1 || dil == 2, "depthwise: dilation must be 1 or 2");
   if ((int64_t)N * H == 0) return XDET_OK;
   const int items = ((W + DW_SX - 1) / DW_SX) * (ld / 4);
-  const dim3 grid((unsigned)(N * H), (unsigned)cdiv(items, 256));
+  const int nrows = N * H;
+  const dim3 grid((unsigned)(cdiv(nrows, 8) * 8), (unsigned)cdiv(items, 256));
   const bool split = hi != nullptr;
-  if (dil == 1 && !split) hipLaunchKernelGGL((depthwise3x3_kernel<1, false>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in);
-  else if (dil == 1) hipLaunchKernelGGL((depthwise3x3_kernel<1, true>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in);
-  else if (!split) hipLaunchKernelGGL((depthwise3x3_kernel<2, false>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in);
-  else hipLaunchKernelGGL((depthwise3x3_kernel<2, true>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in);
+  if (dil == 1 && !split) hipLaunchKernelGGL((depthwise3x3_kernel<1, false>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows);
+  else if (dil == 1) hipLaunchKernelGGL((depthwise3x3_kernel<1, true>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows);
+  else if (!split) hipLaunchKernelGGL((depthwise3x3_kernel<2, false>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows);
+  else hipLaunchKernelGGL((depthwise3x3_kernel<2, true>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }
@@ -158,13 +163,15 @@ int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, in
 __global__ __launch_bounds__(256) void maxpool3x3s2_add_kernel(const float* __restrict__ in,
                                                                const float* __restrict__ res,
                                                                float* __restrict__ out, int H, int W, int ld, int Ho,
-                                                               int Wo, int pad_t, int pad_l) {
+                                                               int Wo, int pad_t, int pad_l, int norows) {
   const int c4n = ld >> 2;
   const int item = blockIdx.y * 256 + threadIdx.x;
   if (item >= Wo * c4n) return;
   const int ox = item / c4n;
   const int c = (item - ox * c4n) * 4;
-  const int orow = blockIdx.x;                 // n*Ho + oy
+  const int per_xcd = gridDim.x >> 3;          // XCD-aware row bands (see depthwise3x3_kernel)
+  const int orow = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // n*Ho + oy
+  if (orow >= norows) return;
   const int n = orow / Ho;
   const int oy = orow - n * Ho;
   const float* base = in + (size_t)n * H * W * ld + c;
@@ -193,8 +200,9 @@ int launch_maxpool3x3s2_add(const float* in, const float* res, float* out, int N
                             int Ho, int Wo, int pad_t, int pad_l, hipStream_t s) {
   XDET_REQUIRE(ld % 4 == 0 && ld >= C, "maxpool: channel stride must be a multiple of 4");
   if ((int64_t)N * Ho == 0) return XDET_OK;
-  const dim3 grid((unsigned)(N * Ho), (unsigned)cdiv((int64_t)Wo * (ld / 4), 256));
-  hipLaunchKernelGGL(maxpool3x3s2_add_kernel, grid, dim3(256), 0, s, in, res, out, H, W, ld, Ho, Wo, pad_t, pad_l);
+  const dim3 grid((unsigned)(cdiv(N * Ho, 8) * 8), (unsigned)cdiv((int64_t)Wo * (ld / 4), 256));
+  hipLaunchKernelGGL(maxpool3x3s2_add_kernel, grid, dim3(256), 0, s, in, res, out, H, W, ld, Ho, Wo, pad_t, pad_l,
+                     N * Ho);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }
