@@ -184,3 +184,54 @@ def synthetic_images(n, size=480, seed=0):
     preprocessing/common_preprocessing.py:391-392 is about [-0.97, 1.18]."""
     rng = np.random.default_rng(seed)
     return rng.uniform(-1.0, 1.0, (n, 3, size, size)).astype(np.float32)
+
+
+# ---- F3 (SURVEY.md 8f): checkpoint / variable-name import ------------------------------------------------
+
+def lighthead_variable_shapes(**kw):
+    """{TF variable name: shape} of the eval graph (scope prefix stripped) -- what
+    LightHeadDetector / xdet_net_set_weight expect."""
+    out = {}
+    for name, kind, shape in lighthead_tables(**kw):
+        if kind in ('conv', 'convb'):
+            out[name + '/kernel'] = tuple(shape)
+            if kind == 'convb':
+                out[name + '/bias'] = (shape[3],)
+        elif kind == 'sep':
+            out[name + '/depthwise_kernel'] = (3, 3, shape[0], 1)
+            out[name + '/pointwise_kernel'] = (1, 1, shape[0], shape[1])
+        elif kind == 'dense':
+            out[name + '/kernel'] = tuple(shape)
+            out[name + '/bias'] = (shape[1],)
+        else:
+            for v in ('gamma', 'beta', 'moving_mean', 'moving_variance'):
+                out[name + '/' + v] = (shape[0],)
+    return out
+
+
+def load_weights_npz(path, model_scope='xception_lighthead', **kw):
+    """Load a `{tf variable name: array}` archive dumped from the reference's checkpoint
+    (`{v.name: sess.run(v) for v in tf.global_variables()}`; scope `--model_scope`,
+    light_head_rfcn_eval.py:130) into the dict the detector takes: strips `<scope>/` and `:0`,
+    ignores optimizer / global-step variables (the `ignore_missing_vars` spirit of
+    utility/train_helper.py:5-72), and checks names and shapes against the graph's table."""
+    want = lighthead_variable_shapes(**kw)
+    arc = np.load(path)
+    got = {}
+    for k in arc.files:
+        name = k[:-2] if k.endswith(':0') else k
+        if model_scope and name.startswith(model_scope + '/'):
+            name = name[len(model_scope) + 1:]
+        if name in want:
+            a = np.asarray(arc[k], np.float32)
+            if tuple(a.shape) != want[name]:
+                raise ValueError('variable %s has shape %s, expected %s' % (name, a.shape, want[name]))
+            got[name] = a
+    missing = sorted(set(want) - set(got))
+    if missing:
+        raise KeyError('checkpoint is missing %d variables, e.g. %s' % (len(missing), missing[:3]))
+    return got
+
+
+def save_weights_npz(path, weights, model_scope='xception_lighthead'):
+    np.savez(path, **{'%s/%s:0' % (model_scope, k): v for k, v in weights.items()})
