@@ -71,6 +71,20 @@ int xdet_psroialign_fwd(const float* feat, const float* rois, float* pooled, int
                         int W, int R, int grid_w, int grid_h, int use_max, int feat_layout, int ldc, int out_ld,
                         int rois_are_corners, void* stream);
 
+/* ---- F2: PsRoiAlignGrad (training backward of A9) ---------------------------
+ * Replaces op_module.ps_roi_align_grad(inputs, rois, pooled_features_grad, pooled_index,
+ * grid_dim_width, grid_dim_height, pool_method) (REGISTER_OP ps_roi_align_grad_op.cc:39-57; CUDA
+ * kernel ps_roi_align_grad_op.cu:36-171; python gradient registration test_op.py:93-104).
+ *   rois         f32 [N,R,4] (cy,cx,h,w)
+ *   grad_pooled  f32 [N,R,C]   (= [N,R,gh*gw,bank])
+ *   pooled_index i32 [N,R,C]   the forward's argmax sample ids ('max'; may be NULL for 'mean')
+ *   grad_feat    f32 [N,C,H,W] (feat_layout 0) or [N,H,W,ldc] (feat_layout 1); zero-filled, then
+ *                accumulated with float atomics exactly as the reference does -- summation order is
+ *                therefore unspecified and results agree with a sequential evaluation to rounding. */
+int xdet_psroialign_grad(const float* rois, const float* grad_pooled, const int32_t* pooled_index, float* grad_feat,
+                         int N, int C, int H, int W, int R, int grid_w, int grid_h, int use_max, int feat_layout,
+                         int ldc, void* stream);
+
 /* ---- layer objects: the tf.layers.* kernels the graph builders call ---------------------
  * xdet_conv_create: tf.layers.conv2d / dense (+ folded inference BN / bias, + ReLU)
  * (net/xception_body.py:243-265,381-400,450-475,540-558; net/resnet_v2.py:89-100).
@@ -85,12 +99,13 @@ int xdet_conv_create(void** layer, int kh, int kw, int cin, int cout, int stride
 int xdet_conv_forward(void* layer, const float* in, int N, int H, int W, int ld_in, float* out, int ld_out,
                       const float* residual, int relu_in, void* stream);
 int xdet_conv_out_shape(void* layer, int H, int W, int* Ho, int* Wo);
-/* Split-precision operand planes (modes 1/2): x = hi + lo, both f16, same NHWC layout / ld as x.
- * xdet_split_f32 writes them element-wise (optionally through a ReLU); xdet_conv_forward_planes runs a
+/* Split-precision operand planes (modes 1/2): x = hi + lo, both f16, channel-blocked
+ * [ld/32][n_pix][32] with n_pix = N*H*W (the 32-channel slab of consecutive pixels is contiguous:
+ * what one K-step of a conv tile ingests).  xdet_split_f32 (x NHWC [n_pix][ld], ld % 32 == 0) writes them element-wise (optionally through a ReLU); xdet_conv_forward_planes runs a
  * layer whose A operand already lives as planes (LDS-DMA kernel, no register staging).  Inside a
  * net the depthwise kernels and split passes produce the planes; these two entry points expose the
  * same kernels for tests. */
-int xdet_split_f32(const float* in, uint16_t* hi, uint16_t* lo, int64_t n, int relu, void* stream);
+int xdet_split_f32(const float* in, uint16_t* hi, uint16_t* lo, int64_t n_pix, int ld, int relu, void* stream);
 int xdet_conv_forward_planes(void* layer, const uint16_t* in_hi, const uint16_t* in_lo, int N, int H, int W,
                              int ld_in, float* out, int ld_out, const float* residual, void* stream);
 int xdet_layer_destroy(void* layer);

@@ -398,6 +398,7 @@ def _c():
     if _clib is None:
         _clib = ctypes.CDLL(build_c_oracle())
         _clib.oracle_psroialign_fwd.restype = ctypes.c_int
+        _clib.oracle_psroialign_grad.restype = ctypes.c_int
     return _clib
 
 
@@ -423,6 +424,24 @@ def ps_roi_align(inputs, rois, grid_w, grid_h, pool_method='max', layout='NCHW')
     if rc != 0:
         raise ValueError('oracle_psroialign_fwd rc=%d' % rc)
     return pooled, index
+
+
+def ps_roi_align_grad(inputs, rois, pooled_features_grad, pooled_index, grid_w, grid_h, pool_method='max'):
+    """Same positional signature as op_module.ps_roi_align_grad (ps_roi_align_grad_op.cc:39-57;
+    cpp/PSROIPooling/test_op.py:93-104).  inputs only gives the [N,C,H,W] shape."""
+    N, C, H, W = inputs.shape
+    rois = np.ascontiguousarray(rois, F32)
+    g = np.ascontiguousarray(pooled_features_grad, F32)
+    idx = np.ascontiguousarray(pooled_index, np.int32)
+    R = rois.shape[1]
+    out = np.empty((N, C, H, W), F32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    rc = _c().oracle_psroialign_grad(rois.ctypes.data_as(fp), g.ctypes.data_as(fp),
+                                     idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), out.ctypes.data_as(fp),
+                                     N, C, H, W, R, grid_w, grid_h, 1 if 'max' in pool_method else 0, 0, C)
+    if rc != 0:
+        raise ValueError('oracle_psroialign_grad rc=%d' % rc)
+    return out
 
 
 def ps_roi_align_np(inputs, rois, grid_w, grid_h, pool_method='max'):

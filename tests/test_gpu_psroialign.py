@@ -80,3 +80,55 @@ def test_empty_and_errors():
         xdet.ps_roi_align(feat, np.zeros((1, 2, 4), np.float32), -1, 2, 'max')            # grid >= 0
     with pytest.raises(xdet.InvalidArgumentError):
         xdet.ps_roi_align(feat, np.zeros((1, 2, 4), np.float32), 3, 1, 'max')             # C % grid
+
+
+@pytest.mark.parametrize('method', ['max', 'mean'])
+@pytest.mark.parametrize('shape', [(1, 490, 30, 30, 300, 7), (2, 36, 50, 50, 64, 3), (3, 16, 5, 7, 9, 2)])
+def test_grad_matches_oracle(method, shape, oracle):
+    """F2: the backward scatters with float atomics as the reference does (ps_roi_align_grad_op.cu:118-134),
+    so the summation order is unspecified: agreement with the sequential oracle is to rounding
+    (|diff| <= 1e-5 * (sum of |terms|) bound, far below one term), not bit-exact."""
+    import xdet
+    n, c, h, w, r, g = shape
+    rng = np.random.default_rng(9)
+    feat = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    rois = random_rois(rng, n, max(r, 8))[:, :r]
+    _, idx = oracle.ps_roi_align(feat, rois, g, g, method)
+    G = rng.standard_normal(idx.shape).astype(np.float32)
+    got = xdet.ps_roi_align_grad(feat, rois, G, idx, g, g, method)
+    ref = oracle.ps_roi_align_grad(feat, rois, G, idx, g, g, method)
+    mag = oracle.ps_roi_align_grad(feat, rois, np.abs(G), idx, g, g, method)
+    assert got.shape == ref.shape
+    assert np.all(np.abs(got - ref) <= 1e-5 * mag + 1e-30)
+    assert np.array_equal(got == 0, ref == 0) or np.all(np.abs(got - ref)[(got == 0) != (ref == 0)] < 1e-6)
+
+
+def test_grad_roundtrip_with_gpu_forward(oracle):
+    """forward (GPU) -> its own pooled_index -> backward (GPU): adjoint identity on the device path."""
+    import xdet
+    rng = np.random.default_rng(3)
+    n, c, h, w, r, g = 2, 490, 30, 30, 128, 7
+    feat = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    rois = random_rois(rng, n, r)
+    p0, idx = xdet.ps_roi_align(feat, rois, g, g, 'mean')
+    G = rng.standard_normal(p0.shape).astype(np.float32)
+    gx = xdet.ps_roi_align_grad(feat, rois, G, idx, g, g, 'mean')
+    dx = rng.standard_normal(feat.shape).astype(np.float32)
+    p1, _ = xdet.ps_roi_align(feat + dx, rois, g, g, 'mean')
+    lhs = np.sum(gx.astype(np.float64) * dx)
+    rhs = np.sum(G.astype(np.float64) * (p1.astype(np.float64) - p0))
+    assert abs(lhs - rhs) <= 1e-3 * max(abs(lhs), abs(rhs))
+
+
+def test_grad_errors():
+    import xdet
+    feat = np.zeros((1, 8, 4, 4), np.float32)
+    z = np.zeros((1, 2, 4, 2), np.float32)
+    with pytest.raises(xdet.InvalidArgumentError):
+        xdet.ps_roi_align_grad(feat, np.zeros((2, 2, 4), np.float32), z, z.astype(np.int32), 2, 2, 'max')
+    with pytest.raises(xdet.InvalidArgumentError):
+        xdet.ps_roi_align_grad(feat, np.zeros((1, 2, 4), np.float32), z, z.astype(np.int32), 2, 2, 'avg')
+    with pytest.raises(xdet.InvalidArgumentError):
+        xdet.ps_roi_align_grad(feat, np.zeros((1, 2, 4), np.float32), z[:, :1], z.astype(np.int32), 2, 2, 'max')
+    out = xdet.ps_roi_align_grad(feat, np.zeros((1, 2, 4), np.float32), z + 1, z.astype(np.int32), 2, 2, 'max')
+    assert not out.any()          # all rois degenerate -> zero gradient

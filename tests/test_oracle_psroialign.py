@@ -57,3 +57,43 @@ def test_light_head_shape_and_sample_counts(oracle):
     assert i.min() >= 0 and i.max() < 25
     full = i[0, 0]          # full-image ROI: bin 30/7 = 4.29 -> 5x5 samples
     assert full.max() > 15
+
+
+@pytest.mark.parametrize('method', ['max', 'mean'])
+def test_grad_is_the_adjoint_of_the_forward(method, oracle):
+    """F2 pin (no reference vectors exist for the backward): PsRoiAlign is linear in `inputs` once the
+    argmax samples are fixed, so <grad_output, dX> == <G, fwd(X + dX) - fwd(X)> for any dX that does not
+    move an argmax ('mean': any dX).  Checked in float64-accumulated inner products."""
+    rng = np.random.default_rng(11)
+    n, c, h, w, r, g = 2, 36, 9, 11, 7, 3
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    rois = np.stack([rng.uniform(0.2, 0.8, (n, r)), rng.uniform(0.2, 0.8, (n, r)),
+                     rng.uniform(0.1, 0.9, (n, r)), rng.uniform(0.1, 0.9, (n, r))], -1).astype(np.float32)
+    rois[0, 0, 2:] = 0.          # degenerate roi: contributes nothing
+    p0, idx = oracle.ps_roi_align(x, rois, g, g, method)
+    G = rng.standard_normal(p0.shape).astype(np.float32)
+    gx = oracle.ps_roi_align_grad(x, rois, G, idx, g, g, method)
+    assert gx.shape == x.shape
+    dx = (rng.standard_normal(x.shape) * (1e-4 if method == 'max' else 1.)).astype(np.float32)
+    p1, idx1 = oracle.ps_roi_align(x + dx, rois, g, g, method)
+    same = (idx1 == idx)
+    assert same.mean() > 0.99
+    lhs = np.sum(gx.astype(np.float64) * dx.astype(np.float64))
+    rhs = np.sum((G.astype(np.float64) * (p1.astype(np.float64) - p0.astype(np.float64)))[same])
+    # the moved-argmax elements are excluded on the rhs; remove their lhs part too
+    if not same.all():
+        Gm = np.where(same, G, 0).astype(np.float32)
+        lhs = np.sum(oracle.ps_roi_align_grad(x, rois, Gm, idx, g, g, method).astype(np.float64) * dx)
+    assert abs(lhs - rhs) <= 2e-3 * max(abs(lhs), abs(rhs), 1e-3), (lhs, rhs)
+
+
+def test_grad_hand_check_single_sample(oracle):
+    """One roi covering one pixel-sized bin -> a single sample: its 4 bilinear weights sum to the grad."""
+    x = np.zeros((1, 1, 6, 6), np.float32)
+    rois = np.array([[[0.5, 0.5, 1. / 6, 1. / 6]]], np.float32)      # 1x1 px box around (3,3)
+    _, idx = oracle.ps_roi_align(x, rois, 1, 1, 'max')
+    gx = oracle.ps_roi_align_grad(x, rois, np.full((1, 1, 1, 1), 2., np.float32), idx, 1, 1, 'max')
+    assert np.isclose(gx.sum(), 2.)
+    assert np.count_nonzero(gx) <= 4
+    ys, xs = np.nonzero(gx[0, 0])
+    assert ys.min() >= 2 and ys.max() <= 3 and xs.min() >= 2 and xs.max() <= 3

@@ -42,8 +42,11 @@ struct ConvParams {
   const float* wt;   // [Cout_pad][Kp], K contiguous, k = tap*Cin_p + ci   (f32 path)
   const unsigned short* wt_hi;   // f16 planes of the (per-channel power-of-two scaled) matrix: split path
   const unsigned short* wt_lo;
-  const unsigned short* in_hi;   // A operand already split into f16 planes (conv_mfma_dma.hip), same NHWC/ldi
+  // A operand already split into f16 planes (conv_mfma_dma.hip), channel-blocked: [ldi/32][in_pix][32]
+  // (pixel = n*H*W + y*W + x), so the 32-channel slab of consecutive pixels is one contiguous run
+  const unsigned short* in_hi;
   const unsigned short* in_lo;
+  int64_t in_pix;                // N*H*W of the input tensor (plane stride in pixels)
   const unsigned short* zeros;   // >= 16 B of zeros: the source of out-of-image taps for the LDS DMA
   float* out;        // NHWC, channel stride ldo
   const float* scale;   // [Cout_pad] folded BN scale (1 for plain bias)
@@ -71,7 +74,8 @@ int launch_depthwise3x3(const float* in, const float* w9c, float* out, int N, in
 int launch_maxpool3x3s2_add(const float* in, const float* res, float* out, int N, int H, int W, int C, int ld,
                             int Ho, int Wo, int pad_t, int pad_l, hipStream_t s);
 int launch_relu_copy(const float* in, float* out, int64_t n, hipStream_t s);
-int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, int64_t n, int relu, hipStream_t s);
+int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, int64_t n_pix, int ld, int relu,
+                     hipStream_t s);
 int launch_depthwise3x3_split(const float* in, const float* w9c, unsigned short* hi, unsigned short* lo, int N,
                               int H, int W, int C, int ld, int dil, int relu_in, hipStream_t s);
 
@@ -82,6 +86,9 @@ int launch_preprocess_eval(const unsigned char* img, int H, int W, float* out_ch
 int launch_psroialign(const float* feat, const float* rois, float* pooled, int32_t* index, int N, int C, int H,
                       int W, int R, int gw, int gh, int use_max, int layout, int ldc, int out_ld,
                       int rois_are_corners, hipStream_t s);
+int launch_psroialign_grad(const float* rois, const float* grad_pooled, const int32_t* pooled_index, float* grad_out,
+                           int N, int C, int H, int W, int R, int gw, int gh, int use_max, int layout, int ldc,
+                           hipStream_t s);
 
 // ---- RPN tail / proposals (proposals.hip) ----------------------------------------------
 struct ProposalWorkspace {

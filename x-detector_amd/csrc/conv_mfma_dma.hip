@@ -8,6 +8,10 @@
 //   * LDS tiles are dense [row][32 halves] (the DMA destination is lane-linear), made
 //     conflict-free for the MFMA operand reads by permuting the 16-B chunks of a row with
 //     (row>>2)&3 on the SOURCE address and undoing it on the ds_read_b128 address;
+//   * both operands are K-blocked in HBM -- activations [C/32][pixels][32], weights
+//     [Kp/32][Cout_pad][32] -- so the 16 rows x 64 B one DMA instruction moves are one contiguous
+//     1 KB run (tools/ubench/dma_rate.hip: 63 GB/s per CU for 1 KB runs vs 30 GB/s for 64 B segments
+//     at a row stride when the stream misses L2);
 //   * two LDS stages (64 KB for a 128x128 tile -> two workgroups per CU), one barrier per
 //     32-deep K step: the DMA of step k+1 flies while step k is multiplied.
 //
@@ -83,25 +87,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
 #pragma unroll
   for (int q = 0; q < B_IT; ++q) {
     const int rt = (wave * B_IT + q) * 16 + lr;
-    boff[q] = (size_t)(n0 + rt) * p.Kp + (pos ^ ((rt >> 2) & 3)) * 8;
+    boff[q] = (size_t)(n0 + rt) * 32 + (pos ^ ((rt >> 2) & 3)) * 8;   // K-blocked weights [Kp/32][Cout_pad][32]
   }
   const int nk = p.Kp / 32;
+  const int ntaps = p.KH * p.KW;
 
   auto issue = [&](int kt, int buf) {
     u16* Ah = smem16 + buf * STAGE;
     u16* Al = Ah + BM * ROWB;
     u16* Bh = Al + BM * ROWB;
     u16* Bl = Bh + BN * ROWB;
-    const int k0 = kt * 32;
-    const int tap = k0 / p.Cin_p;                // block-uniform
+    // K order: channel chunk outer, filter tap inner.  The KH*KW shifted views of one 32-channel
+    // slab are consumed back to back, so a multi-tap conv (3x3, 15x1, 1x15) pulls each activation
+    // line over the fabric once and takes the other taps from L2; tap-outer order streamed the
+    // whole [rows x Cin] slab per tap and evicted it before the next tap came round (15x the HBM
+    // reads on the 2048-channel large-separable convs).
+    const int cc = kt / ntaps;                   // block-uniform
+    const int tap = kt - cc * ntaps;
     const int ky = tap / p.KW;
     const int dy = ky * p.dil, dx = (tap - ky * p.KW) * p.dil;
-    const int coff = k0 - tap * p.Cin_p;
+    const size_t k0 = (size_t)(tap * (p.Cin_p >> 5) + cc) * p.Cout_pad * 32;   // weight K-block
 #pragma unroll
     for (int q = 0; q < A_IT; ++q) {
       const int iy = iy0[q] + dy, ix = ix0[q] + dx;
       const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const size_t off = (size_t)(pbase[q] + iy * p.W + ix) * p.ldi + coff + achunk[q];
+      const size_t off = ((size_t)cc * p.in_pix + (size_t)(pbase[q] + iy * p.W + ix)) * 32 + achunk[q];
       const u16* sh = ok ? p.in_hi + off : p.zeros;
       XDET_GLDS16(sh, Ah + (wave * A_IT + q) * 16 * ROWB);
       if (NSPLIT > 1) {
@@ -283,6 +293,8 @@ int launch_conv_mfma_dma(const ConvParams& p, int n_tile, int nsplit, hipStream_
     if (p.Cout_pad % 256 == 0 && (b256 >= thr256 || full_rounds || (b256 >= 200 && nk >= 40))) tile = 2;
     else if (b128n >= 170) tile = 1;
     if (tile_env) tile = !strcmp(tile_env, "256x256") ? (p.Cout_pad % 256 == 0 ? 2 : 1) : !strcmp(tile_env, "256x128") ? 1 : 0;
+    static const char* w4_env = getenv("XDET_W4");
+    if (tile == 2 && w4_env && w4_env[0] == '1') return launch_d<256, 256, 2, 2, 3>(p, s);
     if (tile == 2) return launch_d<256, 256, 2, 4, 3>(p, s);
     static const char* st_env = getenv("XDET_STAGES");
     const bool s3 = st_env && st_env[0] == '3';

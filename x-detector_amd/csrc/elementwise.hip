@@ -38,6 +38,11 @@ constexpr int DW_SX = 4;
 
 typedef _Float16 f16x4e __attribute__((ext_vector_type(4)));
 
+// offset (in halves) of channel c of pixel `pix` in a channel-blocked plane [ld/32][n_pix][32]
+__device__ __forceinline__ int64_t blocked_off(int64_t pix, int c, int64_t n_pix) {
+  return ((int64_t)(c >> 5) * n_pix + pix) * 32 + (c & 31);
+}
+
 __device__ __forceinline__ void split_store(const float4 v, unsigned short* hi, unsigned short* lo, int64_t o) {
   const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y, h2 = (_Float16)v.z, h3 = (_Float16)v.w;
   f16x4e hv = {h0, h1, h2, h3};
@@ -53,6 +58,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const float* __restri
                                                            unsigned short* __restrict__ lo, int H, int W, int ld,
                                                            int relu_in, int nrows) {
   constexpr int NC = DW_SX + 2 * DIL;
+  const int64_t n_pix = (int64_t)nrows * W;
   const int c4n = ld >> 2;
   const int nstrip = (W + DW_SX - 1) / DW_SX;
   const int item = blockIdx.y * 256 + threadIdx.x;
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const float* __restri
     const int x = x0 + k;
     if (x >= W) break;
     const size_t o = ((size_t)row * W + x) * ld + c;
-    if (SPLIT) split_store(acc[k], hi, lo, (int64_t)o);
+    if (SPLIT) split_store(acc[k], hi, lo, blocked_off((int64_t)row * W + x, c, n_pix));
     else *reinterpret_cast<float4*>(out + o) = acc[k];
   }
 }
@@ -134,27 +140,33 @@ int launch_depthwise3x3(const float* in, const float* w9c, float* out, int N, in
 int launch_depthwise3x3_split(const float* in, const float* w9c, unsigned short* hi, unsigned short* lo, int N,
                               int H, int W, int C, int ld, int dil, int relu_in, hipStream_t s) {
   XDET_REQUIRE(hi && lo, "depthwise(split): NULL planes");
+  XDET_REQUIRE(ld % 32 == 0, "depthwise(split): channel stride must be a multiple of 32");
   return launch_dw(in, w9c, nullptr, hi, lo, N, H, W, C, ld, dil, relu_in, s);
 }
 
 // ---- split-precision planes: x = hi + lo, both f16 (the A operand format of conv_mfma_dma.hip) ----
+// in: NHWC f32 [n_pix][ld]; hi/lo: channel-blocked planes [ld/32][n_pix][32]
 __global__ void split_f32_kernel(const float4* __restrict__ in, unsigned short* __restrict__ hi,
-                                 unsigned short* __restrict__ lo, int64_t n4, int relu) {
+                                 unsigned short* __restrict__ lo, int64_t n_pix, int c4n, int relu) {
+  const int64_t n4 = n_pix * c4n;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 v = in[i];
     if (relu) {
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
-    split_store(v, hi, lo, i * 4);
+    const int64_t pix = i / c4n;
+    split_store(v, hi, lo, blocked_off(pix, (int)(i - pix * c4n) * 4, n_pix));
   }
 }
 
-int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, int64_t n, int relu, hipStream_t s) {
-  XDET_REQUIRE(n % 4 == 0, "split: length must be a multiple of 4");
-  if (n == 0) return XDET_OK;
+int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, int64_t n_pix, int ld, int relu,
+                     hipStream_t s) {
+  XDET_REQUIRE(ld > 0 && ld % 32 == 0, "split: channel stride must be a multiple of 32");
+  if (n_pix == 0) return XDET_OK;
+  const int64_t n = n_pix * ld;
   const int blocks = (int)std::min<int64_t>(cdiv(n / 4, 256), 256 * 32);
   hipLaunchKernelGGL(split_f32_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(in), hi, lo,
-                     n / 4, relu);
+                     n_pix, ld / 4, relu);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }

@@ -95,8 +95,13 @@ struct ConvLayer : LayerBase {
   int precision = PREC_F32;
   float *d_wt = nullptr, *d_scale = nullptr, *d_shift = nullptr;
   unsigned short *d_wt_hi = nullptr, *d_wt_lo = nullptr;
+  // the same f16 weights K-blocked as [Kp/32][Cout_pad][32] for the LDS-DMA kernel: one K-step of a
+  // tile's B operand is then one contiguous run
+  unsigned short *d_wt_hi_b = nullptr, *d_wt_lo_b = nullptr;
 
   ~ConvLayer() override {
+    if (d_wt_hi_b) (void)hipFree(d_wt_hi_b);
+    if (d_wt_lo_b) (void)hipFree(d_wt_lo_b);
     if (d_wt_hi) (void)hipFree(d_wt_hi);
     if (d_wt_lo) (void)hipFree(d_wt_lo);
     if (d_wt) (void)hipFree(d_wt);
@@ -154,6 +159,21 @@ struct ConvLayer : LayerBase {
         XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_wt_lo), lo.size() * 2));
         XDET_HIP(hipMemcpy(d_wt_lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
       }
+      if (!small_cin) {
+        std::vector<unsigned short> hb(hi.size()), lb(lo.size());
+        for (int co = 0; co < cout_pad; ++co)
+          for (int k = 0; k < kp; ++k) {
+            const size_t d = ((size_t)(k >> 5) * cout_pad + co) * 32 + (k & 31);
+            hb[d] = hi[(size_t)co * kp + k];
+            lb[d] = lo[(size_t)co * kp + k];
+          }
+        XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_wt_hi_b), hb.size() * 2));
+        XDET_HIP(hipMemcpy(d_wt_hi_b, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+        if (precision == PREC_F16X3) {
+          XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_wt_lo_b), lb.size() * 2));
+          XDET_HIP(hipMemcpy(d_wt_lo_b, lb.data(), lb.size() * 2, hipMemcpyHostToDevice));
+        }
+      }
     }
     XDET_TRY(upload(sc, &d_scale));
     XDET_TRY(upload(sh, &d_shift));
@@ -199,6 +219,8 @@ struct ConvLayer : LayerBase {
     if (precision == PREC_F32) return launch_conv_mfma_f32(p, small_cin, n_tile, s);
     if (in_hi) {   // A operand already split into f16 planes by its producer: LDS-DMA kernel
       XDET_REQUIRE(!small_cin && relu_in == 0, "conv(dma): needs >= 32 input channels and no ReLU-on-load");
+      p.wt_hi = d_wt_hi_b; p.wt_lo = d_wt_lo_b;   // K-blocked copies
+      p.in_pix = (int64_t)N * H * W;              // plane stride of the channel-blocked A planes
       return launch_conv_mfma_dma(p, n_tile, precision == PREC_F16X3 ? 3 : 1, s);
     }
     return launch_conv_mfma_split(p, small_cin, n_tile, precision == PREC_F16X3 ? 3 : 1, s);
@@ -323,7 +345,7 @@ struct Plan {
     XDET_TRY(new_planes(out));
     const Buf i = in, o = *out;
     ops.push_back({name, stage, 0.0, [=](int N, hipStream_t s) {
-                     return launch_split_f32(i.p, o.hi, o.lo, (int64_t)N * i.per_image(), relu, s);
+                     return launch_split_f32(i.p, o.hi, o.lo, (int64_t)N * i.H * i.W, i.ld, relu, s);
                    }});
     return XDET_OK;
   }
@@ -867,6 +889,13 @@ int xdet_psroialign_fwd(const float* feat, const float* rois, float* pooled, int
                            feat_layout == 0 ? C : ldc, out_ld, rois_are_corners, S(stream));
 }
 
+int xdet_psroialign_grad(const float* rois, const float* grad_pooled, const int32_t* pooled_index, float* grad_feat,
+                         int N, int C, int H, int W, int R, int grid_w, int grid_h, int use_max, int feat_layout,
+                         int ldc, void* stream) {
+  return launch_psroialign_grad(rois, grad_pooled, pooled_index, grad_feat, N, C, H, W, R, grid_w, grid_h, use_max,
+                                feat_layout, feat_layout == 0 ? C : ldc, S(stream));
+}
+
 int xdet_conv_create(void** layer, int kh, int kw, int cin, int cout, int stride, int dilation, int pad_mode,
                      int pad_t, int pad_l, const float* k, const float* scale, const float* shift, int relu_out) {
   XDET_REQUIRE(layer, "layer is NULL");
@@ -881,9 +910,9 @@ int xdet_conv_forward(void* layer, const float* in, int N, int H, int W, int ld_
   XDET_REQUIRE(b && b->kind == 1, "not a conv layer");
   return static_cast<ConvLayer*>(b)->forward(in, N, H, W, ld_in, out, ld_out, residual, relu_in, S(stream));
 }
-int xdet_split_f32(const float* in, uint16_t* hi, uint16_t* lo, int64_t n, int relu, void* stream) {
+int xdet_split_f32(const float* in, uint16_t* hi, uint16_t* lo, int64_t n_pix, int ld, int relu, void* stream) {
   XDET_REQUIRE(in && hi && lo, "split: NULL argument");
-  return launch_split_f32(in, hi, lo, n, relu, S(stream));
+  return launch_split_f32(in, hi, lo, n_pix, ld, relu, S(stream));
 }
 int xdet_conv_forward_planes(void* layer, const uint16_t* in_hi, const uint16_t* in_lo, int N, int H, int W,
                              int ld_in, float* out, int ld_out, const float* residual, void* stream) {

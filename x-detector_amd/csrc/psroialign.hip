@@ -127,3 +127,86 @@ int launch_psroialign(const float* feat, const float* rois, float* pooled, int32
 }
 
 }  // namespace xdet
+
+// ---------------------------------------------------------------------------------------
+// F2: PsRoiAlignGrad -- the reference's training backward
+// (cpp/PSROIPooling/ps_roi_align_grad_op.cu:36-171): zero-fill, then scatter grad * bilinear weight
+// with 4 float atomics per sample ('max': the argmax sample only; 'mean': every sample, grad/(n_h n_w)).
+// Same wavefront-per-ROI decomposition and literal geometry as the forward kernel above.
+// ---------------------------------------------------------------------------------------
+namespace xdet {
+
+__device__ __forceinline__ float* gout_at(float* __restrict__ g, int layout, int ldc, int H, int W, int64_t n, int c,
+                                          int y, int x) {
+  if (layout == 0) return g + ((n * ldc + c) * H + y) * W + x;
+  return g + ((n * H + y) * W + x) * ldc + c;
+}
+
+__global__ __launch_bounds__(256) void psroialign_grad_kernel(const float* __restrict__ rois,
+                                                              const float* __restrict__ grad_pooled,
+                                                              const int32_t* __restrict__ pooled_index,
+                                                              float* __restrict__ grad_out, int N, int C, int H, int W,
+                                                              int R, int gw, int gh, int use_max, int layout, int ldc) {
+  const int bank = C / (gw * gh);
+  const int lane = threadIdx.x & 63;
+  const int64_t nr = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (nr >= (int64_t)N * R) return;
+  const int64_t n = nr / R;
+  const float* roi = rois + nr * 4;
+  const float r0 = roi[0], r1 = roi[1], r2 = roi[2], r3 = roi[3];
+  if (r2 < FLT_MIN || r3 < FLT_MIN) return;
+  const float yc = r0 * (float)H, xc = r1 * (float)W;
+  const float rh = fmaxf(r2 * (float)H, 1.f), rw = fmaxf(r3 * (float)W, 1.f);
+  const float ymin = fmaxf(yc - rh / 2.f, 0.f), xmin = fmaxf(xc - rw / 2.f, 0.f);
+  const float ymax = fminf(yc + rh / 2.f, (float)H - FLT_MIN), xmax = fminf(xc + rw / 2.f, (float)W - FLT_MIN);
+  const float bin_w = (xmax - xmin) / (float)gw, bin_h = (ymax - ymin) / (float)gh;
+  const int n_w = (int)bin_w + 1, n_h = (int)bin_h + 1;
+  const float step_w = bin_w / (float)n_w, step_h = bin_h / (float)n_h;
+  const double half_w = (double)step_w / 2., half_h = (double)step_h / 2.;
+  for (int e = lane; e < C; e += 64) {
+    const int pos = e / bank, row = pos / gw, col = pos - row * gw;
+    const float x0 = xmin + bin_w * (float)col, y0 = ymin + bin_h * (float)row;
+    const int64_t w = nr * C + e;
+    const int pi = use_max ? pooled_index[w] : 0;
+    const int i_lo = use_max ? pi / n_w : 0, i_hi = use_max ? i_lo + 1 : n_h;
+    const int j_lo = use_max ? pi % n_w : 0, j_hi = use_max ? j_lo + 1 : n_w;
+    const float g = use_max ? grad_pooled[w] : grad_pooled[w] / (float)(n_w * n_h);
+    for (int i = i_lo; i < i_hi; ++i) {
+      const float y = (float)((double)(y0 + step_h * (float)i) + half_h);
+      const int iy = (int)y;
+      const float fy = y - (float)iy;
+      const int iy1 = min(iy + 1, H - 1);
+      for (int j = j_lo; j < j_hi; ++j) {
+        const float x = (float)((double)(x0 + step_w * (float)j) + half_w);
+        const int ix = (int)x;
+        const float fx = x - (float)ix;
+        const int ix1 = min(ix + 1, W - 1);
+        atomicAdd(gout_at(grad_out, layout, ldc, H, W, n, e, iy, ix), (float)((1. - fx) * (1. - fy) * g));
+        atomicAdd(gout_at(grad_out, layout, ldc, H, W, n, e, iy1, ix), (float)((1. - fx) * fy * g));
+        atomicAdd(gout_at(grad_out, layout, ldc, H, W, n, e, iy, ix1), (float)(fx * (1. - fy) * g));
+        atomicAdd(gout_at(grad_out, layout, ldc, H, W, n, e, iy1, ix1), (float)(fx * fy * g));
+      }
+    }
+  }
+}
+
+int launch_psroialign_grad(const float* rois, const float* grad_pooled, const int32_t* pooled_index, float* grad_out,
+                           int N, int C, int H, int W, int R, int gw, int gh, int use_max, int layout, int ldc,
+                           hipStream_t s) {
+  XDET_REQUIRE(gw > 0 && gh > 0, "Need Attr grid_dim_width/grid_dim_height > 0");
+  XDET_REQUIRE(N >= 0 && C > 0 && H > 0 && W > 0 && R >= 0, "inputs must be in 'NCHW' format.");
+  XDET_REQUIRE(C % (gw * gh) == 0, "channels must be divisible by grid_dim_width * grid_dim_height");
+  XDET_REQUIRE(layout == 0 || layout == 1, "feat_layout must be 0 (NCHW) or 1 (NHWC)");
+  XDET_REQUIRE(rois && grad_pooled && grad_out && (!use_max || pooled_index), "psroialign_grad: NULL argument");
+  const int cs = layout == 0 ? C : ldc;
+  XDET_REQUIRE(cs >= C, "channel stride must be >= C");
+  XDET_HIP(hipMemsetAsync(grad_out, 0, (size_t)N * cs * H * W * sizeof(float), s));
+  const int64_t n_waves = (int64_t)N * R;
+  if (n_waves == 0) return XDET_OK;
+  hipLaunchKernelGGL(psroialign_grad_kernel, dim3((unsigned)cdiv(n_waves, 4)), dim3(256), 0, s, rois, grad_pooled,
+                     pooled_index, grad_out, N, C, H, W, R, gw, gh, use_max, layout, cs);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
+}  // namespace xdet

@@ -2,6 +2,7 @@
 
 The names below mirror the interfaces of HiKapok/X-Detector's eval path:
   ps_roi_align            <- op_module.ps_roi_align          (light_head_rfcn_eval.py:143-155)
+  ps_roi_align_grad       <- op_module.ps_roi_align_grad     (cpp/PSROIPooling/test_op.py:93-104)
   XceptionBody, get_rpn, get_proposals, large_sep_kernel, get_head
                           <- net/xception_body.py:236,381,402,450,477
   AnchorCreator, ext_decode_rois

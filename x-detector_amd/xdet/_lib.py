@@ -69,10 +69,11 @@ SIGNATURES = {
     'xdet_event_record': (c_int, [c_void_p, c_void_p]),
     'xdet_event_elapsed_ms': (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_float)]),
     'xdet_psroialign_fwd': (c_int, [PF, PF, PF, PI] + [c_int] * 12 + [c_void_p]),
+    'xdet_psroialign_grad': (c_int, [PF, PF, PI, PF] + [c_int] * 10 + [c_void_p]),
     'xdet_conv_create': (c_int, [ctypes.POINTER(c_void_p)] + [c_int] * 9 + [PF, PF, PF, c_int]),
     'xdet_conv_forward': (c_int, [c_void_p, PF, c_int, c_int, c_int, c_int, PF, c_int, PF, c_int, c_void_p]),
     'xdet_conv_out_shape': (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
-    'xdet_split_f32': (c_int, [PF, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    'xdet_split_f32': (c_int, [PF, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'xdet_conv_forward_planes': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, PF, c_int, PF,
                                          c_void_p]),
     'xdet_layer_destroy': (c_int, [c_void_p]),

@@ -47,6 +47,41 @@ def ps_roi_align(inputs, rois, grid_dim_width, grid_dim_height, pool_method, str
     return to_host(d_pool.ptr, shape, np.float32, stream), to_host(d_idx.ptr, shape, np.int32, stream)
 
 
+def ps_roi_align_grad(inputs, rois, pooled_features_grad, pooled_index, grid_dim_width, grid_dim_height, pool_method,
+                      stream=None):
+    """op_module.ps_roi_align_grad (REGISTER_OP cpp/PSROIPooling/ps_roi_align_grad_op.cc:39-57; registered as
+    the gradient of PsRoiAlign in cpp/PSROIPooling/test_op.py:93-104).
+
+    inputs [N,C,H,W] (only its shape is used, as in the reference), rois [N,R,4],
+    pooled_features_grad / pooled_index [N,R,gh*gw,C/(gh*gw)] -> grad_output [N,C,H,W] f32."""
+    if not isinstance(pool_method, str) or ('mean' not in pool_method and 'max' not in pool_method):
+        raise InvalidArgumentError(-1, "Need Attr pool_method to be either 'mean' or 'max', got %r" % (pool_method,))
+    shape = tuple(inputs.shape)
+    rois = np.asarray(rois, np.float32)
+    if len(shape) != 4:
+        raise InvalidArgumentError(-1, "inputs must be in 'NCHW' format.")
+    if rois.ndim != 3 or rois.shape[2] != 4:
+        raise InvalidArgumentError(-1, "rois must be in 'batch_size x num_rois x 4' format.")
+    if shape[0] != rois.shape[0]:
+        raise InvalidArgumentError(-1, "'batch_size' in inputs and rois don't match.")
+    N, C, H, W = shape
+    R = rois.shape[1]
+    gs = grid_dim_width * grid_dim_height
+    if gs <= 0 or C % gs != 0:
+        raise InvalidArgumentError(-1, 'channels must be divisible by grid_dim_width * grid_dim_height')
+    grad = np.ascontiguousarray(pooled_features_grad, np.float32)
+    index = np.ascontiguousarray(pooled_index, np.int32)
+    if grad.size != N * R * C or index.size != N * R * C:
+        raise InvalidArgumentError(-1, 'pooled_features_grad / pooled_index must hold batch_size*num_rois*channels '
+                                       'elements')
+    d_roi, d_grad, d_idx = to_device(rois), to_device(grad), to_device(index)
+    d_out = DeviceBuffer(max(N * C * H * W * 4, 16))
+    check(lib().xdet_psroialign_grad(d_roi.ptr, d_grad.ptr, d_idx.ptr, d_out.ptr, N, C, H, W, R, grid_dim_width,
+                                     grid_dim_height, 1 if 'max' in pool_method else 0, 0, C,
+                                     stream.handle if stream else None))
+    return to_host(d_out.ptr, shape, np.float32, stream)
+
+
 PAD_VALID, PAD_SAME, PAD_EXPLICIT = 0, 1, 2
 
 
@@ -77,7 +112,7 @@ class Conv2D(object):
             n = N * H * W * x.ld
             hi, lo = DeviceBuffer(n * 2 + 512, zero=True), DeviceBuffer(n * 2 + 512, zero=True)
             st = stream.handle if stream else None
-            check(lib().xdet_split_f32(x.ptr, hi.ptr, lo.ptr, n, 1 if relu_in else 0, st))
+            check(lib().xdet_split_f32(x.ptr, hi.ptr, lo.ptr, N * H * W, x.ld, 1 if relu_in else 0, st))
             check(lib().xdet_conv_forward_planes(self.handle, hi.ptr, lo.ptr, N, H, W, x.ld, out.ptr, out.ld,
                                                  residual.ptr if residual is not None else None, st))
             synchronize(stream)
