@@ -99,9 +99,9 @@ int xdet_conv_create(void** layer, int kh, int kw, int cin, int cout, int stride
 int xdet_conv_forward(void* layer, const float* in, int N, int H, int W, int ld_in, float* out, int ld_out,
                       const float* residual, int relu_in, void* stream);
 int xdet_conv_out_shape(void* layer, int H, int W, int* Ho, int* Wo);
-/* Split-precision operand planes (modes 1/2): x = hi + lo, both f16, channel-blocked
- * [ld/32][n_pix][32] with n_pix = N*H*W (the 32-channel slab of consecutive pixels is contiguous:
- * what one K-step of a conv tile ingests).  xdet_split_f32 (x NHWC [n_pix][ld], ld % 32 == 0) writes them element-wise (optionally through a ReLU); xdet_conv_forward_planes runs a
+/* Split-precision operand planes (modes 1/2): x = hi + lo, both f16, blocked
+ * [ceil(n_pix/16)][ld/32][16][32] with n_pix = N*H*W (16 pixels x 32 channels = one contiguous 1 KB
+ * block: what one LDS-DMA instruction of a conv tile ingests); a plane holds ceil(n_pix/16)*16*ld halves.  xdet_split_f32 (x NHWC [n_pix][ld], ld % 32 == 0) writes them element-wise (optionally through a ReLU); xdet_conv_forward_planes runs a
  * layer whose A operand already lives as planes (LDS-DMA kernel, no register staging).  Inside a
  * net the depthwise kernels and split passes produce the planes; these two entry points expose the
  * same kernels for tests. */

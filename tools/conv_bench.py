@@ -50,7 +50,7 @@ def main():
         from xdet._lib import lib, check
         if a.planes:
             from xdet.runtime import DeviceBuffer
-            n = a.batch * H * W * x.ld
+            n = -(-a.batch * H * W // 16) * 16 * x.ld
             hi, lo = DeviceBuffer(n * 2 + 512, zero=True), DeviceBuffer(n * 2 + 512, zero=True)
             check(lib().xdet_split_f32(x.ptr, hi.ptr, lo.ptr, a.batch * H * W, x.ld, 0, st.handle))
             check(lib().xdet_conv_forward_planes(L.handle, hi.ptr, lo.ptr, a.batch, H, W, x.ld, y.ptr, y.ld, None, st.handle))

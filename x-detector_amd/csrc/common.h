@@ -42,11 +42,10 @@ struct ConvParams {
   const float* wt;   // [Cout_pad][Kp], K contiguous, k = tap*Cin_p + ci   (f32 path)
   const unsigned short* wt_hi;   // f16 planes of the (per-channel power-of-two scaled) matrix: split path
   const unsigned short* wt_lo;
-  // A operand already split into f16 planes (conv_mfma_dma.hip), channel-blocked: [ldi/32][in_pix][32]
-  // (pixel = n*H*W + y*W + x), so the 32-channel slab of consecutive pixels is one contiguous run
+  // A operand already split into f16 planes (conv_mfma_dma.hip), blocked [pixels/16][ldi/32][16][32]
+  // (pixel = n*H*W + y*W + x): 16 pixels x 32 channels are one contiguous 1 KB block
   const unsigned short* in_hi;
   const unsigned short* in_lo;
-  int64_t in_pix;                // N*H*W of the input tensor (plane stride in pixels)
   const unsigned short* zeros;   // >= 16 B of zeros: the source of out-of-image taps for the LDS DMA
   float* out;        // NHWC, channel stride ldo
   const float* scale;   // [Cout_pad] folded BN scale (1 for plain bias)

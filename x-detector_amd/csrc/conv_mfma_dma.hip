@@ -8,7 +8,7 @@
 //   * LDS tiles are dense [row][32 halves] (the DMA destination is lane-linear), made
 //     conflict-free for the MFMA operand reads by permuting the 16-B chunks of a row with
 //     (row>>2)&3 on the SOURCE address and undoing it on the ds_read_b128 address;
-//   * both operands are K-blocked in HBM -- activations [C/32][pixels][32], weights
+//   * both operands are K-blocked in HBM -- activations [pixels/16][C/32][16][32], weights
 //     [Kp/32][Cout_pad][32] -- so the 16 rows x 64 B one DMA instruction moves are one contiguous
 //     1 KB run (tools/ubench/dma_rate.hip: 63 GB/s per CU for 1 KB runs vs 30 GB/s for 64 B segments
 //     at a row stride when the stream misses L2);
@@ -20,6 +20,7 @@
 #include "common.h"
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace xdet {
 
@@ -33,7 +34,7 @@ typedef unsigned short u16;
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(ConvParams p) {
-  static_assert(NSTAGE == 2 || NSTAGE == 3, "2 or 3 LDS stages");
+  static_assert(NSTAGE == 2, "two LDS stages");
   constexpr int NW = WAVES_M * WAVES_N;          // waves per workgroup (4 or 8)
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
   }
   const int nk = p.Kp / 32;
   const int ntaps = p.KH * p.KW;
+  const unsigned c32n = (unsigned)(p.ldi >> 5);   // channel blocks per 16-pixel group of a split plane
 
   auto issue = [&](int kt, int buf) {
     u16* Ah = smem16 + buf * STAGE;
@@ -111,7 +113,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
     for (int q = 0; q < A_IT; ++q) {
       const int iy = iy0[q] + dy, ix = ix0[q] + dx;
       const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const size_t off = ((size_t)cc * p.in_pix + (size_t)(pbase[q] + iy * p.W + ix)) * 32 + achunk[q];
+      const unsigned pix = (unsigned)(pbase[q] + iy * p.W + ix);
+      const size_t off = ((size_t)((pix >> 4) * c32n + cc) << 9) + ((pix & 15) << 5) + achunk[q];
       const u16* sh = ok ? p.in_hi + off : p.zeros;
       XDET_GLDS16(sh, Ah + (wave * A_IT + q) * 16 * ROWB);
       if (NSPLIT > 1) {
@@ -151,63 +154,93 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
     bsw[j] = (rt >> 2) & 3;
   }
 
-  // DMA instructions one wave issues per stage: the counted wait below leaves exactly the newest
-  // stage in flight (LDS-DMA completions retire in order on vmcnt)
-  constexpr int PER_STAGE = (A_IT + B_IT) * (NSPLIT > 1 ? 2 : 1);
-  issue(0, 0);
-  if (NSTAGE == 3 && nk > 1) issue(1, 1);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt % NSTAGE;
-    if (NSTAGE == 2) {
-      __syncthreads();                           // DMA(kt) landed for every wave; the other stage is free
-      if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
-    } else {
-      // stage kt must have landed, stage kt+1 may still be in flight; raw barrier so that nothing
-      // drains the DMA queue; after it every wave has finished reading stage kt-1 == (kt+2)%3
-      if (kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F70 | (PER_STAGE & 15) | ((PER_STAGE >> 4) << 14));
-      else __builtin_amdgcn_s_waitcnt(0x0F70);
-      __builtin_amdgcn_s_barrier();
-      if (kt + 2 < nk) issue(kt + 2, (kt + 2) % NSTAGE);
-    }
+  // Main loop.  Fragments are double-buffered in registers and the single barrier of a K step sits
+  // BETWEEN its two 16-deep halves, so the matrix pipe never waits for LDS across the barrier:
+  //     ds_read  half 1 of stage kt        -> set B      (lands under the MFMAs below)
+  //     MFMA     half 0 of stage kt        (set A, read before the previous barrier)
+  //     barrier: every wave's DMA(kt+1) has landed AND every wave is done reading stage kt
+  //     DMA      stage kt+2 -> the buffer stage kt just vacated (a whole step to land)
+  //     ds_read  half 0 of stage kt+1      -> set A      (lands under the MFMAs below)
+  //     MFMA     half 1 of stage kt        (set B)
+  auto load_frags = [&](int buf, int ks, f16x8* ah, f16x8* al, f16x8* bh, f16x8* bl) {
     const u16* Ah = smem16 + buf * STAGE;
     const u16* Al = Ah + BM * ROWB;
     const u16* Bh = Al + BM * ROWB;
     const u16* Bl = Bh + BN * ROWB;
+    const int c = ks * 2 + fh;                   // logical 8-half chunk of the 32-deep step
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int c = ks * 2 + fh;                 // logical 8-half chunk of the 32-deep step
-      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+    for (int i = 0; i < TM; ++i) {
+      const int o = aoff[i] + ((c ^ asw[i]) << 3);
+      ah[i] = *reinterpret_cast<const f16x8*>(Ah + o);
+      if (NSPLIT > 1) al[i] = *reinterpret_cast<const f16x8*>(Al + o);
+    }
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int o = aoff[i] + ((c ^ asw[i]) << 3);
-        ah[i] = *reinterpret_cast<const f16x8*>(Ah + o);
-        if (NSPLIT > 1) al[i] = *reinterpret_cast<const f16x8*>(Al + o);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int o = boffs[j] + ((c ^ bsw[j]) << 3);
-        bh[j] = *reinterpret_cast<const f16x8*>(Bh + o);
-        if (NSPLIT > 1) bl[j] = *reinterpret_cast<const f16x8*>(Bl + o);
-      }
-      if (NSPLIT > 1) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-      }
+    for (int j = 0; j < TN; ++j) {
+      const int o = boffs[j] + ((c ^ bsw[j]) << 3);
+      bh[j] = *reinterpret_cast<const f16x8*>(Bh + o);
+      if (NSPLIT > 1) bl[j] = *reinterpret_cast<const f16x8*>(Bl + o);
+    }
+  };
+  auto mma = [&](const f16x8* ah, const f16x8* al, const f16x8* bh, const f16x8* bl) {
+    if (NSPLIT > 1) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
     }
-  }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+  };
+
+  f16x8 a0h[TM], a0l[TM], b0h[TN], b0l[TN];      // set A: half 0 of the current stage
+  f16x8 a1h[TM], a1l[TM], b1h[TN], b1l[TN];      // set B: half 1
+  issue(0, 0);
+  __syncthreads();                               // stage 0 landed
+  if (nk > 1) issue(1, 1);
+  load_frags(0, 0, a0h, a0l, b0h, b0l);
+  // one K step; STEADY = both the DMA two stages ahead and the next stage's fragments exist, so the
+  // whole second half is one basic block and its DMA pieces / fragment reads can be interleaved with
+  // the MFMAs (a piece costs ~60 cycles of issue among MFMAs, 100-185 in a burst of eight next to the
+  // fragment reads -- MI355X_MICROARCH.md)
+  auto step = [&](int kt, auto steady) {
+    constexpr bool STEADY = decltype(steady)::value;
+    const int buf = kt & 1;
+    load_frags(buf, 1, a1h, a1l, b1h, b1l);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0h, a0l, b0h, b0l);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                             // waits vmcnt(0)/lgkmcnt(0) first: DMA(kt+1) + set B landed
+    // fragment reads first: the compiler orders LDS reads against the DMA's LDS writes, so reads
+    // placed after issue() could not move up between the DMA pieces
+    if (STEADY || kt + 1 < nk) load_frags(buf ^ 1, 0, a0h, a0l, b0h, b0l);
+    if (STEADY || kt + 2 < nk) issue(kt + 2, buf);
+    if (!STEADY) __builtin_amdgcn_sched_barrier(0);
+    mma(a1h, a1l, b1h, b1l);
+    if (STEADY) {
+      constexpr int NPIECE = (A_IT + B_IT) * (NSPLIT > 1 ? 2 : 1);
+      constexpr int NMMA = TM * TN * (NSPLIT > 1 ? 3 : 1);
+      constexpr int NRD = (TM + TN) * (NSPLIT > 1 ? 2 : 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+#pragma unroll
+      for (int k = 0; k < NPIECE; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NMMA / NPIECE > 0 ? NMMA / NPIECE : 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) step(kt, std::true_type{});
+  for (; kt < nk; ++kt) step(kt, std::false_type{});
 
   // Epilogue.  The MFMA accumulator layout gives each lane one column and 16 scattered rows, i.e.
   // 4-byte global stores (and residual loads).  Bounce each 32-row slab of the wave tile through
@@ -226,6 +259,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
     sc4 = *reinterpret_cast<const float4*>(p.scale + co4);
     sh4 = *reinterpret_cast<const float4*>(p.shift + co4);
   }
+  constexpr int NQ = (32 * C4N) / 64;            // float4 rows a lane handles per 32-row slab
+  // residual rows of slab i are requested before slab i-1 is stored, so their HBM latency hides
+  // behind the LDS bounce instead of being paid once per slab (one workgroup per CU: nothing else
+  // would cover it)
+  float4 rr[NQ];
+  auto load_res = [&](int i) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int m = m0 + wm * WM + i * 32 + (q * 64 + lane) / C4N;
+      rr[q] = (col_ok && m < p.M) ? *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldr + co4)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (p.res) load_res(0);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -233,23 +280,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         ep[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP_LD + j * 32 + frow] = acc[i][j][r];
+    float4 v[NQ];
 #pragma unroll
-    for (int q = 0; q < (32 * C4N) / 64; ++q) {
-      const int row = (q * 64 + lane) / C4N;
-      const float4 a = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4 * 4);
-      const int m = m0 + wm * WM + i * 32 + row;
-      if (col_ok && m < p.M) {
-        float4 v = make_float4(fmaf(a.x, sc4.x, sh4.x), fmaf(a.y, sc4.y, sh4.y), fmaf(a.z, sc4.z, sh4.z),
-                               fmaf(a.w, sc4.w, sh4.w));
-        if (p.res) {
-          const float4 rr = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldr + co4);
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-        }
-        if (p.relu_out) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        }
-        *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + co4) = v;
+    for (int q = 0; q < NQ; ++q) {
+      const float4 a = *reinterpret_cast<const float4*>(ep + ((q * 64 + lane) / C4N) * EP_LD + c4 * 4);
+      v[q] = make_float4(fmaf(a.x, sc4.x, sh4.x), fmaf(a.y, sc4.y, sh4.y), fmaf(a.z, sc4.z, sh4.z),
+                         fmaf(a.w, sc4.w, sh4.w));
+      if (p.res) { v[q].x += rr[q].x; v[q].y += rr[q].y; v[q].z += rr[q].z; v[q].w += rr[q].w; }
+      if (p.relu_out) {
+        v[q].x = fmaxf(v[q].x, 0.f); v[q].y = fmaxf(v[q].y, 0.f); v[q].z = fmaxf(v[q].z, 0.f); v[q].w = fmaxf(v[q].w, 0.f);
       }
+    }
+    if (p.res && i + 1 < TM) load_res(i + 1);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int m = m0 + wm * WM + i * 32 + (q * 64 + lane) / C4N;
+      if (col_ok && m < p.M) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + co4) = v[q];
     }
   }
 }
@@ -293,13 +339,8 @@ int launch_conv_mfma_dma(const ConvParams& p, int n_tile, int nsplit, hipStream_
     if (p.Cout_pad % 256 == 0 && (b256 >= thr256 || full_rounds || (b256 >= 200 && nk >= 40))) tile = 2;
     else if (b128n >= 170) tile = 1;
     if (tile_env) tile = !strcmp(tile_env, "256x256") ? (p.Cout_pad % 256 == 0 ? 2 : 1) : !strcmp(tile_env, "256x128") ? 1 : 0;
-    static const char* w4_env = getenv("XDET_W4");
-    if (tile == 2 && w4_env && w4_env[0] == '1') return launch_d<256, 256, 2, 2, 3>(p, s);
     if (tile == 2) return launch_d<256, 256, 2, 4, 3>(p, s);
-    static const char* st_env = getenv("XDET_STAGES");
-    const bool s3 = st_env && st_env[0] == '3';
-    if (tile == 1) return s3 ? launch_d<256, 128, 4, 2, 3, 3>(p, s) : launch_d<256, 128, 4, 2, 3>(p, s);
-    if (s3) return launch_d<128, 128, 2, 2, 3, 3>(p, s);
+    if (tile == 1) return launch_d<256, 128, 4, 2, 3>(p, s);
   }
   if (n_tile == 128)
     return nsplit == 1 ? launch_d<128, 128, 2, 2, 1>(p, s) : launch_d<128, 128, 2, 2, 3>(p, s);

@@ -4,6 +4,7 @@
 //     tf.layers.separable_conv2d (net/xception_body.py:220-234,268,354,366)
 //   * max-pool 3x3/2 SAME + residual add (net/xception_body.py:281-286,302-307,321-326)
 #include "common.h"
+#include <cstdlib>
 
 namespace xdet {
 
@@ -38,9 +39,12 @@ constexpr int DW_SX = 4;
 
 typedef _Float16 f16x4e __attribute__((ext_vector_type(4)));
 
-// offset (in halves) of channel c of pixel `pix` in a channel-blocked plane [ld/32][n_pix][32]
-__device__ __forceinline__ int64_t blocked_off(int64_t pix, int c, int64_t n_pix) {
-  return ((int64_t)(c >> 5) * n_pix + pix) * 32 + (c & 31);
+// offset (in halves) of channel c of pixel `pix` in a split plane.  Layout: [pix/16][ld/32][16][32]:
+// 16 pixels x 32 channels form one contiguous 1 KB block (what one LDS-DMA instruction of the conv
+// kernel moves), and all channel blocks of a 16-pixel group are adjacent, so a producer that walks
+// pixels x all channels (depthwise, split) still writes one compact region like plain NHWC.
+__device__ __forceinline__ int64_t blocked_off(int64_t pix, int c, int c32n) {
+  return (((pix >> 4) * c32n + (c >> 5)) << 9) + ((pix & 15) << 5) + (c & 31);
 }
 
 __device__ __forceinline__ void split_store(const float4 v, unsigned short* hi, unsigned short* lo, int64_t o) {
@@ -52,66 +56,107 @@ __device__ __forceinline__ void split_store(const float4 v, unsigned short* hi, 
   *reinterpret_cast<uint2*>(lo + o) = *reinterpret_cast<uint2*>(&lv);
 }
 
+template <bool SPLIT>
+__device__ __forceinline__ void dw_store_strip(const float4* acc, float* __restrict__ out, unsigned short* __restrict__ hi,
+                                               unsigned short* __restrict__ lo, int64_t rowpix, int x0, int W, int ld,
+                                               int c) {
+  if (SPLIT) {
+    // lane pairs swap halves: the even lane ends up with all 8 channels of pixels 0 and 2, the odd lane
+    // with those of pixels 1 and 3 -> 16-B stores, 128-B runs per 8 lanes (instead of 8-B stores in 64-B runs)
+    uint2 h[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 v = acc[k];
+      const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y, h2 = (_Float16)v.z, h3 = (_Float16)v.w;
+      f16x4e hv = {h0, h1, h2, h3};
+      f16x4e lv = {(_Float16)(v.x - (float)h0), (_Float16)(v.y - (float)h1), (_Float16)(v.z - (float)h2),
+                   (_Float16)(v.w - (float)h3)};
+      h[k] = *reinterpret_cast<uint2*>(&hv);
+      l[k] = *reinterpret_cast<uint2*>(&lv);
+    }
+    const bool odd = threadIdx.x & 1;
+    const int cb = c & ~7, c32n = ld >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const uint2 sh = odd ? h[2 * t] : h[2 * t + 1], sl = odd ? l[2 * t] : l[2 * t + 1];
+      uint2 rh, rl;
+      rh.x = __shfl_xor(sh.x, 1); rh.y = __shfl_xor(sh.y, 1);
+      rl.x = __shfl_xor(sl.x, 1); rl.y = __shfl_xor(sl.y, 1);
+      const uint2 mh = odd ? h[2 * t + 1] : h[2 * t], ml = odd ? l[2 * t + 1] : l[2 * t];
+      const uint4 oh = odd ? make_uint4(rh.x, rh.y, mh.x, mh.y) : make_uint4(mh.x, mh.y, rh.x, rh.y);
+      const uint4 ol = odd ? make_uint4(rl.x, rl.y, ml.x, ml.y) : make_uint4(ml.x, ml.y, rl.x, rl.y);
+      const int x = x0 + 2 * t + (odd ? 1 : 0);
+      if (x < W) {
+        const int64_t o = blocked_off(rowpix + x, cb, c32n);
+        *reinterpret_cast<uint4*>(hi + o) = oh;
+        *reinterpret_cast<uint4*>(lo + o) = ol;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (x0 + k < W) *reinterpret_cast<float4*>(out + (size_t)(rowpix + x0 + k) * ld + c) = acc[k];
+  }
+}
+
 template <int DIL, bool SPLIT>
 __global__ __launch_bounds__(256) void depthwise3x3_kernel(const float* __restrict__ in, const float* __restrict__ w9c,
                                                            float* __restrict__ out, unsigned short* __restrict__ hi,
                                                            unsigned short* __restrict__ lo, int H, int W, int ld,
                                                            int relu_in, int nrows) {
+  static_assert(DW_SX == 4, "strip of 4");
   constexpr int NC = DW_SX + 2 * DIL;
-  const int64_t n_pix = (int64_t)nrows * W;
   const int c4n = ld >> 2;
   const int nstrip = (W + DW_SX - 1) / DW_SX;
   const int item = blockIdx.y * 256 + threadIdx.x;
   if (item >= nstrip * c4n) return;
   const int strip = item / c4n;
   const int c = (item - strip * c4n) * 4;
+  const int x0 = strip * DW_SX;
+  // One workgroup per output row (x 256 strip/channel items), 64 VGPRs = full occupancy: this stencil
+  // is latency-bound, and every variant that traded occupancy for reuse in registers (sliding window
+  // down the rows: 148-180 VGPRs) or walked several rows per workgroup measured 10-60 % slower.
   // XCD-aware row order: workgroups go round-robin to the 8 XCDs; give each XCD a contiguous band of
-  // rows so the two halo rows a row shares with its neighbours are re-read from that XCD's L2
+  // rows so the two halo rows a row shares with its neighbours are re-read from that XCD's L2.
   const int per_xcd = gridDim.x >> 3;
   const int row = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // n*H + y
   if (row >= nrows) return;
   const int y = row % H;
-  const int x0 = strip * DW_SX;
   const float* base = in + (size_t)(row - y) * W * ld + c;       // image origin + channel offset
-  float4 acc[DW_SX];
+  {
+    float4 acc[DW_SX];
 #pragma unroll
-  for (int k = 0; k < DW_SX; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < DW_SX; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int iy = y + (ky - 1) * DIL;
-    if ((unsigned)iy >= (unsigned)H) continue;
-    const float* rp = base + (size_t)iy * W * ld;
-    float4 col[NC];
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = y + (ky - 1) * DIL;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      const float* rp = base + (size_t)iy * W * ld;
+      float4 col[NC];
 #pragma unroll
-    for (int k = 0; k < NC; ++k) {
-      const int ix = x0 - DIL + k;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)ix < (unsigned)W) {
-        v = *reinterpret_cast<const float4*>(rp + (size_t)ix * ld);
-        if (relu_in) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      for (int k = 0; k < NC; ++k) {
+        const int ix = x0 - DIL + k;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)ix < (unsigned)W) {
+          v = *reinterpret_cast<const float4*>(rp + (size_t)ix * ld);
+          if (relu_in) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          }
+        }
+        col[k] = v;
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float4 w = *reinterpret_cast<const float4*>(w9c + (ky * 3 + kx) * ld + c);
+#pragma unroll
+        for (int k = 0; k < DW_SX; ++k) {
+          const float4 v = col[k + kx * DIL];
+          acc[k].x = fmaf(v.x, w.x, acc[k].x); acc[k].y = fmaf(v.y, w.y, acc[k].y);
+          acc[k].z = fmaf(v.z, w.z, acc[k].z); acc[k].w = fmaf(v.w, w.w, acc[k].w);
         }
       }
-      col[k] = v;
     }
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const float4 w = *reinterpret_cast<const float4*>(w9c + (ky * 3 + kx) * ld + c);
-#pragma unroll
-      for (int k = 0; k < DW_SX; ++k) {
-        const float4 v = col[k + kx * DIL];
-        acc[k].x = fmaf(v.x, w.x, acc[k].x); acc[k].y = fmaf(v.y, w.y, acc[k].y);
-        acc[k].z = fmaf(v.z, w.z, acc[k].z); acc[k].w = fmaf(v.w, w.w, acc[k].w);
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < DW_SX; ++k) {
-    const int x = x0 + k;
-    if (x >= W) break;
-    const size_t o = ((size_t)row * W + x) * ld + c;
-    if (SPLIT) split_store(acc[k], hi, lo, blocked_off((int64_t)row * W + x, c, n_pix));
-    else *reinterpret_cast<float4*>(out + o) = acc[k];
+    dw_store_strip<SPLIT>(acc, out, hi, lo, (int64_t)row * W, x0, W, ld, c);
   }
 }
 
@@ -145,17 +190,44 @@ int launch_depthwise3x3_split(const float* in, const float* w9c, unsigned short*
 }
 
 // ---- split-precision planes: x = hi + lo, both f16 (the A operand format of conv_mfma_dma.hip) ----
-// in: NHWC f32 [n_pix][ld]; hi/lo: channel-blocked planes [ld/32][n_pix][32]
-__global__ void split_f32_kernel(const float4* __restrict__ in, unsigned short* __restrict__ hi,
-                                 unsigned short* __restrict__ lo, int64_t n_pix, int c4n, int relu) {
-  const int64_t n4 = n_pix * c4n;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    float4 v = in[i];
+// in: NHWC f32 [n_pix][ld]; hi/lo: split planes [n_pix/16][ld/32][16][32] (blocked_off above).
+// One thread = 8 channels of one pixel (two float4 in, one 16-B store per plane); consecutive lanes
+// walk the OUTPUT order, so a wave writes one 1 KB block (16 pixels x 32 channels) and reads whole
+// 128-B lines (one pixel's 32-channel chunk per 4 lanes); consecutive waves take the next channel
+// block of the same 16 pixels.
+typedef _Float16 f16x8e __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const float4 a, const float4 b, f16x8e* h, f16x8e* l) {
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const _Float16 t = (_Float16)v[i];
+    (*h)[i] = t;
+    (*l)[i] = (_Float16)(v[i] - (float)t);
+  }
+}
+
+__global__ __launch_bounds__(256) void split_f32_kernel(const float* __restrict__ in, unsigned short* __restrict__ hi,
+                                                        unsigned short* __restrict__ lo, int64_t n_pix, int ld,
+                                                        int relu) {
+  const int c32n = ld >> 5;
+  const int64_t n8 = ((n_pix + 15) >> 4) * c32n * 64;   // 16-B output chunks per plane (64 per 1 KB block)
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t blk = i >> 6;                  // (pix/16) * c32n + cc
+    const int64_t grp = blk / c32n;
+    const int cc = (int)(blk - grp * c32n);
+    const int64_t pix = grp * 16 + ((i >> 2) & 15);
+    if (pix >= n_pix) continue;
+    const float* src = in + pix * ld + cc * 32 + (i & 3) * 8;
+    float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
     if (relu) {
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+      b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f);
     }
-    const int64_t pix = i / c4n;
-    split_store(v, hi, lo, blocked_off(pix, (int)(i - pix * c4n) * 4, n_pix));
+    f16x8e h, l;
+    split8(a, b, &h, &l);
+    *reinterpret_cast<f16x8e*>(hi + i * 8) = h;
+    *reinterpret_cast<f16x8e*>(lo + i * 8) = l;
   }
 }
 
@@ -163,10 +235,9 @@ int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, in
                      hipStream_t s) {
   XDET_REQUIRE(ld > 0 && ld % 32 == 0, "split: channel stride must be a multiple of 32");
   if (n_pix == 0) return XDET_OK;
-  const int64_t n = n_pix * ld;
-  const int blocks = (int)std::min<int64_t>(cdiv(n / 4, 256), 256 * 32);
-  hipLaunchKernelGGL(split_f32_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(in), hi, lo,
-                     n_pix, ld / 4, relu);
+  const int64_t n = cdiv(n_pix, 16) * 16 * ld;
+  const int blocks = (int)std::min<int64_t>(cdiv(n / 8, 256), 256 * 32);
+  hipLaunchKernelGGL(split_f32_kernel, dim3(blocks), dim3(256), 0, s, in, hi, lo, n_pix, ld, relu);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }

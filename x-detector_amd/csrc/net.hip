@@ -220,7 +220,6 @@ struct ConvLayer : LayerBase {
     if (in_hi) {   // A operand already split into f16 planes by its producer: LDS-DMA kernel
       XDET_REQUIRE(!small_cin && relu_in == 0, "conv(dma): needs >= 32 input channels and no ReLU-on-load");
       p.wt_hi = d_wt_hi_b; p.wt_lo = d_wt_lo_b;   // K-blocked copies
-      p.in_pix = (int64_t)N * H * W;              // plane stride of the channel-blocked A planes
       return launch_conv_mfma_dma(p, n_tile, precision == PREC_F16X3 ? 3 : 1, s);
     }
     return launch_conv_mfma_split(p, small_cin, n_tile, precision == PREC_F16X3 ? 3 : 1, s);
@@ -332,7 +331,8 @@ struct Plan {
     return XDET_OK;
   }
   int new_planes(Buf* b) {
-    const size_t bytes = ((size_t)max_batch * b->per_image() + 256) * sizeof(unsigned short);
+    // [pixels/16][ld/32][16][32]: the pixel count is rounded up to a whole 16-pixel group
+    const size_t bytes = ((size_t)cdiv((int64_t)max_batch * b->H * b->W, 16) * 16 * b->ld + 256) * sizeof(unsigned short);
     XDET_TRY(alloc_bytes(bytes, reinterpret_cast<void**>(&b->hi)));
     XDET_TRY(alloc_bytes(bytes, reinterpret_cast<void**>(&b->lo)));
     return get_zeros();

@@ -109,7 +109,7 @@ class Conv2D(object):
         check(lib().xdet_conv_out_shape(self.handle, H, W, ctypes.byref(ho), ctypes.byref(wo)))
         out = DeviceTensor.empty((N, ho.value, wo.value, self.cout))
         if planes:
-            n = N * H * W * x.ld
+            n = -(-N * H * W // 16) * 16 * x.ld
             hi, lo = DeviceBuffer(n * 2 + 512, zero=True), DeviceBuffer(n * 2 + 512, zero=True)
             st = stream.handle if stream else None
             check(lib().xdet_split_f32(x.ptr, hi.ptr, lo.ptr, N * H * W, x.ld, 1 if relu_in else 0, st))
