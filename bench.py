@@ -104,7 +104,9 @@ def traffic_from_profiles(precision):
     (profiles/<tag>_summary.json, written by tools/summarize_profile.py with the gfx950 x2 read
     correction); PMC collection cannot run inside the bench itself."""
     import glob
-    want = 'conv_mfma_f32' if precision == 'f32' else 'conv_dma_f16'
+    if precision != 'f16x3':      # the committed PMC passes are of the default configuration only
+        return None, None
+    want = 'conv_dma_f16'
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_summary.json')), reverse=True):
         try:
             d = json.load(open(path))
@@ -260,12 +262,15 @@ def main():
             ach = conv_flops / (conv_ms * 1e-3) / 1e12
             peak = PEAK_F32_MFMA_TFLOPS if args.precision == 'f32' else PEAK_F16_MFMA_TFLOPS
             kname = 'conv_mfma_f32_kernel' if args.precision == 'f32' else 'conv_dma_f16_kernel (+conv_mfma_f16_kernel for the 5 small/strided convs)'
+            default_cfg = args.workload == 'lighthead' and B == 64 and args.proposals == 300
+            traffic = traffic_from_profiles(args.precision) if default_cfg else (None, None)
             roof = {'bound': 'mfma', 'kernel': kname, 'achieved': round(ach, 2),
                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                     'mfma_issued_tflops': round(ach * (3 if args.precision == 'f16x3' else 1), 2),
                     'mfma_util': round(ach * (3 if args.precision == 'f16x3' else 1) / peak, 4),
-                    'traffic': traffic_from_profiles(args.precision)[0],
-                    'traffic_unit': 'HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE), from ' + str(traffic_from_profiles(args.precision)[1]),
+                    'traffic': traffic[0],
+                    'traffic_unit': ('HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE), from ' + str(traffic[1]))
+                    if traffic[0] else 'no PMC pass committed for this configuration',
                     'launches_per_step': conv_launches // K,
                     'avg_launch_us': round(conv_ms * 1e3 / max(conv_launches, 1), 2),
                     'kernel_ms_per_step': round(conv_ms / K, 3), 'gflop_per_image': round(flops_img / 1e9, 2),
