@@ -5,7 +5,9 @@
 
 One "step" = one pass of the whole hot path (backbone + RPN + proposals + PsRoiAlign + light
 head + per-class NMS) over one batch of B synthetic 480x480 images per GPU, inputs already
-resident in HBM.  N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N`
+resident in HBM.  The batch runs as --ways concurrent sub-batches (default 2 x 64), each a net
+instance replaying its hipGraph on its own stream, so the partial last round of workgroups of one
+launch is filled by the other stream's kernels.  N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N`
 (one rank per GPU); images are sharded by rank (independent units, weak scaling) and the only
 exchange is one all-gather of the fixed-size padded detections per step over RCCL
 (torch.distributed backend "nccl").  Rank 0 prints ONE JSON line.
@@ -40,7 +42,10 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=64, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=128, help='images per GPU per step')
+    ap.add_argument('--ways', type=int, default=2,
+                    help='the batch runs as this many concurrent sub-batches (net instances on their own HIP '
+                         'streams): the partial last round of one launch is filled by the other stream')
     ap.add_argument('--workload', default='lighthead', choices=['lighthead', 'resnet50'])
     ap.add_argument('--proposals', type=int, default=300, help='rpn_post_nms_top_n (BASELINE config 3: 300)')
     ap.add_argument('--precision', default='f16x3', choices=['f32', 'f16x3', 'f16'],
@@ -174,11 +179,19 @@ def main():
     if args.workload == 'lighthead':
         from xdet.model import LightHeadDetector
         weights = W.make_lighthead_weights(1234)
-        net = LightHeadDetector(weights, image_size=480, max_batch=B, rpn_post_nms_top_n=args.proposals)
+        ways = max(1, args.ways)
+        if B % ways:
+            raise SystemExit('--batch must be a multiple of --ways')
+        sb = B // ways                               # images per sub-batch / net instance
+        nets = [LightHeadDetector(weights, image_size=480, max_batch=sb, rpn_post_nms_top_n=args.proposals)
+                for _ in range(ways)]
+        net = nets[0]
         kind = 0
         fl = net.flops_per_image()
         flops_img = sum(fl.values())
-        net.set_images(W.synthetic_images(B, 480, seed=100 + rank))
+        imgs = W.synthetic_images(B, 480, seed=100 + rank)
+        for i, nt in enumerate(nets):
+            nt.set_images(imgs[i * sb:(i + 1) * sb])
         nc, topk = net.num_classes - 1, net.nms_topk
         gather = None
         if use_dist:
@@ -190,14 +203,19 @@ def main():
 
         use_graph = not args.eager
 
-        def step(graph=None):
+        def step(graph=None, only_first=False):
             g = use_graph if graph is None else graph
+            run = nets[:1] if only_first else nets
             if gather is None:
-                net.forward_device(B, use_graph=g)
+                for nt in run:
+                    nt.forward_device(sb, use_graph=g)
             else:
                 sc, bx, allb = gather
-                net.forward_device(B, use_graph=g, det_scores_ptr=sc.data_ptr(), det_boxes_ptr=bx.data_ptr())
-                net.stream.synchronize()
+                for i, nt in enumerate(run):
+                    nt.forward_device(sb, use_graph=g, det_scores_ptr=sc[i * sb:].data_ptr(),
+                                      det_boxes_ptr=bx[i * sb:].data_ptr())
+                for nt in run:
+                    nt.stream.synchronize()
                 xdist.gather_detections(xdist.pack_detections(sc, bx), world, allb)
     else:
         from xdet.resnet import ResNet50Trunk
@@ -209,12 +227,14 @@ def main():
         net.set_images(W.synthetic_images(B, 480, seed=100 + rank))
 
         use_graph = False
+        nets, sb, ways = [net], B, 1
 
-        def step(graph=None):
+        def step(graph=None, only_first=False):
             net.forward_device(B)
 
     def sync_all():
-        net.stream.synchronize()
+        for nt in nets:
+            nt.stream.synchronize()
         if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
@@ -239,11 +259,12 @@ def main():
     dt = time.perf_counter() - t0
     dev_ms = ev0.elapsed_ms(ev1)
     if not profile:
-        step(graph=False)
+        # roofline leg: one sub-batch alone, eager and instrumented (per-launch HIP event pairs)
+        step(graph=False, only_first=True)
         sync_all()
         check(lib().xdet_profile_enable(net.handle, kind, 1))
         for _ in range(K):
-            step(graph=False)
+            step(graph=False, only_first=True)
         sync_all()
     rows = read_profile(net.handle, kind)
     check(lib().xdet_profile_enable(net.handle, kind, 0))
@@ -256,13 +277,13 @@ def main():
         value = world * B * K / dt
         conv_ms = sum(r[1] for r in rows if r[3] > 0)
         conv_launches = sum(r[2] for r in rows if r[3] > 0)
-        conv_flops = sum(r[3] * r[2] for r in rows if r[3] > 0) * B     # flops are per image, launches cover B images
+        conv_flops = sum(r[3] * r[2] for r in rows if r[3] > 0) * sb    # flops are per image, a launch covers one sub-batch
         roof = None
         if conv_ms > 0:
             ach = conv_flops / (conv_ms * 1e-3) / 1e12
             peak = PEAK_F32_MFMA_TFLOPS if args.precision == 'f32' else PEAK_F16_MFMA_TFLOPS
             kname = 'conv_mfma_f32_kernel' if args.precision == 'f32' else 'conv_dma_f16_kernel (+conv_mfma_f16_kernel for the 5 small/strided convs)'
-            default_cfg = args.workload == 'lighthead' and B == 64 and args.proposals == 300
+            default_cfg = args.workload == 'lighthead' and sb == 64 and args.proposals == 300
             traffic = traffic_from_profiles(args.precision) if default_cfg else (None, None)
             roof = {'bound': 'mfma', 'kernel': kname, 'achieved': round(ach, 2),
                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
@@ -287,6 +308,7 @@ def main():
                                     'light head + per-class NMS), %d proposals, 480x480' % args.proposals)
                        if args.workload == 'lighthead' else 'ResNet-50 v2 trunk only (BASELINE config 2), 480x480',
                        'batch_per_gpu': B, 'global_batch': B * world, 'image_size': 480,
+                       'concurrent_sub_batches': ways,
                        'parallelism': 'image-sharded dp%d, all-gather of detections' % world,
                        'weights': 'seeded random init (no checkpoint exists)', 'graph_replay': bool(use_graph)},
             'device_ms_per_step': round(dev_ms / K, 3),
@@ -302,7 +324,7 @@ def main():
         if args.ops and rows:
             tot = sum(r[1] for r in rows)
             for name, ms, cnt, f in sorted(rows, key=lambda r: -r[1]):
-                tf = (f * B * cnt / (ms * 1e-3) / 1e12) if (ms > 0 and f > 0) else 0
+                tf = (f * sb * cnt / (ms * 1e-3) / 1e12) if (ms > 0 and f > 0) else 0
                 sys.stderr.write('%-52s %8.3f ms/step %5.1f%%  %7.1f TFLOP/s\n' % (name, ms / K, 100 * ms / tot, tf))
             sys.stderr.write('planned ops %.3f ms/step of %.3f ms/step\n' % (tot / K, ms_per_step))
         print(json.dumps(out))
