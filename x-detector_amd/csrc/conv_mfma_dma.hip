@@ -308,221 +308,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
   conv_epilogue<WM, WN, TM, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wm, wn, m0, n0);
 }
 
-// ---------------------------------------------------------------------------------------
-// 256x256 tile, f16x3, "ping-pong" schedule.  Same tile, LDS image, arithmetic (and bit-identical
-// results) as conv_dma_f16_kernel<256,256,2,4,3,2>; what differs is WHEN each wave does what:
-//
-//   The 8 waves form two groups (wm = 0 / 1: the upper / lower 128 rows of the tile; waves w and w+4
-//   share a SIMD, so every SIMD hosts one wave of each group).  A group alternates between a MEMORY
-//   phase -- read all 24 fragments of its K step from LDS, issue its 8 DMA pieces -- and an MFMA
-//   phase -- 48 back-to-back MFMAs from registers, no memory instruction at all -- and the two groups
-//   run half a step apart.  While one wave of a SIMD pays the issue cost of its LDS-DMA pieces
-//   (60-185 cycles each next to MFMAs, MI355X_MICROARCH.md) and the ds_read latency, the other keeps
-//   the matrix pipe saturated; in the lock-step schedule both waves of a SIMD hit their DMA pieces at
-//   the same moment and the pipe idled.
-//
-//   phase 2k   : group 0  reads stage k (A rows 0..127, all of B); issues B(k+1)
-//                group 1  MFMAs of step k-1
-//   phase 2k+1 : group 0  MFMAs of step k
-//                group 1  reads stage k (A rows 128..255, all of B); issues A0(k+2) and A1(k+1)
-//   one workgroup barrier between phases.  Every sub-buffer is refilled >= one barrier after its
-//   last reader finished and is waited for (vmcnt(0) at the end of the issuer's MFMA phase, then a
-//   barrier) >= one phase before its first reader -- the DMA gets about one full K step to land,
-//   as in the lock-step kernel, with the same two LDS stages.
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void conv_pp_f16_kernel(ConvParams p) {
-  constexpr int BM = 256, BN = 256, WM = 128, WN = 64, TM = 4, TN = 2, NW = 8;
-  constexpr int ROWB = 32;
-  constexpr int STAGE = (2 * BM + 2 * BN) * ROWB;
-
-  extern __shared__ __attribute__((aligned(16))) u16 smem16[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, wq = wave & 3;      // grp == wm, wq == wn
-  const int wm = grp, wn = wq;
-  const int nby = p.Cout_pad / BN;
-  const int slot = blockIdx.x >> 3;
-  const int bx = (slot / nby) * 8 + (blockIdx.x & 7);
-  if (bx * BM >= p.M) return;
-  const int m0 = bx * BM;
-  const int n0 = (slot % nby) * BN;
-
-  const int lr = lane >> 2, pos = lane & 3;
-  const int chunk = (pos ^ ((lr >> 2) & 3)) * 8;  // slabs start at multiples of 16 rows: (row>>2)&3 == (lr>>2)&3
-  // group 1: four 16-row A slabs per wave -- two of A0 (tile rows 0..127), two of A1 (rows 128..255)
-  int iy0[4], ix0[4], pbase[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int rt = (q >> 1) * 128 + (wq * 2 + (q & 1)) * 16 + lr;
-    const int m = m0 + rt;
-    iy0[q] = -(1 << 20); ix0[q] = 0; pbase[q] = 0;
-    if (grp == 1 && m < p.M) {
-      const int hw = p.Ho * p.Wo;
-      const int n = m / hw;
-      const int rem = m - n * hw;
-      const int oy = rem / p.Wo;
-      iy0[q] = oy * p.stride - p.pad_t;
-      ix0[q] = (rem - oy * p.Wo) * p.stride - p.pad_l;
-      pbase[q] = n * p.H * p.W;
-    }
-  }
-  // group 0: four 16-row B slabs per wave (K-blocked weights [Kp/32][Cout_pad][32])
-  const unsigned boff0 = (unsigned)(n0 + wq * 64 + lr) * 32 + chunk;
-  const int nk = p.Kp / 32;
-  const int ntaps = p.KH * p.KW;
-  const unsigned c32n = (unsigned)(p.ldi >> 5);
-
-  auto issue_B = [&](int kt, int buf) {
-    u16* Bh = smem16 + buf * STAGE + 2 * BM * ROWB;
-    u16* Bl = Bh + BN * ROWB;
-    const int cc = kt / ntaps;
-    const int tap = kt - cc * ntaps;
-    const size_t k0 = (size_t)(tap * (p.Cin_p >> 5) + cc) * p.Cout_pad * 32;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const size_t o = k0 + boff0 + q * 16 * 32;
-      XDET_GLDS16(p.wt_hi + o, Bh + (wq * 4 + q) * 16 * ROWB);
-      XDET_GLDS16(p.wt_lo + o, Bl + (wq * 4 + q) * 16 * ROWB);
-    }
-  };
-  auto issue_A = [&](int kt, int buf, int half) {
-    u16* Ah = smem16 + buf * STAGE;
-    u16* Al = Ah + BM * ROWB;
-    const int cc = kt / ntaps;
-    const int tap = kt - cc * ntaps;
-    const int ky = tap / p.KW;
-    const int dy = ky * p.dil, dx = (tap - ky * p.KW) * p.dil;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int q = half * 2 + j;
-      const int iy = iy0[q] + dy, ix = ix0[q] + dx;
-      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const unsigned pix = (unsigned)(pbase[q] + iy * p.W + ix);
-      const size_t off = ((size_t)((pix >> 4) * c32n + cc) << 9) + ((pix & 15) << 5) + chunk;
-      const int slab = half * 8 + wq * 2 + j;
-      XDET_GLDS16(ok ? p.in_hi + off : p.zeros, Ah + slab * 16 * ROWB);
-      XDET_GLDS16(ok ? p.in_lo + off : p.zeros, Al + slab * 16 * ROWB);
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int frow = lane & 31;
-  const int fh = lane >> 5;
-  const int fsw = (frow >> 2) & 3;               // tile rows of a fragment start at multiples of 32
-  const int arow0 = (wm * WM + frow) * ROWB, brow0 = (wn * WN + frow) * ROWB;
-
-  // s_waitcnt simm16 (gfx9): vmcnt = [3:0] | [15:14], expcnt = [6:4], lgkmcnt = [11:8]
-  auto phase_end_mem = [&]() {                   // my fragment reads are done; my DMA stays in flight
-    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0) only
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  };
-  auto phase_end_mfma = [&]() {                  // the DMA pieces I issued a phase ago have landed
-    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) only
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  };
-
-  // prologue: stage 0 entirely, plus A0 of stage 1 (the steady state issues A0 two steps ahead)
-  if (grp == 0) {
-    issue_B(0, 0);
-  } else {
-    issue_A(0, 0, 0);
-    issue_A(0, 0, 1);
-    if (nk > 1) issue_A(1, 1, 0);
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (grp == 1) {                                // group 1 runs one phase behind
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    const u16* Ah = smem16 + buf * STAGE;
-    const u16* Al = Ah + BM * ROWB;
-    const u16* Bh = Al + BM * ROWB;
-    const u16* Bl = Bh + BN * ROWB;
-    // ---- memory phase ----
-    f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int c = ((ks * 2 + fh) ^ fsw) << 3;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[ks][i] = *reinterpret_cast<const f16x8*>(Ah + arow0 + i * 32 * ROWB + c);
-        al[ks][i] = *reinterpret_cast<const f16x8*>(Al + arow0 + i * 32 * ROWB + c);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bh[ks][j] = *reinterpret_cast<const f16x8*>(Bh + brow0 + j * 32 * ROWB + c);
-        bl[ks][j] = *reinterpret_cast<const f16x8*>(Bl + brow0 + j * 32 * ROWB + c);
-      }
-    }
-    if (grp == 0) {
-      if (kt + 1 < nk) issue_B(kt + 1, buf ^ 1);
-    } else {
-      if (kt + 2 < nk) issue_A(kt + 2, buf, 0);
-      if (kt + 1 < nk) issue_A(kt + 1, buf ^ 1, 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    phase_end_mem();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- MFMA phase: registers only ----
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    phase_end_mfma();
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (grp == 0) {                                // pairs with group 1's extra barrier above
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
-  conv_epilogue<WM, WN, TM, TN, NW, 2 * STAGE * 2>(p, acc, smem16, wave, lane, wm, wn, m0, n0);
-}
-
-static int launch_pp(const ConvParams& p, hipStream_t s) {
-  constexpr size_t lds = (size_t)2 * (2 * 256 + 2 * 256) * 32 * sizeof(u16);
-  static bool attr_set = false;
-  if (!attr_set) {
-    XDET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pp_f16_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  dim3 grid((unsigned)(cdiv(cdiv(p.M, 256), 8) * 8 * (p.Cout_pad / 256)));
-  hipLaunchKernelGGL(conv_pp_f16_kernel, grid, dim3(512), lds, s, p);
-  XDET_LAUNCH_CHECK();
-  return XDET_OK;
-}
-
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE = 2>
 static int launch_d(const ConvParams& p, hipStream_t s) {
   constexpr size_t lds = (size_t)NSTAGE * (2 * BM + 2 * BN) * 32 * sizeof(u16);
@@ -562,8 +347,6 @@ int launch_conv_mfma_dma(const ConvParams& p, int n_tile, int nsplit, hipStream_
     if (p.Cout_pad % 256 == 0 && (b256 >= thr256 || full_rounds || (b256 >= 200 && nk >= 40))) tile = 2;
     else if (b128n >= 170) tile = 1;
     if (tile_env) tile = !strcmp(tile_env, "256x256") ? (p.Cout_pad % 256 == 0 ? 2 : 1) : !strcmp(tile_env, "256x128") ? 1 : 0;
-    static const char* pp_env = getenv("XDET_PP");
-    if (tile == 2 && pp_env && pp_env[0] == '1') return launch_pp(p, s);
     if (tile == 2) return launch_d<256, 256, 2, 4, 3>(p, s);
     if (tile == 1) return launch_d<256, 128, 4, 2, 3>(p, s);
   }
