@@ -103,12 +103,19 @@ template <int DIL, bool SPLIT>
 __global__ __launch_bounds__(256) void depthwise3x3_kernel(const float* __restrict__ in, const float* __restrict__ w9c,
                                                            float* __restrict__ out, unsigned short* __restrict__ hi,
                                                            unsigned short* __restrict__ lo, int H, int W, int ld,
-                                                           int relu_in, int nrows) {
+                                                           int relu_in, int nrows, int yblocks) {
   static_assert(DW_SX == 4, "strip of 4");
   constexpr int NC = DW_SX + 2 * DIL;
   const int c4n = ld >> 2;
   const int nstrip = (W + DW_SX - 1) / DW_SX;
-  const int item = blockIdx.y * 256 + threadIdx.x;
+  // 1-D grid, XCD-aware: workgroup b runs on XCD b & 7; inside an XCD consecutive workgroups walk the
+  // `yblocks` strip/channel slices of one row first and the rows of that XCD's band second, so the
+  // workgroups in flight together cover few rows x all slices and a row's neighbours (which re-read it)
+  // are scheduled right after it -- with slices outermost the set in flight spanned the whole band
+  // (~6 MB per XCD against a 4 MB L2) and rows were fetched 2.9x.
+  const int slot = blockIdx.x >> 3;
+  const int rl = slot / yblocks;
+  const int item = (slot - rl * yblocks) * 256 + threadIdx.x;
   if (item >= nstrip * c4n) return;
   const int strip = item / c4n;
   const int c = (item - strip * c4n) * 4;
@@ -116,11 +123,9 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const float* __restri
   // One workgroup per output row (x 256 strip/channel items), 64 VGPRs = full occupancy: this stencil
   // is latency-bound, and every variant that traded occupancy for reuse in registers (sliding window
   // down the rows: 148-180 VGPRs) or walked several rows per workgroup measured 10-60 % slower.
-  // XCD-aware row order: workgroups go round-robin to the 8 XCDs; give each XCD a contiguous band of
-  // rows so the two halo rows a row shares with its neighbours are re-read from that XCD's L2.
-  const int per_xcd = gridDim.x >> 3;
-  const int row = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // n*H + y
-  if (row >= nrows) return;
+  const int per_xcd = (nrows + 7) >> 3;
+  const int row = (blockIdx.x & 7) * per_xcd + rl;                // n*H + y
+  if (rl >= per_xcd || row >= nrows) return;
   const int y = row % H;
   const float* base = in + (size_t)(row - y) * W * ld + c;       // image origin + channel offset
   {
@@ -167,12 +172,13 @@ static int launch_dw(const float* in, const float* w9c, float* out, unsigned sho
   if ((int64_t)N * H == 0) return XDET_OK;
   const int items = ((W + DW_SX - 1) / DW_SX) * (ld / 4);
   const int nrows = N * H;
-  const dim3 grid((unsigned)(cdiv(nrows, 8) * 8), (unsigned)cdiv(items, 256));
+  const int yblocks = (int)cdiv(items, 256);
+  const dim3 grid((unsigned)(cdiv(nrows, 8) * 8 * yblocks));
   const bool split = hi != nullptr;
-  if (dil == 1 && !split) hipLaunchKernelGGL((depthwise3x3_kernel<1, false>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows);
-  else if (dil == 1) hipLaunchKernelGGL((depthwise3x3_kernel<1, true>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows);
-  else if (!split) hipLaunchKernelGGL((depthwise3x3_kernel<2, false>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows);
-  else hipLaunchKernelGGL((depthwise3x3_kernel<2, true>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows);
+  if (dil == 1 && !split) hipLaunchKernelGGL((depthwise3x3_kernel<1, false>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows, yblocks);
+  else if (dil == 1) hipLaunchKernelGGL((depthwise3x3_kernel<1, true>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows, yblocks);
+  else if (!split) hipLaunchKernelGGL((depthwise3x3_kernel<2, false>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows, yblocks);
+  else hipLaunchKernelGGL((depthwise3x3_kernel<2, true>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows, yblocks);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }
