@@ -1,0 +1,111 @@
+"""BASELINE's full bench size (64 images per net instance, 300 proposals, f16x3, hipGraph replay) checked
+through size-independent properties: the oracle needs ~1.5 s per image, so only sampled images are compared
+with it directly; everything else is asserted through invariants of the path."""
+import numpy as np
+import pytest
+
+from test_gpu_e2e import match_detections
+
+pytestmark = pytest.mark.gpu
+
+B = 64
+PROBE = 37           # position of the probe image inside the big batch
+
+
+@pytest.fixture(scope='module')
+def big(lh_weights):
+    from xdet import weights as W
+    from xdet.model import LightHeadDetector
+    from xdet.runtime import set_precision
+    imgs = W.synthetic_images(B, 480, seed=4242)
+    set_precision('f16x3')
+    try:
+        det = LightHeadDetector(lh_weights, image_size=480, max_batch=B, rpn_post_nms_top_n=300)
+        one = LightHeadDetector(lh_weights, image_size=480, max_batch=1, rpn_post_nms_top_n=300)
+    finally:
+        set_precision('f32')
+    det.set_images(imgs)
+    det.forward_device(B, use_graph=True)
+    s, b = det.detections(B)
+    return det, one, imgs, s.copy(), b.copy()
+
+
+def iou_matrix(bx):
+    """bx [k,4] (ymin,xmin,ymax,xmax)"""
+    y0 = np.maximum(bx[:, None, 0], bx[None, :, 0]); x0 = np.maximum(bx[:, None, 1], bx[None, :, 1])
+    y1 = np.minimum(bx[:, None, 2], bx[None, :, 2]); x1 = np.minimum(bx[:, None, 3], bx[None, :, 3])
+    inter = np.clip(y1 - y0, 0, None) * np.clip(x1 - x0, 0, None)
+    area = (bx[:, 2] - bx[:, 0]) * (bx[:, 3] - bx[:, 1])
+    return inter / np.maximum(area[:, None] + area[None, :] - inter, 1e-12)
+
+
+def test_output_invariants(big):
+    """bboxes_eval contract (light_head_rfcn_eval.py:263-287) on every one of the 64 x 20 class lists:
+    scores above select_threshold, sorted, zero padded; boxes clipped to the image; survivors of the
+    per-class NMS pairwise below the IoU threshold (NMS is idempotent on its own output)."""
+    _, _, _, s, b = big
+    assert s.shape == (B, 20, 200) and b.shape == (B, 20, 200, 4)
+    assert np.isfinite(s).all() and np.isfinite(b).all()
+    k = (s > 0).sum(-1)
+    assert k.sum() > 5000
+    worst = 0.0
+    for i in range(B):
+        for c in range(20):
+            n = int(k[i, c])
+            assert np.all(s[i, c, n:] == 0) and np.all(b[i, c, n:] == 0)
+            if n == 0:
+                continue
+            sc, bx = s[i, c, :n], b[i, c, :n]
+            assert np.all(sc > 0.01) and np.all(sc <= 1.0)
+            assert np.all(np.diff(sc) <= 0)
+            assert bx.min() >= 0.0 and bx.max() <= 1.0
+            assert np.all(bx[:, 2] >= bx[:, 0]) and np.all(bx[:, 3] >= bx[:, 1])
+            if n > 1:
+                m = iou_matrix(bx.astype(np.float64))
+                np.fill_diagonal(m, 0)
+                worst = max(worst, float(m.max()))
+    assert worst <= 0.3 + 1e-6, worst
+
+
+def test_replay_and_eager_agree_at_full_size(big):
+    det, _, _, s, b = big
+    det.forward_device(B, use_graph=True)
+    s2, b2 = det.detections(B)
+    det.forward_device(B, use_graph=False)
+    s3, b3 = det.detections(B)
+    assert np.array_equal(s, s2) and np.array_equal(b, b2)
+    assert np.array_equal(s, s3) and np.array_equal(b, b3)
+
+
+def test_batch_invariance(big):
+    """Images are independent units (what the multi-GPU sharding relies on): an image's detections do not
+    depend on its batch, its position in the batch, or the tile shapes the batch size selects (256x256
+    tiles at 64 images, 128x128 at 1) -- bit for bit."""
+    det, one, imgs, s, b = big
+    for pos in (0, PROBE, B - 1):
+        got = one.forward(imgs[pos:pos + 1])
+        for c in range(20):
+            gs, gb = got[0][c + 1]
+            assert np.array_equal(gs, s[pos, c]), (pos, c)
+            assert np.array_equal(gb, b[pos, c]), (pos, c)
+    # moving an image inside the batch moves its result with it
+    perm = np.roll(np.arange(B), 5)
+    det.set_images(imgs[perm])
+    det.forward_device(B, use_graph=True)
+    s2, b2 = det.detections(B)
+    assert np.array_equal(s2, s[perm]) and np.array_equal(b2, b[perm])
+    det.set_images(imgs)
+
+
+def test_sampled_images_against_the_oracle(big, oracle, lh_weights):
+    """two images of the full-size batch through the CPU oracle: every detection within 1e-3"""
+    _, _, imgs, s, b = big
+    total = matched = extra = 0
+    for pos in (PROBE, 3):
+        ref = oracle.lighthead_forward(imgs[pos:pos + 1], lh_weights, rpn_post_nms_top_n=300)
+        got = {c + 1: (s[pos, c], b[pos, c]) for c in range(20)}
+        t, m, e = match_detections(got, ref[0])
+        total, matched, extra = total + t, matched + m, extra + e
+    print('full-size batch, 2 sampled images: oracle %d matched %d extra %d' % (total, matched, extra))
+    assert total > 100
+    assert matched == total and extra == 0, (matched, total, extra)
