@@ -48,6 +48,11 @@ struct ConvParams {
   const unsigned short* in_lo;
   const unsigned short* zeros;   // >= 16 B of zeros: the source of out-of-image taps for the LDS DMA
   float* out;        // NHWC, channel stride ldo
+  // optional second copy of the output as split planes [pix/16][ldo/32][16][32] for a consumer on the
+  // LDS-DMA path (saves its split pass); planes_relu: the planes hold max(out, 0) (a `relu -> conv` edge)
+  unsigned short* out_hi;
+  unsigned short* out_lo;
+  int planes_relu;
   const float* scale;   // [Cout_pad] folded BN scale (1 for plain bias)
   const float* shift;   // [Cout_pad] folded BN shift / bias
   const float* res;     // optional residual, same N,Ho,Wo, channel stride ldr

@@ -26,6 +26,7 @@ namespace xdet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 
 #define XDET_GLDS16(gptr, lptr)                                                                        \
@@ -90,7 +91,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int m = m0 + wm * WM + i * 32 + (q * 64 + lane) / C4N;
-      if (col_ok && m < p.M) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + co4) = v[q];
+      if (col_ok && m < p.M) {
+        *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + co4) = v[q];
+        if (p.out_hi) {   // second copy as split planes for a consumer on the LDS-DMA path
+          float4 t = v[q];
+          if (p.planes_relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+          const _Float16 h0 = (_Float16)t.x, h1 = (_Float16)t.y, h2 = (_Float16)t.z, h3 = (_Float16)t.w;
+          f16x4 hv = {h0, h1, h2, h3};
+          f16x4 lv = {(_Float16)(t.x - (float)h0), (_Float16)(t.y - (float)h1), (_Float16)(t.z - (float)h2),
+                      (_Float16)(t.w - (float)h3)};
+          const size_t o = ((((size_t)m >> 4) * (size_t)(p.ldo >> 5) + (size_t)(co4 >> 5)) << 9) + ((m & 15) << 5) + (co4 & 31);
+          *reinterpret_cast<uint2*>(p.out_hi + o) = *reinterpret_cast<uint2*>(&hv);
+          *reinterpret_cast<uint2*>(p.out_lo + o) = *reinterpret_cast<uint2*>(&lv);
+        }
+      }
     }
   }
 }

@@ -230,6 +230,13 @@ __global__ __launch_bounds__(256) void conv_mfma_f16_kernel(ConvParams p) {
           if (p.res) v += p.res[(size_t)m * p.ldr + co];
           if (p.relu_out) v = fmaxf(v, 0.f);
           p.out[(size_t)m * p.ldo + co] = v;
+          if (p.out_hi) {
+            const float t = p.planes_relu ? fmaxf(v, 0.f) : v;
+            const _Float16 h = (_Float16)t, l = (_Float16)(t - (float)h);
+            const size_t o = ((((size_t)m >> 4) * (size_t)(p.ldo >> 5) + (size_t)(co >> 5)) << 9) + ((m & 15) << 5) + (co & 31);
+            p.out_hi[o] = *reinterpret_cast<const u16*>(&h);
+            p.out_lo[o] = *reinterpret_cast<const u16*>(&l);
+          }
         }
       }
     }

@@ -203,7 +203,8 @@ struct ConvLayer : LayerBase {
 
   int forward(const float* in, int N, int H, int W, int ldi, float* out, int ldo, const float* res, int relu_in,
               hipStream_t s, const unsigned short* in_hi = nullptr, const unsigned short* in_lo = nullptr,
-              const unsigned short* zeros = nullptr) const {
+              const unsigned short* zeros = nullptr, unsigned short* out_hi = nullptr,
+              unsigned short* out_lo = nullptr, int planes_relu = 0) const {
     XDET_REQUIRE(ldi == ld_in(), "conv: ld_in must be round_up(cin,32) (4 for cin<=4)");
     XDET_REQUIRE(ldo == ld_out(), "conv: ld_out must be round_up(cout,32)");
     ConvParams p;
@@ -216,6 +217,7 @@ struct ConvLayer : LayerBase {
     p.M = N * p.Ho * p.Wo;
     p.relu_in = relu_in; p.relu_out = relu_out;
     p.in_hi = in_hi; p.in_lo = in_lo; p.zeros = zeros;
+    p.out_hi = precision == PREC_F32 ? nullptr : out_hi; p.out_lo = out_lo; p.planes_relu = planes_relu;
     if (precision == PREC_F32) return launch_conv_mfma_f32(p, small_cin, n_tile, s);
     if (in_hi) {   // A operand already split into f16 planes by its producer: LDS-DMA kernel
       XDET_REQUIRE(!small_cin && relu_in == 0, "conv(dma): needs >= 32 input channels and no ReLU-on-load");
@@ -253,6 +255,7 @@ struct DepthwiseLayer : LayerBase {
 struct Buf {
   float* p = nullptr;
   unsigned short *hi = nullptr, *lo = nullptr;   // optional split-precision f16 planes of the same tensor
+  bool planes_relu = false;                      // the planes hold relu(tensor)
   int H = 0, W = 0, C = 0, ld = 0;
   size_t per_image() const { return (size_t)H * W * ld; }
 };
@@ -351,12 +354,21 @@ struct Plan {
   }
 
   // ---- op builders ----
+  // Set by a builder right before add_conv / conv_bn when it knows the output feeds a conv on the
+  // LDS-DMA path: 1 = the conv also writes its output as split planes (the consumer then needs no
+  // split pass), 2 = the planes hold relu(output) (for a consumer that applies ReLU on load).
+  int emit_planes_next = 0;
   int add_conv(const std::string& name, int stage, const Buf& in_, ConvLayer* L, const Buf* res, int relu_in, Buf* out) {
     Buf in = in_;
+    const int emit = L->precision == PREC_F32 ? 0 : emit_planes_next;
+    emit_planes_next = 0;
     // split path: big stride-1 contractions take their A operand as f16 planes through the LDS DMA;
     // if the producer did not emit planes, one cheap element-wise pass makes them (ReLU folded in)
     if (L->dma_capable() && L->stride == 1) {
-      if (!in.hi || relu_in) {
+      if (in.hi && in.planes_relu && !relu_in) in.hi = in.lo = nullptr;   // relu(x) planes are no use here
+      if (in.hi && relu_in && in.planes_relu) {
+        relu_in = 0;                               // the producer already wrote relu(x) planes
+      } else if (!in.hi || relu_in) {
         Buf sp;
         XDET_TRY(add_split(name + "/split_in", stage, in_, relu_in, &sp));
         in = sp;
@@ -369,12 +381,17 @@ struct Plan {
     L->out_shape(in.H, in.W, &Ho, &Wo, &a, &b);
     XDET_TRY(new_buf(Ho, Wo, L->cout, out));
     XDET_REQUIRE(in.ld == L->ld_in() && out->ld == L->ld_out(), "plan: conv channel strides do not match");
+    if (emit) {
+      XDET_TRY(new_planes(out));
+      out->planes_relu = emit == 2;
+    }
     const Buf i = in, o = *out;
     const float* rp = res ? res->p : nullptr;
     const unsigned short* z = zeros;
     if (res) XDET_REQUIRE(res->H == Ho && res->W == Wo && res->ld == o.ld, "plan: residual shape mismatch");
     ops.push_back({name, stage, L->flops(in.H, in.W), [=](int N, hipStream_t s) {
-                     return L->forward(i.p, N, i.H, i.W, i.ld, o.p, o.ld, rp, relu_in, s, i.hi, i.lo, z);
+                     return L->forward(i.p, N, i.H, i.W, i.ld, o.p, o.ld, rp, relu_in, s, i.hi, i.lo, z, o.hi, o.lo,
+                                       o.planes_relu ? 1 : 0);
                    }});
     return XDET_OK;
   }
@@ -511,6 +528,7 @@ struct LightHeadNet : Plan {
     in4.H = S; in4.W = S; in4.C = 3;
     XDET_TRY(new_buf(S, S, 3, &in4));
     Buf x, r, t;
+    emit_planes_next = 1;   // feeds block1_conv2 (LDS-DMA path) only
     XDET_TRY(conv_bn("block1_conv1", "block1_conv1_bn", eps, ST_BODY, in4, 3, 32, 2, 0, 1, nullptr, 0, &x));
     XDET_TRY(conv_bn("block1_conv2", "block1_conv2_bn", eps, ST_BODY, x, 3, 64, 1, 0, 1, nullptr, 0, &t));
     x = t;
@@ -532,6 +550,7 @@ struct LightHeadNet : Plan {
       const std::string pre = "block" + std::to_string(blk);
       XDET_TRY(sep_bn(pre + "_sepconv1", eps, ST_BODY, x, 728, 1, 1, 0, nullptr, &a));
       XDET_TRY(sep_bn(pre + "_sepconv2", eps, ST_BODY, a, 728, 1, 1, 0, nullptr, &b2));
+      if (blk == 12) emit_planes_next = 2;   // mid_outputs = ReLU(this) feeds the RPN 3x3 conv
       XDET_TRY(sep_bn(pre + "_sepconv3", eps, ST_BODY, b2, 728, 1, 1, 0, &res, &c3));
       x = c3;
     }
@@ -541,6 +560,7 @@ struct LightHeadNet : Plan {
     XDET_TRY(sep_bn("block13_sepconv1", eps, ST_BODY, x, 728, 1, 1, 0, nullptr, &a));
     XDET_TRY(sep_bn("block13_sepconv2", eps, ST_BODY, a, 1024, 1, 1, 0, &r, &b2));
     XDET_TRY(sep_bn("block14_sepconv1", eps, ST_BODY, b2, 1536, 0, 2, 1, nullptr, &c3));   // :354-364
+    emit_planes_next = 1;   // feeds the large-separable (15,1) conv
     XDET_TRY(sep_bn("block14_sepconv2", eps, ST_BODY, c3, 2048, 0, 2, 1, nullptr, &d4));   // :366-376
     out = d4;
     fmap = out.H;
@@ -559,6 +579,7 @@ struct LightHeadNet : Plan {
     ConvLayer* L0 = keep(new ConvLayer());
     XDET_TRY(L0->init(3, 3, 728, 512, 1, 1, 1, 0, 0, k0->v.data(), nullptr, b0->v.data(), 1));
     Buf hid;
+    emit_planes_next = 1;
     XDET_TRY(add_conv("rpn_head/conv2d", ST_RPN, mid_x, L0, nullptr, /*relu_in=*/1, &hid));
     // cls (2A) and box (4A) 1x1 heads share their input: one GEMM over the concatenated filters
     const int co = 6 * A;
@@ -596,6 +617,7 @@ struct LightHeadNet : Plan {
     ConvLayer* LA = keep(new ConvLayer());
     XDET_TRY(LA->init(15, 1, 2048, 2 * mid, 1, 1, 1, 0, 0, ka.data(), nullptr, ba.data(), 0));
     Buf t;
+    emit_planes_next = 1;
     XDET_TRY(add_conv("large_sep_feature/Branch_0+1/conv2d", ST_LSEP, out, LA, nullptr, 0, &t));
     // branch_0b + branch_1b = one (1,15) conv over the 2*mid stacked channels; then BN(1e-5)+ReLU
     std::vector<float> kb((size_t)15 * 2 * mid * co);
@@ -626,6 +648,7 @@ struct LightHeadNet : Plan {
     XDET_TRY(new_buf(R, 1, C, &pooled));
     ConvLayer* L0 = keep(new ConvLayer());
     XDET_TRY(L0->init(1, 1, C, 2048, 1, 1, 0, 0, 0, k0->v.data(), nullptr, b0->v.data(), 1));
+    emit_planes_next = 1;
     XDET_TRY(add_conv("final_head/subnet_fc", ST_HEAD, pooled, L0, nullptr, 0, &fc));
     const int co = nc + 4;
     std::vector<float> kc((size_t)2048 * co), bc(co);
@@ -775,8 +798,12 @@ struct ResNetTrunk : Plan {
   int build();
 };
 
+// also writes the result as split planes [pix/16][ld/32][16][32] when hi != NULL (its consumers are 1x1
+// convs on the LDS-DMA path)
 __global__ void bn_relu_kernel(const float* __restrict__ in, const float* __restrict__ scale,
-                               const float* __restrict__ shift, float* __restrict__ out, int64_t npix, int ld) {
+                               const float* __restrict__ shift, float* __restrict__ out,
+                               unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, int64_t npix, int ld) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
   const int c4n = ld >> 2;
   const int64_t total = npix * c4n;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -786,6 +813,16 @@ __global__ void bn_relu_kernel(const float* __restrict__ in, const float* __rest
     v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
     v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
     reinterpret_cast<float4*>(out)[i] = v;
+    if (hi) {
+      const int64_t pix = i / c4n;
+      const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y, h2 = (_Float16)v.z, h3 = (_Float16)v.w;
+      h4 hv = {h0, h1, h2, h3};
+      h4 lv = {(_Float16)(v.x - (float)h0), (_Float16)(v.y - (float)h1), (_Float16)(v.z - (float)h2),
+               (_Float16)(v.w - (float)h3)};
+      const int64_t o = (((pix >> 4) * (ld >> 5) + (c >> 5)) << 9) + ((pix & 15) << 5) + (c & 31);
+      *reinterpret_cast<uint2*>(hi + o) = *reinterpret_cast<uint2*>(&hv);
+      *reinterpret_cast<uint2*>(lo + o) = *reinterpret_cast<uint2*>(&lv);
+    }
   }
 }
 
@@ -800,11 +837,13 @@ int ResNetTrunk::add_bn_relu(const std::string& bn, const Buf& in, Buf* out) {
   XDET_HIP(hipMemcpy(dsc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
   XDET_HIP(hipMemcpy(dsh, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
   XDET_TRY(new_buf(in.H, in.W, in.C, out));
+  if (g_default_precision != PREC_F32 && in.ld % 32 == 0) XDET_TRY(new_planes(out));
   const Buf i = in, o = *out;
   ops.push_back({bn, 0, 0.0, [=](int N, hipStream_t s) {
                    const int64_t npix = (int64_t)N * i.H * i.W;
                    const int blocks = (int)std::min<int64_t>(cdiv(npix * (i.ld / 4), 256), 256 * 32);
-                   hipLaunchKernelGGL(bn_relu_kernel, dim3(blocks), dim3(256), 0, s, i.p, dsc, dsh, o.p, npix, i.ld);
+                   hipLaunchKernelGGL(bn_relu_kernel, dim3(blocks), dim3(256), 0, s, i.p, dsc, dsh, o.p, o.hi, o.lo, npix,
+                                      i.ld);
                    XDET_LAUNCH_CHECK();
                    return (int)XDET_OK;
                  }});
@@ -831,7 +870,9 @@ int ResNetTrunk::build() {
       if (b == 0) XDET_TRY(conv_bn(cname(), "", 0.f, 0, pre, 1, 4 * f, s, s > 1 ? 2 : 1, 0, nullptr, 0, &shortcut, 0));
       const std::string c1 = cname(), b1 = bname(), c2 = cname(), b2 = bname(), c3 = cname();
       // conv1x1 -> (BN+ReLU fused into its epilogue) -> conv3x3/s -> (BN+ReLU fused) -> conv1x1 + shortcut
+      if (s == 1) emit_planes_next = 1;           // a stride-1 3x3 takes its input as planes
       XDET_TRY(conv_bn(c1, b1, 1e-5f, 0, pre, 1, f, 1, 1, 1, nullptr, 0, &y1));
+      emit_planes_next = 1;                       // the closing 1x1 always does
       XDET_TRY(conv_bn(c2, b2, 1e-5f, 0, y1, 3, f, s, s > 1 ? 2 : 1, 1, nullptr, 0, &y2, 1));
       XDET_TRY(conv_bn(c3, "", 0.f, 0, y2, 1, 4 * f, 1, 1, 0, &shortcut, 0, &y3));
       x = y3;
