@@ -109,3 +109,22 @@ def test_sampled_images_against_the_oracle(big, oracle, lh_weights):
     print('full-size batch, 2 sampled images: oracle %d matched %d extra %d' % (total, matched, extra))
     assert total > 100
     assert matched == total and extra == 0, (matched, total, extra)
+
+
+def test_pipelined_detector_equals_single(big, lh_weights):
+    """the 2-way concurrent front end (bench default) returns exactly the single detector's detections,
+    also for a ragged batch (the last sub-batch short, one empty)"""
+    from xdet.model import PipelinedDetector
+    from xdet.runtime import set_precision
+    _, _, imgs, s, b = big
+    set_precision('f16x3')
+    try:
+        pd = PipelinedDetector(lh_weights, ways=2, max_batch=B, image_size=480, rpn_post_nms_top_n=300)
+    finally:
+        set_precision('f32')
+    for n in (B, 41, 7):
+        got = pd.forward(imgs[:n])
+        assert len(got) == n
+        for i in (0, n // 2, n - 1):
+            for c in range(20):
+                assert np.array_equal(got[i][c + 1][0], s[i, c]) and np.array_equal(got[i][c + 1][1], b[i, c])
