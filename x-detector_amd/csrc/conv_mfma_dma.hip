@@ -18,6 +18,7 @@
 // Arithmetic is identical to conv_mfma_split.hip (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, f32
 // accumulate, per-channel power-of-two weight pre-scale folded into the epilogue).
 #include "common.h"
+#include "conv_epilogue.h"
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -32,82 +33,6 @@ typedef unsigned short u16;
 #define XDET_GLDS16(gptr, lptr)                                                                        \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),              \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-
-// Epilogue shared by the conv kernels of this file.  The MFMA accumulator layout gives each lane one
-// column and 16 scattered rows, i.e. 4-byte global stores (and residual loads).  Bounce each 32-row slab
-// of the wave tile through the (now idle) operand LDS so a lane owns 4 consecutive channels of a row:
-// 16-B coalesced residual loads and stores, 4x fewer memory instructions.
-template <int WM, int WN, int TM, int TN, int NW, int LDS_BYTES>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[TM][TN], u16* smem16, int wave,
-                                              int lane, int wm, int wn, int m0, int n0) {
-  const int frow = lane & 31;
-  const int fh = lane >> 5;
-  constexpr int EP_LD = WN + 4;                  // floats per staged row (+4: keeps float4 rows 16-B aligned)
-  constexpr int C4N = WN / 4;                    // float4 columns per row
-  static_assert(NW * 32 * EP_LD * 4 <= LDS_BYTES, "epilogue staging must fit the operand LDS");
-  __syncthreads();                               // every wave is done reading its operands
-  float* ep = reinterpret_cast<float*>(smem16) + wave * (32 * EP_LD);
-  const int c4 = lane % C4N;                     // fixed per lane: its 4 output channels
-  const int co4 = n0 + wn * WN + c4 * 4;
-  const bool col_ok = co4 < p.ldo;
-  float4 sc4 = make_float4(0.f, 0.f, 0.f, 0.f), sh4 = sc4;
-  if (col_ok) {
-    sc4 = *reinterpret_cast<const float4*>(p.scale + co4);
-    sh4 = *reinterpret_cast<const float4*>(p.shift + co4);
-  }
-  constexpr int NQ = (32 * C4N) / 64;            // float4 rows a lane handles per 32-row slab
-  // residual rows of slab i are requested before slab i-1 is stored, so their HBM latency hides
-  // behind the LDS bounce instead of being paid once per slab (one workgroup per CU: nothing else
-  // would cover it)
-  float4 rr[NQ];
-  auto load_res = [&](int i) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int m = m0 + wm * WM + i * 32 + (q * 64 + lane) / C4N;
-      rr[q] = (col_ok && m < p.M) ? *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldr + co4)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  if (p.res) load_res(0);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        ep[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP_LD + j * 32 + frow] = acc[i][j][r];
-    float4 v[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const float4 a = *reinterpret_cast<const float4*>(ep + ((q * 64 + lane) / C4N) * EP_LD + c4 * 4);
-      v[q] = make_float4(fmaf(a.x, sc4.x, sh4.x), fmaf(a.y, sc4.y, sh4.y), fmaf(a.z, sc4.z, sh4.z),
-                         fmaf(a.w, sc4.w, sh4.w));
-      if (p.res) { v[q].x += rr[q].x; v[q].y += rr[q].y; v[q].z += rr[q].z; v[q].w += rr[q].w; }
-      if (p.relu_out) {
-        v[q].x = fmaxf(v[q].x, 0.f); v[q].y = fmaxf(v[q].y, 0.f); v[q].z = fmaxf(v[q].z, 0.f); v[q].w = fmaxf(v[q].w, 0.f);
-      }
-    }
-    if (p.res && i + 1 < TM) load_res(i + 1);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int m = m0 + wm * WM + i * 32 + (q * 64 + lane) / C4N;
-      if (col_ok && m < p.M) {
-        *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + co4) = v[q];
-        if (p.out_hi) {   // second copy as split planes for a consumer on the LDS-DMA path
-          float4 t = v[q];
-          if (p.planes_relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
-          const _Float16 h0 = (_Float16)t.x, h1 = (_Float16)t.y, h2 = (_Float16)t.z, h3 = (_Float16)t.w;
-          f16x4 hv = {h0, h1, h2, h3};
-          f16x4 lv = {(_Float16)(t.x - (float)h0), (_Float16)(t.y - (float)h1), (_Float16)(t.z - (float)h2),
-                      (_Float16)(t.w - (float)h3)};
-          const size_t o = ((((size_t)m >> 4) * (size_t)(p.ldo >> 5) + (size_t)(co4 >> 5)) << 9) + ((m & 15) << 5) + (co4 & 31);
-          *reinterpret_cast<uint2*>(p.out_hi + o) = *reinterpret_cast<uint2*>(&hv);
-          *reinterpret_cast<uint2*>(p.out_lo + o) = *reinterpret_cast<uint2*>(&lv);
-        }
-      }
-    }
-  }
-}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(ConvParams p) {

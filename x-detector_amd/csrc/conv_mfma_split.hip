@@ -20,6 +20,7 @@
 // ahead in two register sets (the compute of one 32-deep step is too short to cover L2/HBM
 // latency on its own), LDS is double-buffered: one barrier per K-step.
 #include "common.h"
+#include "conv_epilogue.h"
 
 namespace xdet {
 
@@ -215,32 +216,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16_kernel(ConvParams p) {
     __syncthreads();
   }
 
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int co = n0 + wn * WN + j * 32 + frow;
-    if (co >= p.ldo) continue;
-    const float sc = p.scale[co], sh = p.shift[co];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (m < p.M) {
-          float v = fmaf(acc[i][j][r], sc, sh);
-          if (p.res) v += p.res[(size_t)m * p.ldr + co];
-          if (p.relu_out) v = fmaxf(v, 0.f);
-          p.out[(size_t)m * p.ldo + co] = v;
-          if (p.out_hi) {
-            const float t = p.planes_relu ? fmaxf(v, 0.f) : v;
-            const _Float16 h = (_Float16)t, l = (_Float16)(t - (float)h);
-            const size_t o = ((((size_t)m >> 4) * (size_t)(p.ldo >> 5) + (size_t)(co >> 5)) << 9) + ((m & 15) << 5) + (co & 31);
-            p.out_hi[o] = *reinterpret_cast<const u16*>(&h);
-            p.out_lo[o] = *reinterpret_cast<const u16*>(&l);
-          }
-        }
-      }
-    }
-  }
+  conv_epilogue<WM, WN, TM, TN, 4, 2 * STAGE * 2>(p, acc, smem16, wave, lane, wm, wn, m0, n0);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool SMALL_CIN, int NSPLIT>
