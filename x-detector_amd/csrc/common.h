@@ -47,7 +47,7 @@ struct ConvParams {
   const unsigned short* in_hi;
   const unsigned short* in_lo;
   const unsigned short* zeros;   // >= 16 B of zeros: the source of out-of-image taps for the LDS DMA
-  float* out;        // NHWC, channel stride ldo
+  float* out;        // NHWC, channel stride ldo; may be NULL when only the planes below are wanted
   // optional second copy of the output as split planes [pix/16][ldo/32][16][32] for a consumer on the
   // LDS-DMA path (saves its split pass); planes_relu: the planes hold max(out, 0) (a `relu -> conv` edge)
   unsigned short* out_hi;

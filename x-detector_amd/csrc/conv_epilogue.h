@@ -66,7 +66,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, ep_f32x16 (&a
     for (int q = 0; q < NQ; ++q) {
       const int m = m0 + wm * WM + i * 32 + (q * 64 + lane) / C4N;
       if (col_ok && m < p.M) {
-        *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + co4) = v[q];
+        if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + co4) = v[q];
         if (p.out_hi) {   // second copy as split planes for a consumer on the LDS-DMA path
           float4 t = v[q];
           if (p.planes_relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }

@@ -256,6 +256,7 @@ struct Buf {
   float* p = nullptr;
   unsigned short *hi = nullptr, *lo = nullptr;   // optional split-precision f16 planes of the same tensor
   bool planes_relu = false;                      // the planes hold relu(tensor)
+  bool no_f32 = false;                           // only the planes are ever written (p stays unused)
   int H = 0, W = 0, C = 0, ld = 0;
   size_t per_image() const { return (size_t)H * W * ld; }
 };
@@ -356,7 +357,8 @@ struct Plan {
   // ---- op builders ----
   // Set by a builder right before add_conv / conv_bn when it knows the output feeds a conv on the
   // LDS-DMA path: 1 = the conv also writes its output as split planes (the consumer then needs no
-  // split pass), 2 = the planes hold relu(output) (for a consumer that applies ReLU on load).
+  // split pass), 2 = the planes hold relu(output) (for a consumer that applies ReLU on load),
+  // 3 = planes ONLY: every consumer is on the LDS-DMA path, the f32 tensor is never written.
   int emit_planes_next = 0;
   int add_conv(const std::string& name, int stage, const Buf& in_, ConvLayer* L, const Buf* res, int relu_in, Buf* out) {
     Buf in = in_;
@@ -366,6 +368,7 @@ struct Plan {
     // if the producer did not emit planes, one cheap element-wise pass makes them (ReLU folded in)
     if (L->dma_capable() && L->stride == 1) {
       if (in.hi && in.planes_relu && !relu_in) in.hi = in.lo = nullptr;   // relu(x) planes are no use here
+      XDET_REQUIRE(!in.no_f32 || (in.hi && !relu_in), "plan: this tensor exists as planes only");
       if (in.hi && relu_in && in.planes_relu) {
         relu_in = 0;                               // the producer already wrote relu(x) planes
       } else if (!in.hi || relu_in) {
@@ -375,6 +378,7 @@ struct Plan {
         relu_in = 0;
       }
     } else {
+      XDET_REQUIRE(!in.no_f32, "plan: this tensor exists as planes only");
       in.hi = in.lo = nullptr;
     }
     int Ho, Wo, a, b;
@@ -384,20 +388,22 @@ struct Plan {
     if (emit) {
       XDET_TRY(new_planes(out));
       out->planes_relu = emit == 2;
+      out->no_f32 = emit == 3;
     }
     const Buf i = in, o = *out;
     const float* rp = res ? res->p : nullptr;
     const unsigned short* z = zeros;
     if (res) XDET_REQUIRE(res->H == Ho && res->W == Wo && res->ld == o.ld, "plan: residual shape mismatch");
     ops.push_back({name, stage, L->flops(in.H, in.W), [=](int N, hipStream_t s) {
-                     return L->forward(i.p, N, i.H, i.W, i.ld, o.p, o.ld, rp, relu_in, s, i.hi, i.lo, z, o.hi, o.lo,
-                                       o.planes_relu ? 1 : 0);
+                     return L->forward(i.p, N, i.H, i.W, i.ld, o.no_f32 ? nullptr : o.p, o.ld, rp, relu_in, s, i.hi, i.lo,
+                                       z, o.hi, o.lo, o.planes_relu ? 1 : 0);
                    }});
     return XDET_OK;
   }
   // `planes_only`: the single consumer is a pointwise conv on the split path -> write f16 planes, no f32
   int add_dw(const std::string& name, int stage, const Buf& in, DepthwiseLayer* L, int relu_in, Buf* out,
              bool planes_only = false) {
+    XDET_REQUIRE(!in.no_f32, "plan: this tensor exists as planes only");
     if (planes_only) {
       *out = Buf();
       out->H = in.H; out->W = in.W; out->C = in.C; out->ld = in.ld;
@@ -417,6 +423,7 @@ struct Plan {
     return XDET_OK;
   }
   int add_pool(const std::string& name, int stage, const Buf& in, const Buf* res, Buf* out) {
+    XDET_REQUIRE(!in.no_f32 && !(res && res->no_f32), "plan: this tensor exists as planes only");
     int Ho, Wo, pt, pl;
     same_pad(in.H, 3, 2, 1, &pt, &Ho);
     same_pad(in.W, 3, 2, 1, &pl, &Wo);
@@ -528,7 +535,7 @@ struct LightHeadNet : Plan {
     in4.H = S; in4.W = S; in4.C = 3;
     XDET_TRY(new_buf(S, S, 3, &in4));
     Buf x, r, t;
-    emit_planes_next = 1;   // feeds block1_conv2 (LDS-DMA path) only
+    emit_planes_next = 3;   // feeds block1_conv2 (LDS-DMA path) only
     XDET_TRY(conv_bn("block1_conv1", "block1_conv1_bn", eps, ST_BODY, in4, 3, 32, 2, 0, 1, nullptr, 0, &x));
     XDET_TRY(conv_bn("block1_conv2", "block1_conv2_bn", eps, ST_BODY, x, 3, 64, 1, 0, 1, nullptr, 0, &t));
     x = t;
@@ -579,7 +586,7 @@ struct LightHeadNet : Plan {
     ConvLayer* L0 = keep(new ConvLayer());
     XDET_TRY(L0->init(3, 3, 728, 512, 1, 1, 1, 0, 0, k0->v.data(), nullptr, b0->v.data(), 1));
     Buf hid;
-    emit_planes_next = 1;
+    emit_planes_next = 3;   // only the fused 1x1 heads read it
     XDET_TRY(add_conv("rpn_head/conv2d", ST_RPN, mid_x, L0, nullptr, /*relu_in=*/1, &hid));
     // cls (2A) and box (4A) 1x1 heads share their input: one GEMM over the concatenated filters
     const int co = 6 * A;
@@ -617,7 +624,7 @@ struct LightHeadNet : Plan {
     ConvLayer* LA = keep(new ConvLayer());
     XDET_TRY(LA->init(15, 1, 2048, 2 * mid, 1, 1, 1, 0, 0, ka.data(), nullptr, ba.data(), 0));
     Buf t;
-    emit_planes_next = 1;
+    emit_planes_next = 3;   // only the (1,15) conv reads it
     XDET_TRY(add_conv("large_sep_feature/Branch_0+1/conv2d", ST_LSEP, out, LA, nullptr, 0, &t));
     // branch_0b + branch_1b = one (1,15) conv over the 2*mid stacked channels; then BN(1e-5)+ReLU
     std::vector<float> kb((size_t)15 * 2 * mid * co);
@@ -870,9 +877,9 @@ int ResNetTrunk::build() {
       if (b == 0) XDET_TRY(conv_bn(cname(), "", 0.f, 0, pre, 1, 4 * f, s, s > 1 ? 2 : 1, 0, nullptr, 0, &shortcut, 0));
       const std::string c1 = cname(), b1 = bname(), c2 = cname(), b2 = bname(), c3 = cname();
       // conv1x1 -> (BN+ReLU fused into its epilogue) -> conv3x3/s -> (BN+ReLU fused) -> conv1x1 + shortcut
-      if (s == 1) emit_planes_next = 1;           // a stride-1 3x3 takes its input as planes
+      if (s == 1) emit_planes_next = 3;           // a stride-1 3x3 takes its input as planes (only)
       XDET_TRY(conv_bn(c1, b1, 1e-5f, 0, pre, 1, f, 1, 1, 1, nullptr, 0, &y1));
-      emit_planes_next = 1;                       // the closing 1x1 always does
+      emit_planes_next = 3;                       // the closing 1x1 always does
       XDET_TRY(conv_bn(c2, b2, 1e-5f, 0, y1, 3, f, s, s > 1 ? 2 : 1, 1, nullptr, 0, &y2, 1));
       XDET_TRY(conv_bn(c3, "", 0.f, 0, y2, 1, 4 * f, 1, 1, 0, &shortcut, 0, &y3));
       x = y3;
