@@ -53,6 +53,10 @@ struct ConvParams {
   unsigned short* out_hi;
   unsigned short* out_lo;
   int planes_relu;
+  // optional per-channel affine applied to the planes copy before its ReLU (a following inference BN:
+  // planes = relu(out * pl_scale + pl_shift)); NULL = none
+  const float* pl_scale;
+  const float* pl_shift;
   const float* scale;   // [Cout_pad] folded BN scale (1 for plain bias)
   const float* shift;   // [Cout_pad] folded BN shift / bias
   const float* res;     // optional residual, same N,Ho,Wo, channel stride ldr

@@ -29,6 +29,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, ep_f32x16 (&a
     sc4 = *reinterpret_cast<const float4*>(p.scale + co4);
     sh4 = *reinterpret_cast<const float4*>(p.shift + co4);
   }
+  float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.out_hi && p.pl_scale && col_ok) {
+    psc = *reinterpret_cast<const float4*>(p.pl_scale + co4);
+    psh = *reinterpret_cast<const float4*>(p.pl_shift + co4);
+  }
   constexpr int NQ = (32 * C4N) / 64;            // float4 rows a lane handles per 32-row slab
   // residual rows of slab i are requested before slab i-1 is stored, so their HBM latency hides
   // behind the LDS bounce instead of being paid once per slab (one workgroup per CU: nothing else
@@ -69,6 +74,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, ep_f32x16 (&a
         if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + co4) = v[q];
         if (p.out_hi) {   // second copy as split planes for a consumer on the LDS-DMA path
           float4 t = v[q];
+          if (p.pl_scale) {
+            t.x = fmaf(t.x, psc.x, psh.x); t.y = fmaf(t.y, psc.y, psh.y);
+            t.z = fmaf(t.z, psc.z, psh.z); t.w = fmaf(t.w, psc.w, psh.w);
+          }
           if (p.planes_relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
           const _Float16 h0 = (_Float16)t.x, h1 = (_Float16)t.y, h2 = (_Float16)t.z, h3 = (_Float16)t.w;
           ep_f16x4 hv = {h0, h1, h2, h3};

@@ -204,7 +204,8 @@ struct ConvLayer : LayerBase {
   int forward(const float* in, int N, int H, int W, int ldi, float* out, int ldo, const float* res, int relu_in,
               hipStream_t s, const unsigned short* in_hi = nullptr, const unsigned short* in_lo = nullptr,
               const unsigned short* zeros = nullptr, unsigned short* out_hi = nullptr,
-              unsigned short* out_lo = nullptr, int planes_relu = 0) const {
+              unsigned short* out_lo = nullptr, int planes_relu = 0, const float* pl_scale = nullptr,
+              const float* pl_shift = nullptr) const {
     XDET_REQUIRE(ldi == ld_in(), "conv: ld_in must be round_up(cin,32) (4 for cin<=4)");
     XDET_REQUIRE(ldo == ld_out(), "conv: ld_out must be round_up(cout,32)");
     ConvParams p;
@@ -218,6 +219,7 @@ struct ConvLayer : LayerBase {
     p.relu_in = relu_in; p.relu_out = relu_out;
     p.in_hi = in_hi; p.in_lo = in_lo; p.zeros = zeros;
     p.out_hi = precision == PREC_F32 ? nullptr : out_hi; p.out_lo = out_lo; p.planes_relu = planes_relu;
+    p.pl_scale = pl_scale; p.pl_shift = pl_shift;
     if (precision == PREC_F32) return launch_conv_mfma_f32(p, small_cin, n_tile, s);
     if (in_hi) {   // A operand already split into f16 planes by its producer: LDS-DMA kernel
       XDET_REQUIRE(!small_cin && relu_in == 0, "conv(dma): needs >= 32 input channels and no ReLU-on-load");
@@ -359,11 +361,16 @@ struct Plan {
   // LDS-DMA path: 1 = the conv also writes its output as split planes (the consumer then needs no
   // split pass), 2 = the planes hold relu(output) (for a consumer that applies ReLU on load),
   // 3 = planes ONLY: every consumer is on the LDS-DMA path, the f32 tensor is never written.
+  // With emit_bn_scale/shift set (device arrays, ld floats) the planes copy is relu(out*scale+shift):
+  // a following BN+ReLU pre-activation folded into this conv's epilogue.
   int emit_planes_next = 0;
+  const float *emit_bn_scale = nullptr, *emit_bn_shift = nullptr;
   int add_conv(const std::string& name, int stage, const Buf& in_, ConvLayer* L, const Buf* res, int relu_in, Buf* out) {
     Buf in = in_;
     const int emit = L->precision == PREC_F32 ? 0 : emit_planes_next;
+    const float *bsc = emit ? emit_bn_scale : nullptr, *bsh = emit ? emit_bn_shift : nullptr;
     emit_planes_next = 0;
+    emit_bn_scale = emit_bn_shift = nullptr;
     // split path: big stride-1 contractions take their A operand as f16 planes through the LDS DMA;
     // if the producer did not emit planes, one cheap element-wise pass makes them (ReLU folded in)
     if (L->dma_capable() && L->stride == 1) {
@@ -396,7 +403,7 @@ struct Plan {
     if (res) XDET_REQUIRE(res->H == Ho && res->W == Wo && res->ld == o.ld, "plan: residual shape mismatch");
     ops.push_back({name, stage, L->flops(in.H, in.W), [=](int N, hipStream_t s) {
                      return L->forward(i.p, N, i.H, i.W, i.ld, o.no_f32 ? nullptr : o.p, o.ld, rp, relu_in, s, i.hi, i.lo,
-                                       z, o.hi, o.lo, o.planes_relu ? 1 : 0);
+                                       z, o.hi, o.lo, (o.planes_relu || bsc) ? 1 : 0, bsc, bsh);
                    }});
     return XDET_OK;
   }
@@ -869,11 +876,19 @@ int ResNetTrunk::build() {
   XDET_TRY(add_pool("initial_max_pool", 0, x, nullptr, &t));
   x = t;
   const int filters[4] = {64, 128, 256, 512}, blocks[4] = {3, 4, 6, 3}, strides[4] = {1, 2, 2, 2};
+  Buf fused_pre;                 // planes-only pre-activation of the NEXT block, written by this block's last conv
+  bool have_fused = false;
   for (int st = 0; st < 4; ++st)
     for (int b = 0; b < blocks[st]; ++b) {
       const int f = filters[st], s = b == 0 ? strides[st] : 1;
       Buf pre, shortcut = x, y1, y2, y3;
-      XDET_TRY(add_bn_relu(bname(), x, &pre));
+      if (have_fused) {
+        pre = fused_pre;
+        (void)bname();                              // its BN was folded into the previous block's epilogue
+      } else {
+        XDET_TRY(add_bn_relu(bname(), x, &pre));
+      }
+      have_fused = false;
       if (b == 0) XDET_TRY(conv_bn(cname(), "", 0.f, 0, pre, 1, 4 * f, s, s > 1 ? 2 : 1, 0, nullptr, 0, &shortcut, 0));
       const std::string c1 = cname(), b1 = bname(), c2 = cname(), b2 = bname(), c3 = cname();
       // conv1x1 -> (BN+ReLU fused into its epilogue) -> conv3x3/s -> (BN+ReLU fused) -> conv1x1 + shortcut
@@ -881,7 +896,36 @@ int ResNetTrunk::build() {
       XDET_TRY(conv_bn(c1, b1, 1e-5f, 0, pre, 1, f, 1, 1, 1, nullptr, 0, &y1));
       emit_planes_next = 3;                       // the closing 1x1 always does
       XDET_TRY(conv_bn(c2, b2, 1e-5f, 0, y1, 3, f, s, s > 1 ? 2 : 1, 1, nullptr, 0, &y2, 1));
+      // The next block opens with BN+ReLU of this block's output.  Unless that block starts with strided
+      // convs (which gather f32), fold it in: the closing conv writes its f32 output (the identity
+      // shortcut) AND relu(bn_next(output)) as planes, and the separate element-wise pass disappears.
+      const bool last = st == 3 && b == blocks[st] - 1;
+      const bool next_strided = b == blocks[st] - 1 && !last;      // every later stage opens with stride 2
+      float *nsc = nullptr, *nsh = nullptr;
+      if (!last && !next_strided && g_default_precision != PREC_F32) {
+        const std::string nbn = bi == 0 ? "batch_normalization" : "batch_normalization_" + std::to_string(bi);
+        std::vector<float> sc, sh;
+        XDET_TRY(fold_bn(nbn, 4 * f, 1e-5f, nullptr, &sc, &sh));
+        const int ldn = round_up(4 * f, 32);
+        sc.resize(ldn, 0.f);
+        sh.resize(ldn, 0.f);
+        XDET_TRY(alloc_bytes(sc.size() * 4, reinterpret_cast<void**>(&nsc)));
+        XDET_TRY(alloc_bytes(sh.size() * 4, reinterpret_cast<void**>(&nsh)));
+        XDET_HIP(hipMemcpy(nsc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+        XDET_HIP(hipMemcpy(nsh, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
+        emit_planes_next = 1;
+        emit_bn_scale = nsc;
+        emit_bn_shift = nsh;
+      }
       XDET_TRY(conv_bn(c3, "", 0.f, 0, y2, 1, 4 * f, 1, 1, 0, &shortcut, 0, &y3));
+      if (nsc) {
+        fused_pre = y3;                             // same shape; lives as planes only
+        fused_pre.p = nullptr;
+        fused_pre.no_f32 = true;
+        fused_pre.planes_relu = false;
+        y3.hi = y3.lo = nullptr;                    // the f32 tensor itself has no planes
+        have_fused = true;
+      }
       x = y3;
     }
   XDET_TRY(add_bn_relu(bname(), x, &outb));
