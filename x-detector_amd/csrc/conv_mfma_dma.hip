@@ -12,8 +12,9 @@
 //     [Kp/32][Cout_pad][32] -- so the 16 rows x 64 B one DMA instruction moves are one contiguous
 //     1 KB run (tools/ubench/dma_rate.hip: 63 GB/s per CU for 1 KB runs vs 30 GB/s for 64 B segments
 //     at a row stride when the stream misses L2);
-//   * two LDS stages (64 KB for a 128x128 tile -> two workgroups per CU), one barrier per
-//     32-deep K step: the DMA of step k+1 flies while step k is multiplied.
+//   * two LDS stages (64 KB for a 128x128 tile -> two workgroups per CU), one barrier per 32-deep K
+//     step placed between its two 16-deep halves, fragments double-buffered in registers, the DMA
+//     pieces of step k+2 interleaved with the MFMAs of step k (see the main loop).
 //
 // Arithmetic is identical to conv_mfma_split.hip (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, f32
 // accumulate, per-channel power-of-two weight pre-scale folded into the epilogue).
@@ -27,7 +28,6 @@ namespace xdet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 
 #define XDET_GLDS16(gptr, lptr)                                                                        \
@@ -271,21 +271,17 @@ int launch_conv_mfma_dma(const ConvParams& p, int n_tile, int nsplit, hipStream_
                "conv(dma): split planes missing");
   if (p.M <= 0) return XDET_OK;
   if (n_tile == 128 && nsplit == 3) {
-    // Tile choice.  The kernel is bound by L2->LDS operand traffic, so the biggest tile wins as long
-    // as the grid still covers the 256 CUs (measured on MI355X, tools/conv_bench.py --planes):
+    // Tile choice.  The biggest tile moves the fewest operand bytes and LDS-DMA pieces per MFMA, so it
+    // wins as long as the grid still covers the 256 CUs (measured on MI355X, tools/conv_bench.py --planes):
     // 256x256 once there are >= 2 workgroups per CU, or ~1 per CU with a long K loop to amortise its
     // prologue/epilogue; 256x128 from ~2/3 workgroup per CU; else 128x128 (two workgroups share a CU).
-    static const char* tile_env = getenv("XDET_TILE");   // experiment override: 128x128 | 256x128 | 256x256
     const int64_t b256 = cdiv(p.M, 256) * (p.Cout_pad / 256), b128n = cdiv(p.M, 256) * (p.Cout_pad / 128);
     const int nk = p.Kp / 32;
     int tile = 0;
-    static const char* t256 = getenv("XDET_T256");
-    const int64_t thr256 = t256 ? atoi(t256) : 512;
     // ...or when the 256x256 grid fills whole rounds of the 256 CUs (within 6 %)
     const bool full_rounds = b256 >= 240 && (b256 % 256 == 0 || b256 % 256 >= 240);
-    if (p.Cout_pad % 256 == 0 && (b256 >= thr256 || full_rounds || (b256 >= 200 && nk >= 40))) tile = 2;
+    if (p.Cout_pad % 256 == 0 && (b256 >= 512 || full_rounds || (b256 >= 200 && nk >= 40))) tile = 2;
     else if (b128n >= 170) tile = 1;
-    if (tile_env) tile = !strcmp(tile_env, "256x256") ? (p.Cout_pad % 256 == 0 ? 2 : 1) : !strcmp(tile_env, "256x128") ? 1 : 0;
     if (tile == 2) return launch_d<256, 256, 2, 4, 3>(p, s);
     if (tile == 1) return launch_d<256, 128, 4, 2, 3>(p, s);
   }

@@ -47,14 +47,6 @@ __device__ __forceinline__ int64_t blocked_off(int64_t pix, int c, int c32n) {
   return (((pix >> 4) * c32n + (c >> 5)) << 9) + ((pix & 15) << 5) + (c & 31);
 }
 
-__device__ __forceinline__ void split_store(const float4 v, unsigned short* hi, unsigned short* lo, int64_t o) {
-  const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y, h2 = (_Float16)v.z, h3 = (_Float16)v.w;
-  f16x4e hv = {h0, h1, h2, h3};
-  f16x4e lv = {(_Float16)(v.x - (float)h0), (_Float16)(v.y - (float)h1), (_Float16)(v.z - (float)h2),
-               (_Float16)(v.w - (float)h3)};
-  *reinterpret_cast<uint2*>(hi + o) = *reinterpret_cast<uint2*>(&hv);
-  *reinterpret_cast<uint2*>(lo + o) = *reinterpret_cast<uint2*>(&lv);
-}
 
 template <bool SPLIT>
 __device__ __forceinline__ void dw_store_strip(const float4* acc, float* __restrict__ out, unsigned short* __restrict__ hi,
