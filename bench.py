@@ -53,7 +53,7 @@ def parse():
     ap.add_argument('--eager', action='store_true',
                     help='launch kernel by kernel in the timed region (default: replay the captured hipGraph)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-images', type=int, default=4)
+    ap.add_argument('--cpu-images', type=int, default=12, help='images of the bounded CPU-oracle sample (~1.4 s each)')
     ap.add_argument('--ops', action='store_true', help='also print the per-op table to stderr')
     ap.add_argument('--no-parity', action='store_true', help='skip the live f16x3-vs-f32 GPU cross-check')
     return ap.parse_args()
