@@ -89,3 +89,18 @@ def test_checkpoint_name_import_roundtrip(tmp_path, lh_weights):
     np.savez(path, **extra)
     with pytest.raises(KeyError):
         W.load_weights_npz(path)
+
+
+def test_bboxes_draw_on_img():
+    """F4 drawing helper (utility/draw_toolbox.py:72-104): outline at int(coord*shape), class 0 and
+    sub-pixel boxes skipped, image modified in place and returned."""
+    from xdet.evaluation import bboxes_draw_on_img, COLORS_TABLEAU
+    img = np.zeros((100, 200, 3), np.uint8)
+    boxes = np.array([[0.2, 0.1, 0.8, 0.5], [0.1, 0.6, 0.9, 0.9], [0.5, 0.5, 0.504, 0.9]], np.float32)
+    out = bboxes_draw_on_img(img, np.array([3, 0, 5]), np.array([0.9, 0.8, 0.7]), boxes, thickness=2)
+    assert out is img
+    col = np.array(COLORS_TABLEAU[3], np.uint8)
+    assert np.array_equal(img[20, 60], col) and np.array_equal(img[80, 60], col)        # top / bottom edges
+    assert np.array_equal(img[50, 20], col) and np.array_equal(img[50, 100], col)       # left / right edges
+    assert not img[50, 60].any()                                                          # interior untouched
+    assert not img[:, 110:].any()                                                         # class 0 and the thin box skipped

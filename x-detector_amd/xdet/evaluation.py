@@ -122,3 +122,54 @@ def average_precision_voc07(precision, recall):
     p = np.concatenate([np.asarray(precision, np.float64), [0.]])
     r = np.concatenate([np.asarray(recall, np.float64), [np.inf]])
     return float(sum(p[r >= t].max() / 11. for t in np.arange(0., 1.1, 0.1)))
+
+
+# ---- drawing (utility/draw_toolbox.py:72-104) -------------------------------------------------
+# Tableau-20 palette, white for background -- the colour table the reference indexes by class id
+COLORS_TABLEAU = [(255, 255, 255), (31, 119, 180), (174, 199, 232), (255, 127, 14), (255, 187, 120), (44, 160, 44),
+                  (152, 223, 138), (214, 39, 40), (255, 152, 150), (148, 103, 189), (197, 176, 213), (140, 86, 75),
+                  (196, 156, 148), (227, 119, 194), (247, 182, 210), (127, 127, 127), (199, 199, 199),
+                  (188, 189, 34), (219, 219, 141), (23, 190, 207), (158, 218, 229)]
+
+
+def bboxes_draw_on_img(img, classes, scores, bboxes, thickness=2):
+    """Same contract as the reference's bboxes_draw_on_img: img uint8 [H,W,3] (modified in place and
+    returned), bboxes (ymin,xmin,ymax,xmax) in [0,1]; class 0 and boxes thinner than one pixel are
+    skipped; corners are `int(coord * shape)`.  Rectangles are rasterised with NumPy (no OpenCV here;
+    the outline is `thickness` pixels wide, centred on the box edge like cv2.rectangle); the
+    'name/score%' caption is drawn with Pillow when it is importable and silently omitted otherwise."""
+    h, w = img.shape[:2]
+    names = label2name_table()
+    try:
+        from PIL import Image, ImageDraw
+    except Exception:
+        Image = ImageDraw = None
+    captions = []
+    for i in range(bboxes.shape[0]):
+        c = int(classes[i])
+        if c < 1:
+            continue
+        y0, x0 = int(bboxes[i][0] * h), int(bboxes[i][1] * w)
+        y1, x1 = int(bboxes[i][2] * h), int(bboxes[i][3] * w)
+        if y1 - y0 < 1 or x1 - x0 < 1:
+            continue
+        color = np.asarray(COLORS_TABLEAU[c % len(COLORS_TABLEAU)], img.dtype)
+        lo, hi = thickness // 2, (thickness + 1) // 2
+
+        def span(a, n):
+            return slice(max(a - lo, 0), min(a + hi, n))
+        ys, xs = slice(max(y0 - lo, 0), min(y1 + hi, h)), slice(max(x0 - lo, 0), min(x1 + hi, w))
+        img[span(y0, h), xs] = color
+        img[span(y1, h), xs] = color
+        img[ys, span(x0, w)] = color
+        img[ys, span(x1, w)] = color
+        captions.append((x0, max(y0 - 12, 0), '%s/%.1f%%' % (names.get(c, str(c)), float(scores[i]) * 100), tuple(int(v) for v in color)))
+    if ImageDraw is not None and captions:
+        pil = Image.fromarray(img)
+        d = ImageDraw.Draw(pil)
+        for x, y, s, col in captions:
+            box = d.textbbox((x, y), s)
+            d.rectangle(box, fill=col)
+            d.text((x, y), s, fill=(255, 255, 255))
+        img[...] = np.asarray(pil)
+    return img
