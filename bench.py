@@ -50,6 +50,10 @@ def parse():
     ap.add_argument('--proposals', type=int, default=300, help='rpn_post_nms_top_n (BASELINE config 3: 300)')
     ap.add_argument('--precision', default='f16x3', choices=['f32', 'f16x3', 'f16'],
                     help='conv/dense arithmetic: exact f32 MFMA, split-precision f16 MFMA (~f32 accuracy), plain f16')
+    ap.add_argument('--voc-stream', action='store_true',
+                    help='BASELINE config 4 input: raw uint8 VOC-shape images resident in HBM (shapes cycling '
+                         '375x500, 500x375, 333x500, 500x333); every step runs the F1 pre-processing kernel per '
+                         'image (whiten + TF-legacy bilinear warp to 480x480) in front of the forward')
     ap.add_argument('--eager', action='store_true',
                     help='launch kernel by kernel in the timed region (default: replay the captured hipGraph)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -192,6 +196,13 @@ def main():
         imgs = W.synthetic_images(B, 480, seed=100 + rank)
         for i, nt in enumerate(nets):
             nt.set_images(imgs[i * sb:(i + 1) * sb])
+        raw = None
+        if args.voc_stream:
+            # raw uint8 images stay resident; F1 writes the whitened 480x480 planes into the net's input buffer
+            from xdet.runtime import to_device
+            shapes = [(375, 500), (500, 375), (333, 500), (500, 333)]
+            rng = np.random.default_rng(7 + rank)
+            raw = [(to_device(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)), h, w) for h, w in shapes]
         nc, topk = net.num_classes - 1, net.nms_topk
         gather = None
         if use_dist:
@@ -206,6 +217,12 @@ def main():
         def step(graph=None, only_first=False):
             g = use_graph if graph is None else graph
             run = nets[:1] if only_first else nets
+            if raw is not None:
+                for nt in run:
+                    for j in range(sb):
+                        buf, h, w = raw[j % len(raw)]
+                        check(lib().xdet_preprocess_eval(buf.ptr, h, w, nt._images.ptr + j * 3 * 480 * 480 * 4, 480,
+                                                         nt.stream.handle))
             if gather is None:
                 for nt in run:
                     nt.forward_device(sb, use_graph=g)
@@ -309,6 +326,8 @@ def main():
                        if args.workload == 'lighthead' else 'ResNet-50 v2 trunk only (BASELINE config 2), 480x480',
                        'batch_per_gpu': B, 'global_batch': B * world, 'image_size': 480,
                        'concurrent_sub_batches': ways,
+                       'input': ('uint8 VOC-shape stream + F1 pre-processing kernel in the step' if args.voc_stream
+                                 else 'whitened f32 [B,3,480,480] resident in HBM'),
                        'parallelism': 'image-sharded dp%d, all-gather of detections' % world,
                        'weights': 'seeded random init (no checkpoint exists)', 'graph_replay': bool(use_graph)},
             'device_ms_per_step': round(dev_ms / K, 3),
