@@ -27,8 +27,9 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
     dirty = force or not os.path.exists(LIB)
-    hdr_m = max(os.path.getmtime(os.path.join(CSRC, 'common.h')),
-                os.path.getmtime(os.path.join(os.path.dirname(os.path.dirname(HERE)), 'include', 'xdet.h')))
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    hdrs.append(os.path.join(os.path.dirname(os.path.dirname(HERE)), 'include', 'xdet.h'))
+    hdr_m = max(os.path.getmtime(h) for h in hdrs)
     procs = []
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)
