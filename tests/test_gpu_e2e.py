@@ -157,3 +157,36 @@ def test_other_baseline_configs(size, R, oracle, lh_weights):
     print('size %d R %d: oracle detections %d matched %d extra %d' % (size, R, total, matched, extra))
     assert total > 20
     assert matched >= total - max(2, total // 50) and extra <= max(2, total // 50)
+
+
+def test_net_misuse_is_reported_not_executed(lh_weights):
+    """C-ABI error behaviour of the net handle: argument / state errors come back as codes
+    (XdetError / InvalidArgumentError), nothing is launched, and the handle stays usable."""
+    import ctypes
+    import xdet
+    from xdet._lib import lib, check, LightHeadConfig, c_void_p
+    from xdet.model import LightHeadDetector
+    # forward before build
+    cfg = LightHeadConfig(image_size=480, max_batch=1, rpn_post_nms_top_n=300)
+    h = c_void_p()
+    check(lib().xdet_net_create(ctypes.byref(h), ctypes.byref(cfg)))
+    with pytest.raises(xdet.XdetError):
+        check(lib().xdet_net_forward(h, None, 1, None, None, None, None, 0, None))
+    with pytest.raises(xdet.XdetError):
+        check(lib().xdet_net_build(h))                      # no weights were set
+    check(lib().xdet_net_destroy(h))
+    # a weight with the wrong shape / an unknown variable name
+    bad = dict(lh_weights)
+    bad['block1_conv1/kernel'] = np.zeros((3, 3, 3, 31), np.float32)
+    with pytest.raises(xdet.XdetError):
+        LightHeadDetector(bad, image_size=480, max_batch=1, rpn_post_nms_top_n=300)
+    det = LightHeadDetector(lh_weights, image_size=480, max_batch=2, rpn_post_nms_top_n=300)
+    with pytest.raises(xdet.XdetError):
+        det.buffer('no_such_buffer')
+    with pytest.raises(xdet.XdetError):
+        det.forward_device(3)                               # batch > max_batch
+    with pytest.raises(xdet.XdetError):
+        det.forward_device(0)
+    from xdet import weights as W
+    got = det.forward(W.synthetic_images(1, 480, seed=1))   # still works afterwards
+    assert len(got) == 1 and len(got[0]) == 20
