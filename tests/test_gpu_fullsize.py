@@ -128,3 +128,26 @@ def test_pipelined_detector_equals_single(big, lh_weights):
         for i in (0, n // 2, n - 1):
             for c in range(20):
                 assert np.array_equal(got[i][c + 1][0], s[i, c]) and np.array_equal(got[i][c + 1][1], b[i, c])
+
+
+def test_more_images_against_the_oracle(oracle, lh_weights):
+    """a wider sample for the 1e-3 claim: 6 more images (another seed) through the default product
+    arithmetic (f16x3), every oracle detection matched by a distinct GPU detection and vice versa"""
+    from xdet import weights as W
+    from xdet.model import LightHeadDetector
+    from xdet.runtime import set_precision
+    imgs = W.synthetic_images(6, 480, seed=20260928)
+    set_precision('f16x3')
+    try:
+        det = LightHeadDetector(lh_weights, image_size=480, max_batch=6, rpn_post_nms_top_n=300)
+    finally:
+        set_precision('f32')
+    got = det.forward(imgs, use_graph=True)
+    ref = oracle.lighthead_forward(imgs, lh_weights, rpn_post_nms_top_n=300)
+    total = matched = extra = 0
+    for i in range(6):
+        t, m, e = match_detections(got[i], ref[i])
+        total, matched, extra = total + t, matched + m, extra + e
+    print('6 images, seed 20260928: oracle %d matched %d extra %d' % (total, matched, extra))
+    assert total > 1000
+    assert matched == total and extra == 0, (matched, total, extra)
