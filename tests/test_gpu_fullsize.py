@@ -151,3 +151,21 @@ def test_more_images_against_the_oracle(oracle, lh_weights):
     print('6 images, seed 20260928: oracle %d matched %d extra %d' % (total, matched, extra))
     assert total > 1000
     assert matched == total and extra == 0, (matched, total, extra)
+
+
+@pytest.mark.parametrize('nb', [3, 8, 17, 32])
+def test_batch_invariance_across_batch_sizes(big, lh_weights, nb):
+    """every batch size selects its own mix of tile shapes (128x64 ... 256x256) per layer: the first nb
+    images computed as a batch of nb equal the same images inside the batch of 64, bit for bit"""
+    from xdet.model import LightHeadDetector
+    from xdet.runtime import set_precision
+    _, _, imgs, s, b = big
+    set_precision('f16x3')
+    try:
+        det = LightHeadDetector(lh_weights, image_size=480, max_batch=nb, rpn_post_nms_top_n=300)
+    finally:
+        set_precision('f32')
+    det.set_images(imgs[:nb])
+    det.forward_device(nb, use_graph=True)
+    s2, b2 = det.detections(nb)
+    assert np.array_equal(s2, s[:nb]) and np.array_equal(b2, b[:nb])
