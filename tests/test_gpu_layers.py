@@ -112,6 +112,22 @@ def test_depthwise_matches_oracle(dil, relu_in, C, H, oracle):
     close(y, ref, 1e-6)
 
 
+@pytest.mark.parametrize('N,H,W,C', [(1, 119, 119, 128), (2, 60, 60, 256), (1, 237, 237, 64), (3, 30, 30, 1024),
+                                      (2, 33, 31, 96), (1, 5, 97, 32), (2, 9, 64, 160), (1, 4, 1, 64)])
+def test_depthwise_tile_edges(N, H, W, C, oracle):
+    """the tiled depthwise kernel at the network's own widths and at widths where the right halo column
+    (x = W) falls on a DMA-segment / tile boundary (W % 32 in {0, 1, 23, 29, 31}), ragged last row tile,
+    several tiles per workgroup"""
+    from xdet.ops import DepthwiseConv2D
+    from xdet.runtime import DeviceTensor
+    rng = np.random.default_rng(H * 1000 + W)
+    x = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    k = rng.standard_normal((3, 3, C, 1)).astype(np.float32)
+    ref = oracle.depthwise_conv2d(np.maximum(x, 0), k, 1)
+    y = DepthwiseConv2D(k, 1)(DeviceTensor.from_numpy(x), relu_in=True).numpy()
+    close(y, ref, 1e-6)
+
+
 @pytest.mark.parametrize('H,W', [(237, 237), (119, 119), (60, 60), (7, 10)])
 def test_maxpool_same_padding_asymmetry(H, W, oracle):
     """TF SAME puts the odd padding pixel at the bottom/right: 60->30 pads 0/1, 237->119 pads 1/1."""

@@ -157,6 +157,134 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Depthwise 3x3, dilation 1, as a software-pipelined tile kernel.  The per-row kernel above is
+// latency-bound (three dependent load phases per thread, every input pixel requested 4.5 times through
+// the TA/L1; PMC: waves 82 % in s_waitcnt at 54 % of the streaming rate).  Here a workgroup walks a
+// range of tiles (DT_R output rows x DT_X pixels x 32 channels); the (DT_R+2) x (DT_X+2) input patch
+// of the NEXT tile is pulled into LDS by global_load_lds_dwordx4 (no VGPRs, out-of-image pixels read a
+// zero page) while the current tile is computed out of LDS, so each input pixel crosses the TA once
+// per tile and the HBM latency hides behind compute instead of behind occupancy.  FMA order per output
+// is the per-row kernel's (ky, kx ascending): results are bit-identical.
+// ---------------------------------------------------------------------------------------
+constexpr int DT_R = 4, DT_X = 32, DT_P = 40, DT_ROWS = DT_R + 2;
+constexpr int DT_TILE_F = DT_ROWS * DT_P * 32;   // floats per LDS tile buffer (30 KB)
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void depthwise3x3_tile_kernel(const float* __restrict__ in,
+                                                                const float* __restrict__ w9c, float* __restrict__ out,
+                                                                unsigned short* __restrict__ hi,
+                                                                unsigned short* __restrict__ lo, int N, int H, int W,
+                                                                int ld, int relu_in, int ntiles, int TY, int TX,
+                                                                int tiles_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float dw_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = output row of the tile
+  const int c4 = lane & 7, strip = lane >> 3;
+  const int t_begin = blockIdx.x * tiles_per_block;
+  const int t_end = min(ntiles, t_begin + tiles_per_block);
+  if (t_begin >= t_end) return;
+
+  // Tile order: ty fastest (vertically adjacent tiles are consecutive: shared halo rows come from L2),
+  // then tx, image, channel chunk.  Coordinates are advanced incrementally (no divisions in the loop).
+  struct Coord { int ty, tx, n, chunk; };
+  auto advance = [&](Coord& c) {
+    if (++c.ty == TY) { c.ty = 0; if (++c.tx == TX) { c.tx = 0; if (++c.n == N) { c.n = 0; ++c.chunk; } } }
+  };
+  Coord cur;
+  {
+    int q = t_begin;
+    cur.ty = q % TY; q /= TY;
+    cur.tx = q % TX; q /= TX;
+    cur.n = q % N;
+    cur.chunk = q / N;
+  }
+  // DMA pieces of this wave: instruction i = wave + 4*jj moves 8 pixels x 128 B of patch row rr_j,
+  // segment seg_j.  Everything that does not depend on the tile is computed once: per lane the float
+  // offset of its 16 B relative to the tile's first pixel and its x relative to the tile's x0.  The
+  // loads are raw buffer loads over the whole input tensor: a lane that must read padding gets the
+  // offset 0xffffffff, which the buffer bounds check turns into zeros (no zero page, no branches).
+  constexpr int NSEG = DT_P / 8, NPIECE = DT_ROWS * NSEG, NJ = (NPIECE + 3) / 4;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((size_t)N * H * W * ld * 4), 0x00020000);
+  int lane_rel[NJ], x_rel[NJ], p_row[NJ], p_x[NJ], p_lds[NJ];
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int i = wave + 4 * jj;
+    const int rr = i / NSEG, seg = i - rr * NSEG;
+    p_row[jj] = i < NPIECE ? rr - 1 : -(1 << 20);            // wave-uniform: row relative to the tile, x of lane 0,
+    p_x[jj] = seg * 8 - 1;                                    // LDS float offset of the piece
+    p_lds[jj] = (rr * DT_P + seg * 8) * 32;
+    x_rel[jj] = seg * 8 + (lane >> 3) - 1;
+    lane_rel[jj] = (((rr - 1) * W + x_rel[jj]) * ld + (lane & 7) * 4) * 4;      // bytes
+  }
+  auto issue = [&](const Coord& c, int buf) {
+    const int y0 = c.ty * DT_R, x0 = c.tx * DT_X;
+    const int tile_base = ((((c.n * H + y0) * W + x0) * ld) + c.chunk * 32) * 4;   // bytes, < 2^31 (checked on the host)
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      if (p_row[jj] < -1 || x0 + p_x[jj] > W) continue;          // no such piece / a segment right of the halo column x = W
+      const bool rok = (unsigned)(y0 + p_row[jj]) < (unsigned)H;  // wave-uniform
+      const bool ok = rok && (unsigned)(x0 + x_rel[jj]) < (unsigned)W;
+      const unsigned voff = ok ? (unsigned)(tile_base + lane_rel[jj]) : 0xffffffffu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsrc, (__attribute__((address_space(3))) void*)(dw_lds + buf * DT_TILE_F + p_lds[jj]), 16, voff, 0, 0, 0);
+    }
+  };
+
+  float4 w[9];
+  int cur_chunk = -1;
+  issue(cur, 0);
+  for (int t = t_begin, it = 0; t < t_end; ++t, ++it) {
+    const int buf = it & 1;
+    const int c = cur.chunk * 32 + c4 * 4;
+    if (cur.chunk != cur_chunk) {            // (re)load the taps ahead of the barrier, whose vmcnt(0) retires them:
+#pragma unroll                               // issued after the DMA they would drag its completion into the FMAs
+      for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const float4*>(w9c + k * ld + c);
+      cur_chunk = cur.chunk;
+    }
+    __syncthreads();                         // tile t has landed; everyone is done with the other buffer
+    Coord nxt = cur;
+    advance(nxt);
+    const int y = cur.ty * DT_R + wave, x0 = cur.tx * DT_X, n = cur.n;
+    cur = nxt;
+    // The whole 3 x 6 neighbourhood goes to registers BEFORE the next tile's DMA is issued: the compiler
+    // orders every LDS read after an outstanding LDS-DMA write with a full vmcnt(0) wait, which would
+    // serialise the prefetch with this tile's reads.
+    const float* T = dw_lds + buf * DT_TILE_F + (strip * 4) * 32 + c4 * 4;
+    const float lo_clip = relu_in ? 0.f : -INFINITY;
+    float4 col[3][6];
+    if (y < H) {                              // wave-uniform
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          float4 v = *reinterpret_cast<const float4*>(T + ((wave + ky) * DT_P + k) * 32);
+          v.x = fmaxf(v.x, lo_clip); v.y = fmaxf(v.y, lo_clip); v.z = fmaxf(v.z, lo_clip); v.w = fmaxf(v.w, lo_clip);
+          col[ky][k] = v;
+        }
+    }
+    if (t + 1 < t_end) issue(nxt, buf ^ 1);
+    if (y >= H) continue;
+    float4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float4 ww = w[ky * 3 + kx];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 v = col[ky][k + kx];
+          acc[k].x = fmaf(v.x, ww.x, acc[k].x); acc[k].y = fmaf(v.y, ww.y, acc[k].y);
+          acc[k].z = fmaf(v.z, ww.z, acc[k].z); acc[k].w = fmaf(v.w, ww.w, acc[k].w);
+        }
+      }
+    dw_store_strip<SPLIT>(acc, out, hi, lo, ((int64_t)n * H + y) * W, x0 + strip * 4, W, ld, c);
+  }
+}
+
 static int launch_dw(const float* in, const float* w9c, float* out, unsigned short* hi, unsigned short* lo, int N,
                      int H, int W, int C, int ld, int dil, int relu_in, hipStream_t s) {
   XDET_REQUIRE(ld % 4 == 0 && ld >= C, "depthwise: channel stride must be a multiple of 4");
@@ -167,6 +295,19 @@ static int launch_dw(const float* in, const float* w9c, float* out, unsigned sho
   const int yblocks = (int)cdiv(items, 256);
   const dim3 grid((unsigned)(cdiv(nrows, 8) * 8 * yblocks));
   const bool split = hi != nullptr;
+  // dilation 1 (32 of the 34 depthwise layers): the LDS-pipelined tile kernel; its 32-bit buffer offsets need
+  // the tensor below 2 GiB, else (and for dilation 2) the per-row kernel
+  if (dil == 1 && ld % 32 == 0 && (int64_t)N * H * W * ld * 4 < ((int64_t)1 << 31)) {
+    const int TY = (int)cdiv(H, DT_R), TX = (int)cdiv(W, DT_X);
+    const int64_t nt = (int64_t)(ld / 32) * N * TY * TX;
+    const int blocks = (int)std::min<int64_t>(nt, 512);
+    const int tpb = (int)cdiv(nt, blocks);
+    const size_t lds = 2 * DT_TILE_F * sizeof(float);
+    if (split) hipLaunchKernelGGL((depthwise3x3_tile_kernel<true>), dim3((unsigned)cdiv(nt, tpb)), dim3(256), lds, s, in, w9c, out, hi, lo, N, H, W, ld, relu_in, (int)nt, TY, TX, tpb);
+    else hipLaunchKernelGGL((depthwise3x3_tile_kernel<false>), dim3((unsigned)cdiv(nt, tpb)), dim3(256), lds, s, in, w9c, out, hi, lo, N, H, W, ld, relu_in, (int)nt, TY, TX, tpb);
+    XDET_LAUNCH_CHECK();
+    return XDET_OK;
+  }
   if (dil == 1 && !split) hipLaunchKernelGGL((depthwise3x3_kernel<1, false>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows, yblocks);
   else if (dil == 1) hipLaunchKernelGGL((depthwise3x3_kernel<1, true>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows, yblocks);
   else if (!split) hipLaunchKernelGGL((depthwise3x3_kernel<2, false>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows, yblocks);
