@@ -158,25 +158,27 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------
-// Depthwise 3x3, dilation 1, as a software-pipelined tile kernel.  The per-row kernel above is
+// Depthwise 3x3 (dilation 1 or 2) as a software-pipelined tile kernel.  The per-row kernel above is
 // latency-bound (three dependent load phases per thread, every input pixel requested 4.5 times through
 // the TA/L1; PMC: waves 82 % in s_waitcnt at 54 % of the streaming rate).  Here a workgroup walks a
-// range of tiles (DT_R output rows x DT_X pixels x 32 channels); the (DT_R+2) x (DT_X+2) input patch
-// of the NEXT tile is pulled into LDS by global_load_lds_dwordx4 (no VGPRs, out-of-image pixels read a
-// zero page) while the current tile is computed out of LDS, so each input pixel crosses the TA once
+// range of tiles (DT_R output rows x DT_X pixels x 32 channels); the (DT_R+2*DIL) x (DT_X+2*DIL) input
+// patch of the NEXT tile is pulled into LDS by buffer_load_dwordx4 ... lds (no VGPRs; a lane that must read
+// padding is sent out of the buffer's bounds and gets zeros) while the current tile is computed out of LDS, so each input pixel crosses the TA once
 // per tile and the HBM latency hides behind compute instead of behind occupancy.  FMA order per output
 // is the per-row kernel's (ky, kx ascending): results are bit-identical.
 // ---------------------------------------------------------------------------------------
-constexpr int DT_R = 4, DT_X = 32, DT_P = 40, DT_ROWS = DT_R + 2;
-constexpr int DT_TILE_F = DT_ROWS * DT_P * 32;   // floats per LDS tile buffer (30 KB)
+constexpr int DT_R = 4, DT_X = 32, DT_P = 40;
 
-template <bool SPLIT>
+template <int DIL, bool SPLIT>
 __global__ __launch_bounds__(256) void depthwise3x3_tile_kernel(const float* __restrict__ in,
                                                                 const float* __restrict__ w9c, float* __restrict__ out,
                                                                 unsigned short* __restrict__ hi,
                                                                 unsigned short* __restrict__ lo, int N, int H, int W,
                                                                 int ld, int relu_in, int ntiles, int TY, int TX,
                                                                 int tiles_per_block) {
+  static_assert(DT_X + 2 * DIL <= DT_P, "patch row does not fit the LDS pitch");
+  constexpr int DT_ROWS = DT_R + 2 * DIL, DT_TILE_F = DT_ROWS * DT_P * 32;   // floats per LDS tile buffer
+  constexpr int NC = 4 + 2 * DIL;                                          // input pixels a strip of 4 needs
   extern __shared__ __attribute__((aligned(16))) float dw_lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = output row of the tile
@@ -212,18 +214,18 @@ __global__ __launch_bounds__(256) void depthwise3x3_tile_kernel(const float* __r
   for (int jj = 0; jj < NJ; ++jj) {
     const int i = wave + 4 * jj;
     const int rr = i / NSEG, seg = i - rr * NSEG;
-    p_row[jj] = i < NPIECE ? rr - 1 : -(1 << 20);            // wave-uniform: row relative to the tile, x of lane 0,
-    p_x[jj] = seg * 8 - 1;                                    // LDS float offset of the piece
+    p_row[jj] = i < NPIECE ? rr - DIL : -(1 << 20);            // wave-uniform: row relative to the tile, x of lane 0,
+    p_x[jj] = seg * 8 - DIL;                                    // LDS float offset of the piece
     p_lds[jj] = (rr * DT_P + seg * 8) * 32;
-    x_rel[jj] = seg * 8 + (lane >> 3) - 1;
-    lane_rel[jj] = (((rr - 1) * W + x_rel[jj]) * ld + (lane & 7) * 4) * 4;      // bytes
+    x_rel[jj] = seg * 8 + (lane >> 3) - DIL;
+    lane_rel[jj] = (((rr - DIL) * W + x_rel[jj]) * ld + (lane & 7) * 4) * 4;    // bytes
   }
   auto issue = [&](const Coord& c, int buf) {
     const int y0 = c.ty * DT_R, x0 = c.tx * DT_X;
     const int tile_base = ((((c.n * H + y0) * W + x0) * ld) + c.chunk * 32) * 4;   // bytes, < 2^31 (checked on the host)
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
-      if (p_row[jj] < -1 || x0 + p_x[jj] > W) continue;          // no such piece / a segment right of the halo column x = W
+      if (p_row[jj] < -DIL || x0 + p_x[jj] >= W + DIL) continue;  // no such piece / a segment right of the halo columns
       const bool rok = (unsigned)(y0 + p_row[jj]) < (unsigned)H;  // wave-uniform
       const bool ok = rok && (unsigned)(x0 + x_rel[jj]) < (unsigned)W;
       const unsigned voff = ok ? (unsigned)(tile_base + lane_rel[jj]) : 0xffffffffu;
@@ -253,13 +255,13 @@ __global__ __launch_bounds__(256) void depthwise3x3_tile_kernel(const float* __r
     // serialise the prefetch with this tile's reads.
     const float* T = dw_lds + buf * DT_TILE_F + (strip * 4) * 32 + c4 * 4;
     const float lo_clip = relu_in ? 0.f : -INFINITY;
-    float4 col[3][6];
+    float4 col[3][NC];
     if (y < H) {                              // wave-uniform
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          float4 v = *reinterpret_cast<const float4*>(T + ((wave + ky) * DT_P + k) * 32);
+        for (int k = 0; k < NC; ++k) {
+          float4 v = *reinterpret_cast<const float4*>(T + ((wave + ky * DIL) * DT_P + k) * 32);
           v.x = fmaxf(v.x, lo_clip); v.y = fmaxf(v.y, lo_clip); v.z = fmaxf(v.z, lo_clip); v.w = fmaxf(v.w, lo_clip);
           col[ky][k] = v;
         }
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_tile_kernel(const float* __r
         const float4 ww = w[ky * 3 + kx];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float4 v = col[ky][k + kx];
+          const float4 v = col[ky][k + kx * DIL];
           acc[k].x = fmaf(v.x, ww.x, acc[k].x); acc[k].y = fmaf(v.y, ww.y, acc[k].y);
           acc[k].z = fmaf(v.z, ww.z, acc[k].z); acc[k].w = fmaf(v.w, ww.w, acc[k].w);
         }
@@ -295,16 +297,27 @@ static int launch_dw(const float* in, const float* w9c, float* out, unsigned sho
   const int yblocks = (int)cdiv(items, 256);
   const dim3 grid((unsigned)(cdiv(nrows, 8) * 8 * yblocks));
   const bool split = hi != nullptr;
-  // dilation 1 (32 of the 34 depthwise layers): the LDS-pipelined tile kernel; its 32-bit buffer offsets need
-  // the tensor below 2 GiB, else (and for dilation 2) the per-row kernel
-  if (dil == 1 && ld % 32 == 0 && (int64_t)N * H * W * ld * 4 < ((int64_t)1 << 31)) {
+  // the LDS-pipelined tile kernel; its 32-bit buffer offsets need the tensor below 2 GiB, else the per-row kernel
+  if (ld % 32 == 0 && (int64_t)N * H * W * ld * 4 < ((int64_t)1 << 31)) {
     const int TY = (int)cdiv(H, DT_R), TX = (int)cdiv(W, DT_X);
     const int64_t nt = (int64_t)(ld / 32) * N * TY * TX;
-    const int blocks = (int)std::min<int64_t>(nt, 512);
+    const size_t lds = (size_t)2 * (DT_R + 2 * dil) * DT_P * 32 * sizeof(float);
+    const int blocks = (int)std::min<int64_t>(nt, lds > 80 * 1024 ? 256 : 512);   // workgroups per CU that fit in LDS
     const int tpb = (int)cdiv(nt, blocks);
-    const size_t lds = 2 * DT_TILE_F * sizeof(float);
-    if (split) hipLaunchKernelGGL((depthwise3x3_tile_kernel<true>), dim3((unsigned)cdiv(nt, tpb)), dim3(256), lds, s, in, w9c, out, hi, lo, N, H, W, ld, relu_in, (int)nt, TY, TX, tpb);
-    else hipLaunchKernelGGL((depthwise3x3_tile_kernel<false>), dim3((unsigned)cdiv(nt, tpb)), dim3(256), lds, s, in, w9c, out, hi, lo, N, H, W, ld, relu_in, (int)nt, TY, TX, tpb);
+    const dim3 g((unsigned)cdiv(nt, tpb));
+    if (dil == 1) {
+      if (split) hipLaunchKernelGGL((depthwise3x3_tile_kernel<1, true>), g, dim3(256), lds, s, in, w9c, out, hi, lo, N, H, W, ld, relu_in, (int)nt, TY, TX, tpb);
+      else hipLaunchKernelGGL((depthwise3x3_tile_kernel<1, false>), g, dim3(256), lds, s, in, w9c, out, hi, lo, N, H, W, ld, relu_in, (int)nt, TY, TX, tpb);
+    } else {
+      static bool attr_set = false;
+      if (!attr_set) {
+        XDET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(depthwise3x3_tile_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        XDET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(depthwise3x3_tile_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+      }
+      if (split) hipLaunchKernelGGL((depthwise3x3_tile_kernel<2, true>), g, dim3(256), lds, s, in, w9c, out, hi, lo, N, H, W, ld, relu_in, (int)nt, TY, TX, tpb);
+      else hipLaunchKernelGGL((depthwise3x3_tile_kernel<2, false>), g, dim3(256), lds, s, in, w9c, out, hi, lo, N, H, W, ld, relu_in, (int)nt, TY, TX, tpb);
+    }
     XDET_LAUNCH_CHECK();
     return XDET_OK;
   }
