@@ -20,6 +20,7 @@
 //                staged in LDS, diagonal block resolved by one wavefront); stops at post_n
 //   7. gather  : rois[j] = kept[j mod n_keep]  (tile + identity "shuffle" of :196-213)
 #include "common.h"
+#include <cstdlib>
 
 namespace xdet {
 
@@ -369,6 +370,80 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const u64* __restrict__ m
   if (tid == 0) counts[n * 4 + 2] = s_keep;
 }
 
+// ---------------------------------------------------------------------------------------
+// Greedy NMS against the KEPT list (one workgroup of 8 waves per image).  tf.image.non_max_suppression
+// only ever compares a candidate with boxes that were kept before it, and stops at max_output_size: with
+// R = 300 kept boxes that is <= 64 x 300 IoUs per 64-candidate chunk and a few dozen chunks, instead of
+// the full upper-triangular bit matrix (5000^2 / 2 IoUs per image, 200 MB of mask for 64 images) the
+// mask + scan pair above computes.  Per chunk of 64 candidates (score order):
+//   1. every wave tests the chunk against a strided eighth of the kept boxes (kept box broadcast from
+//      LDS, candidate b in lane b), one ballot per wave -> bits of candidates already suppressed;
+//   2. the 64 x 64 intra-chunk matrix, eight column-strided parts OR-ed through LDS;
+//   3. wave 0 resolves the chunk serially (wave-uniform shuffles) exactly like nms_scan_kernel and
+//      appends the survivors to the kept list.
+// Same comparisons (iou_gt_fast(earlier, later, thr), strict >) and same visiting order as the matrix
+// version: identical keep sets.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void nms_greedy_kernel(const float* __restrict__ sboxes, int* __restrict__ counts,
+                                                         int pre_n, int post_n, float thr, int* __restrict__ kept) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char nmsg_smem[];
+  float4* kbox = reinterpret_cast<float4*>(nmsg_smem);          // [post_n] boxes kept so far
+  __shared__ float4 cb[64];
+  __shared__ u64 part_sup[8];
+  __shared__ u64 part_diag[8][64];
+  __shared__ int s_keep;
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_cand = counts[n * 4 + 1];
+  const float4* B = reinterpret_cast<const float4*>(sboxes) + (int64_t)n * pre_n;
+  int* K = kept + (int64_t)n * post_n;
+  if (tid == 0) s_keep = 0;
+  __syncthreads();
+  const int n_chunk = (n_cand + 63) / 64;
+  for (int c = 0; c < n_chunk; ++c) {
+    const int n_keep = s_keep;                               // uniform: only changes between barriers
+    if (n_keep >= post_n) break;
+    const int rows = min(64, n_cand - c * 64);
+    if (tid < 64) cb[tid] = tid < rows ? B[c * 64 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const float4 me = cb[lane];
+    // 1. against the kept list
+    bool hit = false;
+    if (lane < rows)
+      for (int k = wave; k < n_keep; k += 8)
+        if (iou_gt_fast(kbox[k], me, thr)) { hit = true; break; }
+    const u64 hb = __ballot(hit);
+    if (lane == 0) part_sup[wave] = hb;
+    // 2. intra-chunk: does candidate `lane` suppress a later candidate j of the chunk?
+    u64 bits = 0ull;
+    if (lane < rows)
+      for (int j = lane + 1 + wave; j < rows; j += 8)
+        if (iou_gt_fast(me, cb[j], thr)) bits |= 1ull << j;
+    part_diag[wave][lane] = bits;
+    __syncthreads();
+    // 3. serial resolve of the chunk
+    if (wave == 0) {
+      u64 cur = 0ull, diag = 0ull;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { cur |= part_sup[w]; diag |= part_diag[w][lane]; }
+      u64 keepmask = 0ull;
+      int kc = n_keep;
+      for (int b = 0; b < rows && kc < post_n; ++b) {
+        const u64 d = shfl_u64(diag, b);
+        if (!((cur >> b) & 1ull)) { keepmask |= 1ull << b; cur |= d; ++kc; }
+      }
+      if ((keepmask >> lane) & 1ull) {
+        const int slot = n_keep + __popcll(keepmask & ((1ull << lane) - 1ull));
+        K[slot] = c * 64 + lane;
+        kbox[slot] = me;
+      }
+      if (lane == 0) s_keep = kc;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) counts[n * 4 + 2] = s_keep;
+}
+
 __global__ void prop_gather_kernel(const float* __restrict__ sboxes, const int* __restrict__ kept,
                                    const int* __restrict__ counts, int pre_n, int post_n, float* __restrict__ rois) {
   const int n = blockIdx.y;
@@ -406,18 +481,32 @@ int launch_get_proposals(const float* objectness, const float* boxes, int N, int
   hipLaunchKernelGGL(prop_scatter_kernel, dim3(gb, N), dim3(256), 0, s, ws.cand, ws.ranks, ws.cboxes, n_anchor, pre_n,
                      ws.counts, ws.sboxes, ws.sscores);
   XDET_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)cdiv(w64, 4), w64, N), dim3(256), 0, s, ws.sboxes, ws.counts, pre_n,
-                     w64, nms_thr, ws.mask);
-  XDET_LAUNCH_CHECK();
-  const size_t lds = (size_t)(64 * w64 + w64) * 8;
-  static bool attr_set = false;
-  if (!attr_set) {
-    XDET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (64 * NMS_MAXW + NMS_MAXW) * 8));
-    attr_set = true;
+  static const char* nms_env = getenv("XDET_NMS_MATRIX");
+  if (nms_env && nms_env[0] == '1') {
+    hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)cdiv(w64, 4), w64, N), dim3(256), 0, s, ws.sboxes, ws.counts, pre_n,
+                       w64, nms_thr, ws.mask);
+    XDET_LAUNCH_CHECK();
+    const size_t lds = (size_t)(64 * w64 + w64) * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+      XDET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (64 * NMS_MAXW + NMS_MAXW) * 8));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(256), lds, s, ws.mask, ws.counts, pre_n, w64, post_n, ws.kept);
+    XDET_LAUNCH_CHECK();
+  } else {
+    XDET_REQUIRE((size_t)post_n * 16 <= 96 * 1024, "get_proposals: rpn_post_nms_top_n too large (max 6144)");
+    static bool attr_g = false;
+    if (!attr_g) {
+      XDET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_greedy_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      attr_g = true;
+    }
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(N), dim3(512), (size_t)post_n * 16, s, ws.sboxes, ws.counts, pre_n, post_n,
+                       nms_thr, ws.kept);
+    XDET_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(256), lds, s, ws.mask, ws.counts, pre_n, w64, post_n, ws.kept);
-  XDET_LAUNCH_CHECK();
   hipLaunchKernelGGL(prop_gather_kernel, dim3((unsigned)cdiv(post_n, 256), N), dim3(256), 0, s, ws.sboxes, ws.kept,
                      ws.counts, pre_n, post_n, rois);
   XDET_LAUNCH_CHECK();
