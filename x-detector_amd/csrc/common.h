@@ -110,7 +110,6 @@ struct ProposalWorkspace {
   unsigned long long* cand;   // [N][n_anchor] keys that can still reach the top pre_n
   int* hist;                  // [N][16384] histogram of the keys' top 16 bits
   int* tbin;                  // [N] threshold bin
-  unsigned long long* mask;   // [N][pre_n][W64] IoU>thr bit rows (upper triangle)
   int* kept;                  // [N][post_n]
 };
 size_t proposal_workspace_bytes(int N, int n_anchor, int pre_n, int post_n);

@@ -15,9 +15,9 @@
 //   4. rank    : rank_i = #{j : key_j > key_i} among the candidates (all keys distinct -> a
 //                permutation; equals tf.nn.top_k order: descending score, ties -> lower index)
 //   5. scatter : sorted_boxes[rank] = box  for rank < pre_n
-//   6. mask    : bit (i,j) = IoU(i,j) > thr for j > i, 64x64 tiles of the upper triangle, chip-wide
-//      scan    : one workgroup per image walks the candidates in score order 64 at a time (bit rows
-//                staged in LDS, diagonal block resolved by one wavefront); stops at post_n
+//   6. nms     : one workgroup per image walks the candidates in score order 64 at a time; a chunk is
+//                tested against the boxes kept so far (LDS) and against itself, resolved by one
+//                wavefront; stops at post_n
 //   7. gather  : rois[j] = kept[j mod n_keep]  (tile + identity "shuffle" of :196-213)
 #include "common.h"
 #include <cstdlib>
@@ -40,7 +40,6 @@ size_t proposal_workspace_bytes(int N, int n_anchor, int pre_n, int post_n) {
   add((size_t)N * n_anchor * 8);
   add((size_t)N * HIST_BINS * 4);
   add((size_t)N * 4);
-  add((size_t)N * pre_n * cdiv(pre_n, 64) * 8);
   add((size_t)N * post_n * 4);
   return b;
 }
@@ -57,7 +56,6 @@ void proposal_workspace_carve(void* base, int N, int n_anchor, int pre_n, int po
   ws->cand = reinterpret_cast<u64*>(take((size_t)N * n_anchor * 8));
   ws->hist = reinterpret_cast<int*>(take((size_t)N * HIST_BINS * 4));
   ws->tbin = reinterpret_cast<int*>(take((size_t)N * 4));
-  ws->mask = reinterpret_cast<u64*>(take((size_t)N * pre_n * cdiv(pre_n, 64) * 8));
   ws->kept = reinterpret_cast<int*>(take((size_t)N * post_n * 4));
 }
 
@@ -259,8 +257,6 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
   return ((u64)hi << 32) | lo;
 }
 
-constexpr int NMS_MAXW = 256;        // 64-bit words per bit row: pre_n <= 16384
-
 // IoU(a,b) > thr with the reference's rounding, but without a division on the fast path: the
 // correctly rounded quotient can only disagree with a product test inside a 1e-5 relative band
 // around the threshold; only there is the division actually evaluated.
@@ -281,108 +277,18 @@ __device__ __forceinline__ bool iou_gt_fast(const float4 a, const float4 b, floa
   return inter / uni > thr;
 }
 
-// bit (i,j) = IoU(i,j) > thr for j > i, 64x64 tiles, upper triangle only (the scan never reads
-// words left of the diagonal).  grid (ceil(w64/4), w64, N): wave w of a workgroup = column block
-// blockIdx.x*4 + w, lane = row of row block blockIdx.y.
-__global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ sboxes, const int* __restrict__ counts,
-                                                       int pre_n, int w64, float thr, u64* __restrict__ mask) {
-  __shared__ float4 cbox[4][64];
-  const int n = blockIdx.z;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int rb = blockIdx.y, cb = blockIdx.x * 4 + wv;
-  const int n_cand = counts[n * 4 + 1];
-  if (rb * 64 >= n_cand) return;                 // rows never visited by the scan (workgroup-uniform)
-  const bool active = cb >= rb && cb < w64 && cb * 64 < n_cand;
-  const float4* B = reinterpret_cast<const float4*>(sboxes) + (int64_t)n * pre_n;
-  if (active) {
-    const int col = cb * 64 + lane;
-    cbox[wv][lane] = col < n_cand ? B[col] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  __syncthreads();
-  if (!active) return;
-  const int row = rb * 64 + lane;
-  u64 bits = 0ull;
-  if (row < n_cand) {
-    const float4 me = B[row];
-    const int jstart = (cb == rb) ? lane + 1 : 0;
-    const int jend = min(64, n_cand - cb * 64);
-    for (int j = jstart; j < jend; ++j)
-      if (iou_gt_fast(me, cbox[wv][j], thr)) bits |= 1ull << j;
-  }
-  mask[((int64_t)n * pre_n + row) * w64 + cb] = bits;
-}
-
-// Greedy scan in score order, one 256-thread workgroup per image, 64 candidates per round: the
-// round's bit rows (words right of the diagonal) are staged in LDS by all threads, wave 0 resolves
-// the 64x64 diagonal block serially (wave-uniform), records the kept candidates and ORs their rows
-// into the removed set.  Stops as soon as post_n candidates are kept.
-__global__ __launch_bounds__(256) void nms_scan_kernel(const u64* __restrict__ mask, int* __restrict__ counts,
-                                                       int pre_n, int w64, int post_n, int* __restrict__ kept) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
-  u64* Mr = reinterpret_cast<u64*>(nms_smem);             // [64][w64] staged rows of the round
-  u64* removed = Mr + 64 * w64;                          // [w64]
-  __shared__ int s_keep;
-  const int n = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n_cand = counts[n * 4 + 1];
-  const u64* M = mask + (int64_t)n * pre_n * w64;
-  int* K = kept + (int64_t)n * post_n;
-  for (int w = tid; w < w64; w += 256) removed[w] = 0ull;
-  if (tid == 0) s_keep = 0;
-  __syncthreads();
-  const int n_chunk = (n_cand + 63) / 64;
-  for (int c = 0; c < n_chunk; ++c) {
-    if (s_keep >= post_n) break;                         // uniform: s_keep only changes between barriers
-    const int rows = min(64, n_cand - c * 64), nw = n_chunk - c;
-    for (int e = tid; e < rows * nw; e += 256) {
-      const int r = e / nw, k = e - r * nw;
-      Mr[r * w64 + c + k] = M[(int64_t)(c * 64 + r) * w64 + c + k];
-    }
-    __syncthreads();
-    if (wave == 0) {
-      const int i = c * 64 + lane;
-      const u64 diag = lane < rows ? Mr[lane * w64 + c] : 0ull;
-      u64 cur = removed[c];
-      u64 keepmask = 0ull;
-      const int n_keep = s_keep;
-      int kc = n_keep;
-      for (int b = 0; b < rows && kc < post_n; ++b) {
-        const u64 d = shfl_u64(diag, b);
-        if (!((cur >> b) & 1ull)) { keepmask |= 1ull << b; cur |= d; ++kc; }
-      }
-      if ((keepmask >> lane) & 1ull) K[n_keep + __popcll(keepmask & ((1ull << lane) - 1ull))] = i;
-      if (kc < post_n) {
-        for (int w = c + 1 + lane; w < n_chunk; w += 64) {
-          u64 acc = removed[w];
-          u64 km = keepmask;
-          while (km) {
-            const int b = __ffsll((long long)km) - 1;
-            km &= km - 1ull;
-            acc |= Mr[b * w64 + w];
-          }
-          removed[w] = acc;
-        }
-      }
-      if (lane == 0) s_keep = kc;
-    }
-    __syncthreads();
-  }
-  if (tid == 0) counts[n * 4 + 2] = s_keep;
-}
-
 // ---------------------------------------------------------------------------------------
 // Greedy NMS against the KEPT list (one workgroup of 8 waves per image).  tf.image.non_max_suppression
 // only ever compares a candidate with boxes that were kept before it, and stops at max_output_size: with
-// R = 300 kept boxes that is <= 64 x 300 IoUs per 64-candidate chunk and a few dozen chunks, instead of
-// the full upper-triangular bit matrix (5000^2 / 2 IoUs per image, 200 MB of mask for 64 images) the
-// mask + scan pair above computes.  Per chunk of 64 candidates (score order):
+// R = 300 kept boxes that is <= 64 x 300 IoUs per 64-candidate chunk and a few dozen chunks.  (The first
+// version built the full upper-triangular IoU bit matrix chip-wide -- 5000^2 / 2 IoUs per image, 200 MB of
+// mask for 64 images -- and scanned it: ~25x the CU time.)  Per chunk of 64 candidates (score order):
 //   1. every wave tests the chunk against a strided eighth of the kept boxes (kept box broadcast from
 //      LDS, candidate b in lane b), one ballot per wave -> bits of candidates already suppressed;
 //   2. the 64 x 64 intra-chunk matrix, eight column-strided parts OR-ed through LDS;
-//   3. wave 0 resolves the chunk serially (wave-uniform shuffles) exactly like nms_scan_kernel and
-//      appends the survivors to the kept list.
-// Same comparisons (iou_gt_fast(earlier, later, thr), strict >) and same visiting order as the matrix
-// version: identical keep sets.
+//   3. wave 0 resolves the chunk serially (wave-uniform shuffles) and appends the survivors to the
+//      kept list.
+// Comparisons are iou_gt_fast(earlier, later, thr), strict >, visited in score order.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void nms_greedy_kernel(const float* __restrict__ sboxes, int* __restrict__ counts,
                                                          int pre_n, int post_n, float thr, int* __restrict__ kept) {
@@ -461,8 +367,6 @@ __global__ void prop_gather_kernel(const float* __restrict__ sboxes, const int* 
 int launch_get_proposals(const float* objectness, const float* boxes, int N, int n_anchor, int pre_n, int post_n,
                          float nms_thr, float min_size, const ProposalWorkspace& ws, float* rois, hipStream_t s) {
   XDET_REQUIRE(N > 0 && n_anchor > 0 && pre_n > 0 && post_n > 0, "get_proposals: sizes must be positive");
-  const int w64 = (int)cdiv(pre_n, 64);
-  XDET_REQUIRE(w64 <= NMS_MAXW, "get_proposals: rpn_pre_nms_top_n too large (max 16384)");
   XDET_HIP(hipMemsetAsync(ws.hist, 0, (size_t)N * HIST_BINS * 4, s));
   XDET_HIP(hipMemsetAsync(ws.sboxes, 0, (size_t)N * pre_n * 16, s));
   XDET_HIP(hipMemsetAsync(ws.sscores, 0, (size_t)N * pre_n * 4, s));
@@ -481,21 +385,7 @@ int launch_get_proposals(const float* objectness, const float* boxes, int N, int
   hipLaunchKernelGGL(prop_scatter_kernel, dim3(gb, N), dim3(256), 0, s, ws.cand, ws.ranks, ws.cboxes, n_anchor, pre_n,
                      ws.counts, ws.sboxes, ws.sscores);
   XDET_LAUNCH_CHECK();
-  static const char* nms_env = getenv("XDET_NMS_MATRIX");
-  if (nms_env && nms_env[0] == '1') {
-    hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)cdiv(w64, 4), w64, N), dim3(256), 0, s, ws.sboxes, ws.counts, pre_n,
-                       w64, nms_thr, ws.mask);
-    XDET_LAUNCH_CHECK();
-    const size_t lds = (size_t)(64 * w64 + w64) * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-      XDET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (64 * NMS_MAXW + NMS_MAXW) * 8));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(256), lds, s, ws.mask, ws.counts, pre_n, w64, post_n, ws.kept);
-    XDET_LAUNCH_CHECK();
-  } else {
+  {
     XDET_REQUIRE((size_t)post_n * 16 <= 96 * 1024, "get_proposals: rpn_post_nms_top_n too large (max 6144)");
     static bool attr_g = false;
     if (!attr_g) {
