@@ -54,6 +54,21 @@ def test_get_proposals_exact(n, cnt, pre, post, thr, oracle):
     assert np.array_equal(rois, ref)
 
 
+@pytest.mark.parametrize('tied', [19800, 9000])
+def test_get_proposals_long_candidate_list(tied, oracle):
+    """more than 8192 keys share the threshold bin (here: identical scores, order = anchor index): the LDS
+    sort steps aside and the counting rank kernel takes over; result still exact"""
+    from xdet import ops
+    rng = np.random.default_rng(tied)
+    scores, boxes = _boxes_scores(rng, 2, 19800)
+    scores[:, :tied] = 0.625
+    rois, counts = ops.get_proposals(scores, boxes, None, 5000, 300, 0.7, 16. / 480, False, 'channels_first',
+                                     return_counts=True)
+    ref = oracle.get_proposals(scores, boxes, 5000, 300, 0.7, 16. / 480)
+    assert counts[:, 3].min() > 8192 or tied < 19800
+    assert np.array_equal(rois, ref)
+
+
 def test_get_proposals_few_and_none(oracle):
     """fewer survivors than post_n -> tiled upsample; none -> the [.2,.2,.8,.8] fallback (:196-213)."""
     from xdet import ops
