@@ -7,19 +7,31 @@ One "step" = one pass of the whole hot path (backbone + RPN + proposals + PsRoiA
 head + per-class NMS) over one batch of B synthetic 480x480 images per GPU, inputs already
 resident in HBM.  The batch runs as --ways concurrent sub-batches (default 2 x 64), each a net
 instance replaying its hipGraph on its own stream, so the partial last round of workgroups of one
-launch is filled by the other stream's kernels.  N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N`
-(one rank per GPU); images are sharded by rank (independent units, weak scaling) and the only
-exchange is one all-gather of the fixed-size padded detections per step over RCCL
-(torch.distributed backend "nccl").  Rank 0 prints ONE JSON line.
+launch is filled by the other stream's kernels.
 
-Per-step timing: barrier + device sync on both sides of exactly K steps, MAX over ranks.
-roofline: the conv/dense MFMA kernel, bracketed by HIP events on its launch stream inside
-the timed region (xdet_profile_*); achieved = algorithmic dense FLOPs / summed kernel time.
-cpu_baseline: the NumPy/OpenBLAS oracle (a port of the reference graph, not the TF1 runtime,
-which cannot run here) on a bounded sample, rank 0 at N=1 only.
+Multi-GPU (--gpus N > 1): one process per GPU.  Started plainly, this script spawns the N ranks
+itself (xdet.launch); started by `python -m torch.distributed.run --nproc-per-node N ...` it IS one
+rank (RANK / LOCAL_RANK / WORLD_SIZE from the environment) -- either way no PyTorch is imported:
+images are sharded by rank (independent units, weak scaling) and the only exchange is one
+ncclAllGather of the fixed-size padded detections per step, issued through the C-ABI
+(xdet_comm_*) on the communicator's own stream so that it overlaps the next step's forward.
+Rank 0 prints ONE JSON line.
+
+Timing: barrier + device sync on both sides of exactly K steps, MAX over ranks; the median of the
+per-step device times (event per step on stream 0) is reported next to the mean.
+roofline: the conv/dense MFMA kernels, bracketed by HIP event pairs on their launch stream in an
+eager repeat of K steps right after the graph-replayed
+timed region (events cannot be recorded inside a replayed graph); achieved = algorithmic dense
+FLOPs / summed kernel time.  That leg runs ONE sub-batch stream alone ("one_stream"): with two
+concurrent streams a launch's duration would include the other stream's kernels.  frac_whole_step
+is the un-instrumented view: all algorithmic FLOPs of a step over the timed wall clock.
+cpu_baseline: the CPU restatement of the reference graph under oracle/ (a port, not the TF1
+runtime, which cannot run here) on a bounded sample, rank 0 at N=1 only.
 """
 import argparse
 import ctypes
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -56,11 +68,26 @@ def parse():
                          'image (whiten + TF-legacy bilinear warp to 480x480) in front of the forward')
     ap.add_argument('--eager', action='store_true',
                     help='launch kernel by kernel in the timed region (default: replay the captured hipGraph)')
+    ap.add_argument('--comm', action='store_true',
+                    help='create the RCCL communicator and all-gather the detections every step even at one rank '
+                         '(always on for N > 1 and under torch.distributed.run)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-images', type=int, default=12, help='images of the bounded CPU-oracle sample (~1.4 s each)')
+    ap.add_argument('--cpu-images', type=int, default=12, help='images of the bounded CPU-oracle sample')
     ap.add_argument('--ops', action='store_true', help='also print the per-op table to stderr')
     ap.add_argument('--no-parity', action='store_true', help='skip the live f16x3-vs-f32 GPU cross-check')
+    ap.add_argument('--no-roofline', action='store_true', help='skip the instrumented eager repeat')
     return ap.parse_args()
+
+
+def kernel_source_hash():
+    """identifies the kernel sources a profile was taken with (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'x-detector_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def read_profile(handle, kind):
@@ -79,19 +106,31 @@ def read_profile(handle, kind):
     return rows
 
 
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(args, weights):
     """The oracle timed on this box's host cores (kind "port")."""
     from oracle import lighthead_oracle as O
     from xdet import weights as W
     n = args.cpu_images
     if args.workload == 'lighthead':
+        fwd = getattr(O, 'lighthead_forward_fast', None) or O.lighthead_forward
+        how = getattr(O, 'FAST_PATH_DESCRIPTION', 'NumPy fp32 + OpenBLAS')
         imgs = W.synthetic_images(1, 480, seed=11)
-        O.lighthead_forward(imgs, weights, rpn_post_nms_top_n=args.proposals)      # warm-up (page-in, BLAS threads)
+        fwd(imgs, weights, rpn_post_nms_top_n=args.proposals)      # warm-up (page-in, BLAS threads)
         t = time.time()
         for i in range(n):
-            O.lighthead_forward(W.synthetic_images(1, 480, seed=20 + i), weights, rpn_post_nms_top_n=args.proposals)
+            fwd(W.synthetic_images(1, 480, seed=20 + i), weights, rpn_post_nms_top_n=args.proposals)
         dt = time.time() - t
-        what = '%d x one 480x480 image through the full forward (R=%d), NumPy fp32 + OpenBLAS' % (n, args.proposals)
+        what = '%d x one 480x480 image through the full forward (R=%d), %s' % (n, args.proposals, how)
     else:
         x = np.transpose(W.synthetic_images(1, 480, seed=11), (0, 2, 3, 1))
         O.resnet50_trunk(x, weights)
@@ -105,30 +144,37 @@ def cpu_baseline(args, weights):
         cores = max([d.get('num_threads', 1) for d in threadpool_info()] or [os.cpu_count()])
     except Exception:
         cores = os.cpu_count()
-    return {'value': round(n / dt, 3), 'unit': 'images/sec', 'cores': int(cores), 'kind': 'port', 'sample': what}
+    return {'value': round(n / dt, 3), 'unit': 'images/sec', 'cores': int(cores), 'kind': 'port', 'sample': what,
+            'host': {'nproc': os.cpu_count(), 'cpu': cpu_model()}}
 
 
-def traffic_from_profiles(precision):
-    """HBM bytes per conv launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    (profiles/<tag>_summary.json, written by tools/summarize_profile.py with the gfx950 x2 read
-    correction); PMC collection cannot run inside the bench itself."""
-    import glob
+def counters_from_profiles(precision, src_hash):
+    """HBM bytes per conv launch and counter-based MFMA utilisation from the committed rocprofv3 --pmc
+    passes (profiles/<tag>_summary.json, tools/summarize_profile.py; PMC collection cannot run inside the
+    bench itself).  A summary is quoted only if it was taken with THESE kernel sources (source_hash)."""
     if precision != 'f16x3':      # the committed PMC passes are of the default configuration only
-        return None, None
+        return None
     want = 'conv_dma_f16'
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_summary.json')), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
             continue
+        if d.get('source_hash') != src_hash:
+            continue
         tot = cnt = 0
+        busy = act = 0.0
         for k, e in d.get('kernels', {}).items():
             if want in k and 'hbm_bytes_per_launch' in e:
                 tot += e['hbm_bytes_per_launch'] * e['calls']
                 cnt += e['calls']
+            if want in k and 'mfma_busy_cycles' in e and 'gui_active_cycles' in e:
+                busy += e['mfma_busy_cycles']
+                act += e['gui_active_cycles']
         if cnt:
-            return int(tot / cnt), os.path.relpath(path, ROOT)
-    return None, None
+            return {'traffic': int(tot / cnt), 'mfma_busy_frac': round(busy / act, 4) if act else None,
+                    'file': os.path.relpath(path, ROOT)}
+    return None
 
 
 def live_parity(weights, proposals):
@@ -157,33 +203,36 @@ def live_parity(weights, proposals):
 
 def main():
     args = parse()
+    if 'RANK' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU)
+        from xdet.launch import launch_ranks
+        sys.exit(launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    dist = None
-    torch = None
-    # under torch.distributed.run (RANK set) the collective path is exercised even for one rank
-    use_dist = world > 1 or ('RANK' in os.environ and os.environ.get('XDET_BENCH_NO_DIST') != '1')
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch N ranks with --gpus N)' % (args.gpus, world))
 
     from xdet import weights as W
     from xdet import dist as xdist
     from xdet._lib import lib, check
-    from xdet.runtime import Event
+    from xdet.runtime import Event, DeviceBuffer, set_precision
+    ndev = ctypes.c_int()
+    check(lib().xdet_device_count(ctypes.byref(ndev)))
+    if local_rank >= ndev.value:
+        raise SystemExit('bench.py: rank %d wants GPU %d but only %d visible' % (rank, local_rank, ndev.value))
     check(lib().xdet_set_device(local_rank))
-    from xdet.runtime import set_precision
     set_precision(args.precision)
+    # under a launcher (RANK set) the collective path is exercised even for one rank
+    use_comm = world > 1 or args.comm or 'RANK' in os.environ
+    comm = xdist.Communicator(rank, world) if use_comm else None
 
     B, K, Wm = args.batch, args.steps, args.warmup
+    gathered = None
     if args.workload == 'lighthead':
         from xdet.model import LightHeadDetector
         weights = W.make_lighthead_weights(1234)
-        ways = max(1, args.ways)
+        ways = max(1, min(args.ways, B))
         if B % ways:
             raise SystemExit('--batch must be a multiple of --ways')
         sb = B // ways                               # images per sub-batch / net instance
@@ -204,36 +253,40 @@ def main():
             rng = np.random.default_rng(7 + rank)
             raw = [(to_device(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)), h, w) for h, w in shapes]
         nc, topk = net.num_classes - 1, net.nms_topk
-        gather = None
-        if use_dist:
-            # detections land in torch-owned device memory so RCCL can gather them in place
-            sc = torch.zeros((B, nc, topk), dtype=torch.float32, device='cuda')
-            bx = torch.zeros((B, nc, topk, 4), dtype=torch.float32, device='cuda')
-            allb = torch.zeros((world * B, nc, topk, 5), dtype=torch.float32, device='cuda')
-            gather = (sc, bx, allb)
+        det = None
+        if comm is not None:
+            # the rank's detections live in ONE pair of buffers per parity (each sub-batch net writes its slice),
+            # which the communicator packs and all-gathers in place; two pairs used alternately, so a forward never
+            # has to wait for the pack of the step before it
+            det = [(DeviceBuffer(B * nc * topk * 4, zero=True), DeviceBuffer(B * nc * topk * 16, zero=True))
+                   for _ in range(2)]
+        turn = [0]
 
         use_graph = not args.eager
 
         def step(graph=None, only_first=False):
             g = use_graph if graph is None else graph
-            run = nets[:1] if only_first else nets
+            if only_first:                           # the roofline leg: ONE sub-batch stream alone on the chip
+                nets[0].forward_device(sb, use_graph=g)
+                return
             if raw is not None:
-                for nt in run:
+                for nt in nets:
                     for j in range(sb):
                         buf, h, w = raw[j % len(raw)]
                         check(lib().xdet_preprocess_eval(buf.ptr, h, w, nt._images.ptr + j * 3 * 480 * 480 * 4, 480,
                                                          nt.stream.handle))
-            if gather is None:
-                for nt in run:
+            if comm is None:
+                for nt in nets:
                     nt.forward_device(sb, use_graph=g)
             else:
-                sc, bx, allb = gather
-                for i, nt in enumerate(run):
-                    nt.forward_device(sb, use_graph=g, det_scores_ptr=sc[i * sb:].data_ptr(),
-                                      det_boxes_ptr=bx[i * sb:].data_ptr())
-                for nt in run:
-                    nt.stream.synchronize()
-                xdist.gather_detections(xdist.pack_detections(sc, bx), world, allb)
+                ds, db = det[turn[0]]
+                turn[0] ^= 1
+                for i, nt in enumerate(nets):
+                    nt.forward_device(sb, use_graph=g, det_scores_ptr=ds.ptr + i * sb * nc * topk * 4,
+                                      det_boxes_ptr=db.ptr + i * sb * nc * topk * 16)
+                # asynchronous: waits for the nets' streams on the device, overlaps the next step
+                comm.allgather_detections(ds.ptr, db.ptr, B, nc, topk, streams=[nt.stream for nt in nets],
+                                          double_buffered=True)
     else:
         from xdet.resnet import ResNet50Trunk
         weights = W.make_resnet50_weights(4321)
@@ -252,42 +305,45 @@ def main():
     def sync_all():
         for nt in nets:
             nt.stream.synchronize()
-        if use_dist:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        if comm is not None:
+            comm.wait()
+            comm.barrier()
 
     for _ in range(Wm):
         step()
     sync_all()
-    # per-op HIP events cannot be recorded into a captured graph: with graph replay the roofline leg
-    # is an eager, instrumented repeat of the same K steps right after the timed region
-    profile = not use_graph
+    # per-op HIP events cannot be recorded into a replayed graph: with graph replay the roofline leg is an
+    # eager, instrumented repeat of K steps of ONE sub-batch stream after the timed region
+    profile = not use_graph and not args.no_roofline and ways == 1
     if profile:
         check(lib().xdet_profile_enable(net.handle, kind, 1))
-    ev0, ev1 = Event(), Event()
+    evs = [Event() for _ in range(K + 1)]
     sync_all()
     t0 = time.perf_counter()
-    ev0.record(net.stream)
-    for _ in range(K):
+    evs[0].record(net.stream)
+    for k in range(K):
         step()
-    ev1.record(net.stream)
+        evs[k + 1].record(net.stream)
     sync_all()
     dt = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_ms(ev1)
-    if not profile:
-        # roofline leg: one sub-batch alone, eager and instrumented (per-launch HIP event pairs)
-        step(graph=False, only_first=True)
-        sync_all()
-        check(lib().xdet_profile_enable(net.handle, kind, 1))
-        for _ in range(K):
-            step(graph=False, only_first=True)
-        sync_all()
-    rows = read_profile(net.handle, kind)
-    check(lib().xdet_profile_enable(net.handle, kind, 0))
+    step_ms = [evs[k].elapsed_ms(evs[k + 1]) for k in range(K)]
+    dev_ms = evs[0].elapsed_ms(evs[K])
+    if comm is not None and args.workload == 'lighthead':
+        gathered = comm.gathered()                   # [world*B, C, K, 5]: proves every rank's shard arrived
+    rows = []
+    if not args.no_roofline:
+        if not profile:
+            step(graph=False, only_first=True)       # eager warm-up of the instrumented leg
+            sync_all()
+            check(lib().xdet_profile_enable(net.handle, kind, 1))
+            for _ in range(K):
+                step(graph=False, only_first=True)
+            sync_all()
+        rows = read_profile(net.handle, kind)
+        check(lib().xdet_profile_enable(net.handle, kind, 0))
 
-    if use_dist:
-        dt = xdist.max_over_ranks(dt, device='cuda')
+    if comm is not None:
+        dt = comm.max_over_ranks(dt)
 
     if rank == 0:
         ms_per_step = dt / K * 1e3
@@ -295,26 +351,37 @@ def main():
         conv_ms = sum(r[1] for r in rows if r[3] > 0)
         conv_launches = sum(r[2] for r in rows if r[3] > 0)
         conv_flops = sum(r[3] * r[2] for r in rows if r[3] > 0) * sb    # flops are per image, a launch covers one sub-batch
+        peak = PEAK_F32_MFMA_TFLOPS if args.precision == 'f32' else PEAK_F16_MFMA_TFLOPS
+        nprod = 3 if args.precision == 'f16x3' else 1
         roof = None
         if conv_ms > 0:
             ach = conv_flops / (conv_ms * 1e-3) / 1e12
-            peak = PEAK_F32_MFMA_TFLOPS if args.precision == 'f32' else PEAK_F16_MFMA_TFLOPS
             kname = 'conv_mfma_f32_kernel' if args.precision == 'f32' else 'conv_dma_f16_kernel (+conv_mfma_f16_kernel for the 5 small/strided convs)'
+            src = kernel_source_hash()
             default_cfg = args.workload == 'lighthead' and sb == 64 and args.proposals == 300
-            traffic = traffic_from_profiles(args.precision) if default_cfg else (None, None)
+            ctr = counters_from_profiles(args.precision, src) if default_cfg else None
             roof = {'bound': 'mfma', 'kernel': kname, 'achieved': round(ach, 2),
                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                    'mfma_issued_tflops': round(ach * (3 if args.precision == 'f16x3' else 1), 2),
-                    'mfma_util': round(ach * (3 if args.precision == 'f16x3' else 1) / peak, 4),
-                    'traffic': traffic[0],
-                    'traffic_unit': ('HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE), from ' + str(traffic[1]))
-                    if traffic[0] else 'no PMC pass committed for this configuration',
+                    'mfma_issued_tflops': round(ach * nprod, 2),
+                    'mfma_util': round(ach * nprod / peak, 4),
+                    'mfma_util_how': 'issued MFMA FLOPs (%d products per algorithmic product) / peak' % nprod,
+                    'mfma_busy_frac_pmc': ctr['mfma_busy_frac'] if ctr else None,
+                    'traffic': ctr['traffic'] if ctr else None,
+                    'traffic_unit': ('HBM bytes per conv launch (PMC FETCH_SIZE x2 + WRITE_SIZE), from %s, same kernel '
+                                     'sources (%s)' % (ctr['file'], src)) if ctr
+                    else 'no PMC pass committed for these kernel sources (%s) / this configuration' % src,
                     'launches_per_step': conv_launches // K,
                     'avg_launch_us': round(conv_ms * 1e3 / max(conv_launches, 1), 2),
                     'kernel_ms_per_step': round(conv_ms / K, 3), 'gflop_per_image': round(flops_img / 1e9, 2),
+                    # the un-instrumented view: every algorithmic FLOP of the step over the timed wall clock
+                    'frac_whole_step': round(B * flops_img / (ms_per_step * 1e-3) / 1e12 / peak, 4),
+                    'config': 'one_stream: one sub-batch of %d images alone on the chip' % sb,
                     'how': ('HIP event pair around every conv/dense launch on its launch stream, ' +
-                            ('in an eager repeat of the same K steps right after the graph-replayed timed region'
-                             if use_graph else 'inside the timed region'))}
+                            ('inside the timed region' if profile else
+                             'in an eager repeat of K steps of ONE sub-batch stream right after the timed region (a '
+                             'replayed graph cannot carry event pairs, and with %d concurrent streams a launch\'s '
+                             'duration would include the other stream\'s kernels); frac_whole_step is the '
+                             'un-instrumented figure of the timed region itself' % ways))}
         out = {
             'metric': 'images/sec at 480x480 Light-Head R-CNN, 1/2/4/8 MI355X + backbone MFMA util%',
             'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': K, 'warmup': Wm,
@@ -328,12 +395,23 @@ def main():
                        'concurrent_sub_batches': ways,
                        'input': ('uint8 VOC-shape stream + F1 pre-processing kernel in the step' if args.voc_stream
                                  else 'whitened f32 [B,3,480,480] resident in HBM'),
-                       'parallelism': 'image-sharded dp%d, all-gather of detections' % world,
+                       'parallelism': 'image-sharded dp%d%s' % (world, ', RCCL all-gather of detections per step '
+                                                                '(C-ABI, overlapped with the next forward)'
+                                                                if comm is not None else ''),
                        'weights': 'seeded random init (no checkpoint exists)', 'graph_replay': bool(use_graph)},
             'device_ms_per_step': round(dev_ms / K, 3),
+            'median_ms_per_step': round(float(np.median(step_ms)), 3),
+            'min_ms_per_step': round(float(np.min(step_ms)), 3),
             'gflop_per_image': {k: round(v / 1e9, 2) for k, v in fl.items()},
             'roofline': roof,
         }
+        if comm is not None:
+            info = comm.info()
+            out['comm'] = {'transport': 'RCCL %d via libxdet_hip.so (xdet_comm_*), no torch' % info['rccl_version'],
+                           'world': info['world'],
+                           'gathered_shape': list(gathered.shape) if gathered is not None else None,
+                           'gathered_images_with_detections': int((gathered[..., 0].reshape(gathered.shape[0], -1) > 0)
+                                                                  .any(1).sum()) if gathered is not None else None}
         if args.workload == 'lighthead' and args.precision != 'f32' and not args.no_parity:
             out['parity'] = live_parity(weights, args.proposals)
         if world == 1 and not args.no_cpu_baseline:
@@ -347,9 +425,10 @@ def main():
                 sys.stderr.write('%-52s %8.3f ms/step %5.1f%%  %7.1f TFLOP/s\n' % (name, ms / K, 100 * ms / tot, tf))
             sys.stderr.write('planned ops %.3f ms/step of %.3f ms/step\n' % (tot / K, ms_per_step))
         print(json.dumps(out))
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        sys.stdout.flush()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == '__main__':

@@ -186,9 +186,15 @@ int xdet_net_bboxes_eval(void* net, int N, const int* image_shapes, const float*
                          float* det_boxes, void* stream);
 /* whole forward: images f32 [N,3,S,S] -> det_scores [N,20,topk], det_boxes [N,20,topk,4].
  * image_shapes / bbox_img may be NULL (S x S, [0,0,1,1]).  use_graph != 0 replays a hipGraph
- * captured on first use for this N. */
+ * of the whole forward.  A graph bakes in every pointer it was captured with, so graphs are cached
+ * per argument tuple (N, images, image_shapes, bbox_img, det_scores, det_boxes): the first call with a
+ * new tuple captures (and runs) a new graph, later calls with the same tuple replay it; at most 8
+ * graphs are kept per net (oldest evicted).  The CONTENTS of the buffers may change between replays,
+ * the buffers themselves must stay allocated while their graph is cached.
+ * xdet_net_graph_count: number of graphs currently cached (tests). */
 int xdet_net_forward(void* net, const float* images_nchw, int N, const int* image_shapes, const float* bbox_img,
                      float* det_scores, float* det_boxes, int use_graph, void* stream);
+int xdet_net_graph_count(void* net, int* count);
 /* per-kernel accounting of the last build: total dense FLOPs (2*MAC, unpadded) of one image */
 int xdet_net_flops_per_image(void* net, double* backbone, double* rpn, double* large_sep, double* head);
 
@@ -210,6 +216,34 @@ int xdet_resnet_forward(void* net, const float* images_nchw, int N, float* out_n
 int xdet_resnet_out_shape(void* net, int* Ho, int* Wo, int* C);
 int xdet_resnet_flops_per_image(void* net, double* flops);
 int xdet_resnet_destroy(void* net);
+
+/* ---- (e) multi-GPU: image-sharded ranks + ONE RCCL all-gather of detections per step ------
+ * SURVEY.md 8e.  The reference has nothing to replace here (one tf.estimator session at batch 1,
+ * light_head_rfcn_eval.py:212,466-499); BASELINE config 4 asks for this layer.  One process per GPU.
+ * xdet_comm_init: call after xdet_set_device.  Rank 0 creates the ncclUniqueId and publishes it at
+ *   unique_id_path (temporary name + rename); the other ranks poll for that file for up to timeout_s
+ *   seconds (<= 0: 120), then every rank enters ncclCommInitRank.  world == 1 needs no path.
+ *   librccl.so is bound by dlopen here, not at library load.
+ * xdet_comm_allgather_detections: det_scores [B,C,K] + det_boxes [B,C,K,4] of this rank are packed
+ *   into packed_local [B,C,K,5] (score | ymin xmin ymax xmax) and all-gathered into gathered
+ *   [world*B,C,K,5] (rank-major).  Runs on the communicator's own stream: it first waits for the
+ *   n_producers streams that write the det buffers, and makes those streams wait for the pack, so the
+ *   caller may enqueue the next forward immediately -- the gather overlaps it.  No host sync.
+ *   det_double_buffered != 0: the caller alternates between two det buffer pairs from call to call;
+ *   the producers then only wait for the PREVIOUS call's pack (the one that read the pair they write
+ *   next), which removes the once-per-step join of the producer streams.
+ * xdet_comm_wait: stream != NULL -> that stream waits for the last gather; NULL -> the host does.
+ * xdet_comm_allreduce_max / xdet_comm_barrier: scalar collectives for bench timing (host-synchronous). */
+int xdet_comm_init(void** comm, int rank, int world, const char* unique_id_path, int timeout_s);
+int xdet_comm_destroy(void* comm);
+int xdet_comm_info(void* comm, int* rank, int* world, int* device, int* rccl_version);
+int xdet_pack_detections(const float* det_scores, const float* det_boxes, int64_t n_slots, float* packed, void* stream);
+int xdet_comm_allgather_detections(void* comm, const float* det_scores, const float* det_boxes, int n_images,
+                                   int n_fg_classes, int topk, float* packed_local, float* gathered,
+                                   void* const* producer_streams, int n_producers, int det_double_buffered);
+int xdet_comm_wait(void* comm, void* stream);
+int xdet_comm_allreduce_max(void* comm, double* value_host);
+int xdet_comm_barrier(void* comm);
 
 #ifdef __cplusplus
 }

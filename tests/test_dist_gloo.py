@@ -1,12 +1,17 @@
-"""The N>1 path on CPU: two gloo ranks shard a global batch, pack fixed-size detection records
-and all-gather them -- the same xdet.dist functions bench.py uses over RCCL."""
+"""The N>1 path on CPU.  The product transport is RCCL behind the C-ABI (csrc/comm.hip), which needs
+GPUs; what CAN be checked here is everything around it: the shard partition, the detection record
+layout and rank-major gather layout (two gloo ranks move the records exactly as ncclAllGather
+would -- torch is test infrastructure only, the product imports none of it), the rendezvous file
+naming, and the rank launcher that `bench.py --gpus N` uses."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 
-torch = pytest.importorskip('torch')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -18,9 +23,7 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, 'x-detector_amd'))
+    sys.path.insert(0, os.path.join(ROOT, 'x-detector_amd'))
     import torch
     import torch.distributed as dist
     from xdet import dist as xd
@@ -30,20 +33,25 @@ def _worker(rank, world, port, q):
     G, C, K = 6, 20, 200
     lo, hi = xd.shard_range(G, rank, world)
     # deterministic "detections" of the global batch; each rank fills only its own shard
-    g = torch.Generator().manual_seed(0)
-    all_scores = torch.rand((G, C, K), generator=g)
-    all_boxes = torch.rand((G, C, K, 4), generator=g)
-    packed = xd.pack_detections(all_scores[lo:hi].clone(), all_boxes[lo:hi].clone())
-    out = xd.gather_detections(packed, world)
-    s, b = xd.unpack_detections(out)
-    ok = bool(torch.equal(s, all_scores) and torch.equal(b, all_boxes))
-    t = xd.max_over_ranks(1.0 + rank)
+    rng = np.random.default_rng(0)
+    all_scores = rng.random((G, C, K), dtype=np.float32)
+    all_boxes = rng.random((G, C, K, 4), dtype=np.float32)
+    packed = xd.pack_detections(all_scores[lo:hi], all_boxes[lo:hi])
+    shape = xd.gathered_layout(world, hi - lo, C, K)
+    out = torch.empty(shape, dtype=torch.float32)
+    # all-gather with ncclAllGather semantics: rank r's send buffer lands at offset r * sendcount
+    dist.all_gather(list(out.chunk(world, dim=0)), torch.from_numpy(packed))
+    s, b = xd.unpack_detections(out.numpy())
+    ok = bool(np.array_equal(s, all_scores) and np.array_equal(b, all_boxes))
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)       # the max-over-ranks timing rule of bench.py
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, ok, t, (lo, hi), tuple(out.shape)))
+    q.put((rank, ok, float(t.item()), (lo, hi), tuple(out.shape)))
 
 
 def test_two_rank_gather_of_detections():
+    pytest.importorskip('torch')
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -72,8 +80,73 @@ def test_shard_range_covers_ragged_batches():
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
 
 
+def test_pack_unpack_round_trip():
+    from xdet import dist as xd
+    rng = np.random.default_rng(3)
+    s = rng.random((3, 20, 200), dtype=np.float32)
+    b = rng.random((3, 20, 200, 4), dtype=np.float32)
+    p = xd.pack_detections(s, b)
+    assert p.shape == (3, 20, 200, 5) and p.flags['C_CONTIGUOUS']
+    s2, b2 = xd.unpack_detections(p)
+    assert np.array_equal(s, s2) and np.array_equal(b, b2)
+
+
 def test_payload_is_latency_bound():
     """80 KB per image: at batch 8 per rank x 8 ranks ~5 MB total, far below one xGMI link-second."""
     per_image = 20 * 200 * 5 * 4
     assert per_image == 80000
     assert 8 * 8 * per_image < 153e9 * 1e-3
+
+
+def test_rendezvous_path_is_shared_by_the_workers_of_one_launch():
+    from xdet import dist as xd
+    assert xd.rendezvous_path({'XDET_COMM_ID_FILE': '/x/y'}) == '/x/y'
+    env = {'MASTER_PORT': '29511', 'TORCHELASTIC_RUN_ID': 'none', 'TORCHELASTIC_RESTART_COUNT': '0', 'TMPDIR': '/tmp'}
+    a, b = xd.rendezvous_path(env), xd.rendezvous_path(dict(env))
+    assert a == b and a.startswith('/tmp/xdet_rccl_id_29511_%d_' % os.getppid())
+    assert xd.rendezvous_path(dict(env, MASTER_PORT='29512')) != a
+    assert xd.rendezvous_path(dict(env, TORCHELASTIC_RESTART_COUNT='1')) != a
+
+
+def test_launcher_hands_out_ranks_and_one_id_file(tmp_path):
+    """xdet.launch.launch_ranks == what `bench.py --gpus N` does when started plainly."""
+    from xdet.launch import launch_ranks
+    script = tmp_path / 'rank.py'
+    script.write_text(
+        'import os, sys\n'
+        'r = os.environ["RANK"]\n'
+        'open(os.path.join(%r, "out_" + r), "w").write(" ".join([r, os.environ["LOCAL_RANK"], '
+        'os.environ["WORLD_SIZE"], os.environ["XDET_COMM_ID_FILE"]]))\n'
+        'print("rank", r)\n' % str(tmp_path))
+    assert launch_ranks([sys.executable, str(script)], 3) == 0
+    got = [open(tmp_path / ('out_%d' % r)).read().split() for r in range(3)]
+    assert [g[0] for g in got] == ['0', '1', '2'] and [g[1] for g in got] == ['0', '1', '2']
+    assert all(g[2] == '3' for g in got)
+    assert len({g[3] for g in got}) == 1 and not os.path.exists(os.path.dirname(got[0][3]))   # cleaned up
+
+
+def test_launcher_propagates_a_failing_rank(tmp_path):
+    from xdet.launch import launch_ranks
+    script = tmp_path / 'rank.py'
+    script.write_text('import os, sys, time\n'
+                      'if os.environ["RANK"] == "1": sys.exit(7)\n'
+                      'time.sleep(30)\n')
+    assert launch_ranks([sys.executable, str(script)], 2) == 7
+
+
+def test_bench_rejects_a_world_size_mismatch():
+    """--gpus must equal WORLD_SIZE when a launcher provides ranks (round-1 bug: --gpus was ignored)."""
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='2')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4'], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode != 0 and b'WORLD_SIZE=2' in p.stderr
+
+
+def test_no_torch_in_the_product_or_the_bench():
+    import re
+    files = [os.path.join(ROOT, 'bench.py'), os.path.join(ROOT, '__graft_entry__.py')]
+    for d, _, fs in os.walk(os.path.join(ROOT, 'x-detector_amd')):
+        files += [os.path.join(d, f) for f in fs if f.endswith('.py')]
+    for f in files:
+        src = open(f).read()
+        assert not re.search(r'^\s*(import|from)\s+torch\b', src, flags=re.M), f

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/xdet.h"   // XDET_OK / XDET_ERR_* codes
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -32,6 +33,21 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
     int _rc = (expr);             \
     if (_rc != 0) return _rc;     \
   } while (0)
+
+// hipFuncSetAttribute is a per-DEVICE setting: apply it once per (kernel, device) -- one bit per device
+// ordinal; two threads racing on the first launch just repeat an idempotent call.
+struct DeviceOnce {
+  std::atomic<unsigned long long> done{0};
+};
+static inline int ensure_dynamic_lds(DeviceOnce& once, const void* kern, int bytes) {
+  int dev = 0;
+  XDET_HIP(hipGetDevice(&dev));
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (once.done.load(std::memory_order_acquire) & bit) return XDET_OK;
+  XDET_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  once.done.fetch_or(bit, std::memory_order_release);
+  return XDET_OK;
+}
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

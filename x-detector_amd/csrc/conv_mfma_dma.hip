@@ -251,12 +251,8 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE = 2>
 static int launch_d(const ConvParams& p, hipStream_t s) {
   constexpr size_t lds = (size_t)NSTAGE * (2 * BM + 2 * BN) * 32 * sizeof(u16);
   auto kern = conv_dma_f16_kernel<BM, BN, WAVES_M, WAVES_N, NSPLIT, NSTAGE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    XDET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds));
-    attr_set = true;
-  }
+  static DeviceOnce once;
+  XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
   dim3 grid((unsigned)(cdiv(cdiv(p.M, BM), 8) * 8 * (p.Cout_pad / BN)));
   hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, p);
   XDET_LAUNCH_CHECK();

@@ -223,12 +223,8 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, bool SMALL_CIN, int NSPLIT>
 static int launch_b(const ConvParams& p, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * (2 * BM + 2 * BN) * LDH * sizeof(u16);
   auto kern = conv_mfma_f16_kernel<BM, BN, WAVES_M, WAVES_N, SMALL_CIN, NSPLIT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    XDET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds));
-    attr_set = true;
-  }
+  static DeviceOnce once;
+  XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
   dim3 grid((unsigned)cdiv(p.M, BM), (unsigned)(p.Cout_pad / BN));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
   XDET_LAUNCH_CHECK();

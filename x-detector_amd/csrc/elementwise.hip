@@ -309,12 +309,9 @@ static int launch_dw(const float* in, const float* w9c, float* out, unsigned sho
       if (split) hipLaunchKernelGGL((depthwise3x3_tile_kernel<1, true>), g, dim3(256), lds, s, in, w9c, out, hi, lo, N, H, W, ld, relu_in, (int)nt, TY, TX, tpb);
       else hipLaunchKernelGGL((depthwise3x3_tile_kernel<1, false>), g, dim3(256), lds, s, in, w9c, out, hi, lo, N, H, W, ld, relu_in, (int)nt, TY, TX, tpb);
     } else {
-      static bool attr_set = false;
-      if (!attr_set) {
-        XDET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(depthwise3x3_tile_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        XDET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(depthwise3x3_tile_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-      }
+      static DeviceOnce once_t, once_f;
+      XDET_TRY(ensure_dynamic_lds(once_t, reinterpret_cast<const void*>(depthwise3x3_tile_kernel<2, true>), (int)lds));
+      XDET_TRY(ensure_dynamic_lds(once_f, reinterpret_cast<const void*>(depthwise3x3_tile_kernel<2, false>), (int)lds));
       if (split) hipLaunchKernelGGL((depthwise3x3_tile_kernel<2, true>), g, dim3(256), lds, s, in, w9c, out, hi, lo, N, H, W, ld, relu_in, (int)nt, TY, TX, tpb);
       else hipLaunchKernelGGL((depthwise3x3_tile_kernel<2, false>), g, dim3(256), lds, s, in, w9c, out, hi, lo, N, H, W, ld, relu_in, (int)nt, TY, TX, tpb);
     }

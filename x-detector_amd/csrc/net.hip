@@ -5,6 +5,7 @@
 #include "common.h"
 #include "../../include/xdet.h"
 
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <functional>
@@ -28,6 +29,20 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 }
 
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Layers and nets live on the device that was current when they were created; every entry point that
+// launches on their behalf makes that device current for the call (and restores the caller's), so two
+// detectors on two GPUs can share one process / one host thread per device.
+struct DeviceGuard {
+  int prev = -1, want = -1;
+  explicit DeviceGuard(int dev) : want(dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != want) (void)hipSetDevice(want);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0 && prev != want) (void)hipSetDevice(prev);
+  }
+};
 
 struct HostTensor {
   std::vector<float> v;
@@ -86,6 +101,7 @@ static void same_pad(int n, int k, int s, int d, int* before, int* out) {
 struct LayerBase {
   virtual ~LayerBase() {}
   int kind = 0;   // 1 conv, 2 depthwise
+  int device = 0; // the HIP device the weights live on (current device at creation)
 };
 
 struct ConvLayer : LayerBase {
@@ -98,8 +114,10 @@ struct ConvLayer : LayerBase {
   // the same f16 weights K-blocked as [Kp/32][Cout_pad][32] for the LDS-DMA kernel: one K-step of a
   // tile's B operand is then one contiguous run
   unsigned short *d_wt_hi_b = nullptr, *d_wt_lo_b = nullptr;
+  unsigned short* d_zeros = nullptr;   // 256 B of zeros on the layer's device: the source of out-of-image taps
 
   ~ConvLayer() override {
+    if (d_zeros) (void)hipFree(d_zeros);
     if (d_wt_hi_b) (void)hipFree(d_wt_hi_b);
     if (d_wt_lo_b) (void)hipFree(d_wt_lo_b);
     if (d_wt_hi) (void)hipFree(d_wt_hi);
@@ -133,6 +151,11 @@ struct ConvLayer : LayerBase {
       sh[co] = shift ? shift[co] : 0.f;
     }
     precision = g_default_precision;
+    XDET_HIP(hipGetDevice(&device));
+    if (precision != PREC_F32 && !small_cin) {
+      XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_zeros), 256));
+      XDET_HIP(hipMemset(d_zeros, 0, 256));
+    }
     if (precision == PREC_F32) {
       XDET_TRY(upload(wt, &d_wt));
     } else {
@@ -239,6 +262,7 @@ struct DepthwiseLayer : LayerBase {
   int init(int C_, int dil_, const float* w33c1) {
     XDET_REQUIRE(C_ > 0 && dil_ > 0 && w33c1, "depthwise: bad arguments");
     kind = 2;
+    XDET_HIP(hipGetDevice(&device));
     C = C_; dil = dil_; ld = round_up(C, 32);
     std::vector<float> w((size_t)9 * ld, 0.f);
     for (int t = 0; t < 9; ++t)
@@ -273,6 +297,7 @@ struct Op {
 struct ProfRec { int op; hipEvent_t a, b; };
 
 struct Plan {
+  int device = 0;     // HIP device the plan's weights and workspace live on (current device at creation)
   int max_batch = 1;
   bool profiling = false;
   std::vector<ProfRec> prof;
@@ -515,6 +540,8 @@ struct Plan {
 
 enum { ST_BODY = 0, ST_RPN = 1, ST_LSEP = 2, ST_HEAD = 3 };
 
+typedef std::array<uintptr_t, 6> GraphKey;
+
 struct LightHeadNet : Plan {
   xdet_lighthead_config cfg;
   bool built = false;
@@ -529,8 +556,9 @@ struct LightHeadNet : Plan {
   int fmap = 0, n_anchor = 0;
   hipStream_t aux = nullptr;            // side stream of the RPN/proposal branch
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  std::map<int, hipGraphExec_t> graphs;
-  std::map<int, const float*> graph_inputs;
+  static constexpr size_t kMaxGraphs = 8;
+  std::map<GraphKey, hipGraphExec_t> graphs;   // keyed by (N, images, image_shapes, bbox_img, det_scores, det_boxes)
+  std::vector<GraphKey> graph_order;           // capture order, for eviction
 
   ~LightHeadNet() {
     for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
@@ -1000,6 +1028,7 @@ int xdet_conv_forward(void* layer, const float* in, int N, int H, int W, int ld_
                       const float* residual, int relu_in, void* stream) {
   LayerBase* b = static_cast<LayerBase*>(layer);
   XDET_REQUIRE(b && b->kind == 1, "not a conv layer");
+  DeviceGuard guard(b->device);
   return static_cast<ConvLayer*>(b)->forward(in, N, H, W, ld_in, out, ld_out, residual, relu_in, S(stream));
 }
 int xdet_split_f32(const float* in, uint16_t* hi, uint16_t* lo, int64_t n_pix, int ld, int relu, void* stream) {
@@ -1013,12 +1042,8 @@ int xdet_conv_forward_planes(void* layer, const uint16_t* in_hi, const uint16_t*
   ConvLayer* L = static_cast<ConvLayer*>(b);
   XDET_REQUIRE(L->dma_capable(), "layer was not created in a split-precision mode (or has < 32 input channels)");
   XDET_REQUIRE(in_hi && (in_lo || L->precision == PREC_F16), "conv(planes): NULL planes");
-  static unsigned short* zeros = nullptr;
-  if (!zeros) {
-    XDET_HIP(hipMalloc(reinterpret_cast<void**>(&zeros), 256));
-    XDET_HIP(hipMemset(zeros, 0, 256));
-  }
-  return L->forward(nullptr, N, H, W, ld_in, out, ld_out, residual, 0, S(stream), in_hi, in_lo, zeros);
+  DeviceGuard guard(L->device);
+  return L->forward(nullptr, N, H, W, ld_in, out, ld_out, residual, 0, S(stream), in_hi, in_lo, L->d_zeros);
 }
 int xdet_conv_out_shape(void* layer, int H, int W, int* Ho, int* Wo) {
   LayerBase* b = static_cast<LayerBase*>(layer);
@@ -1027,7 +1052,12 @@ int xdet_conv_out_shape(void* layer, int H, int W, int* Ho, int* Wo) {
   static_cast<ConvLayer*>(b)->out_shape(H, W, Ho, Wo, &a, &c);
   return XDET_OK;
 }
-int xdet_layer_destroy(void* layer) { delete static_cast<LayerBase*>(layer); return XDET_OK; }
+int xdet_layer_destroy(void* layer) {
+  if (!layer) return XDET_OK;
+  DeviceGuard guard(static_cast<LayerBase*>(layer)->device);
+  delete static_cast<LayerBase*>(layer);
+  return XDET_OK;
+}
 int xdet_depthwise_create(void** layer, int C, int dilation, const float* k) {
   XDET_REQUIRE(layer, "layer is NULL");
   std::unique_ptr<DepthwiseLayer> L(new DepthwiseLayer());
@@ -1039,6 +1069,7 @@ int xdet_depthwise_forward(void* layer, const float* in, int N, int H, int W, in
                            void* stream) {
   LayerBase* b = static_cast<LayerBase*>(layer);
   XDET_REQUIRE(b && b->kind == 2, "not a depthwise layer");
+  DeviceGuard guard(b->device);
   return static_cast<DepthwiseLayer*>(b)->forward(in, N, H, W, ld, out, relu_in, S(stream));
 }
 int xdet_maxpool3x3s2_add(const float* in, const float* residual, float* out, int N, int H, int W, int C, int ld,
@@ -1098,14 +1129,24 @@ int xdet_net_create(void** net, const xdet_lighthead_config* cfg) {
   XDET_REQUIRE(net && cfg, "net/cfg is NULL");
   LightHeadNet* n = new LightHeadNet();
   n->cfg = *cfg;
+  XDET_HIP(hipGetDevice(&n->device));
   *net = n;
   return XDET_OK;
 }
 int xdet_net_set_weight(void* net, const char* name, const float* data, int ndim, const int64_t* dims) {
   return set_weight(static_cast<LightHeadNet*>(net), name, data, ndim, dims);
 }
-int xdet_net_build(void* net) { XDET_REQUIRE(net, "net is NULL"); return static_cast<LightHeadNet*>(net)->build(); }
-int xdet_net_destroy(void* net) { delete static_cast<LightHeadNet*>(net); return XDET_OK; }
+int xdet_net_build(void* net) {
+  XDET_REQUIRE(net, "net is NULL");
+  DeviceGuard guard(static_cast<LightHeadNet*>(net)->device);
+  return static_cast<LightHeadNet*>(net)->build();
+}
+int xdet_net_destroy(void* net) {
+  if (!net) return XDET_OK;
+  DeviceGuard guard(static_cast<LightHeadNet*>(net)->device);
+  delete static_cast<LightHeadNet*>(net);
+  return XDET_OK;
+}
 
 int xdet_net_buffer(void* net, const char* name, void** dptr, int64_t dims[4], int* ld) {
   LightHeadNet* n = static_cast<LightHeadNet*>(net);
@@ -1138,6 +1179,7 @@ int xdet_net_buffer(void* net, const char* name, void** dptr, int64_t dims[4], i
 int xdet_net_xception_body(void* net, const float* images, int N, void* stream) {
   LightHeadNet* n = static_cast<LightHeadNet*>(net);
   XDET_REQUIRE(n, "net is NULL");
+  DeviceGuard guard(n->device);
   XDET_TRY(n->xception_body(images, N, S(stream)));
   // materialise mid_outputs = ReLU(x) for API users (the fused forward applies it on load instead)
   return launch_relu_copy(n->mid_x.p, n->mid_relu, (int64_t)N * n->mid_x.per_image(), S(stream));
@@ -1145,22 +1187,41 @@ int xdet_net_xception_body(void* net, const float* images, int N, void* stream) 
 int xdet_net_get_rpn(void* net, int N, void* stream) {
   LightHeadNet* n = static_cast<LightHeadNet*>(net);
   XDET_REQUIRE(n, "net is NULL");
+  DeviceGuard guard(n->device);
   XDET_TRY(n->check(N));
   return n->run_stage(ST_RPN, N, S(stream));
 }
 int xdet_net_large_sep(void* net, int N, void* stream) {
   LightHeadNet* n = static_cast<LightHeadNet*>(net);
   XDET_REQUIRE(n, "net is NULL");
+  DeviceGuard guard(n->device);
   XDET_TRY(n->check(N));
   return n->run_stage(ST_LSEP, N, S(stream));
 }
-int xdet_net_rpn_decode(void* net, int N, void* stream) { XDET_REQUIRE(net, "net is NULL"); return static_cast<LightHeadNet*>(net)->rpn_decode(N, S(stream)); }
-int xdet_net_get_proposals(void* net, int N, void* stream) { XDET_REQUIRE(net, "net is NULL"); return static_cast<LightHeadNet*>(net)->get_proposals(N, S(stream)); }
-int xdet_net_get_head(void* net, int N, void* stream) { XDET_REQUIRE(net, "net is NULL"); return static_cast<LightHeadNet*>(net)->get_head(N, S(stream)); }
-int xdet_net_head_decode(void* net, int N, void* stream) { XDET_REQUIRE(net, "net is NULL"); return static_cast<LightHeadNet*>(net)->head_decode(N, S(stream)); }
+int xdet_net_rpn_decode(void* net, int N, void* stream) {
+  XDET_REQUIRE(net, "net is NULL");
+  DeviceGuard guard(static_cast<LightHeadNet*>(net)->device);
+  return static_cast<LightHeadNet*>(net)->rpn_decode(N, S(stream));
+}
+int xdet_net_get_proposals(void* net, int N, void* stream) {
+  XDET_REQUIRE(net, "net is NULL");
+  DeviceGuard guard(static_cast<LightHeadNet*>(net)->device);
+  return static_cast<LightHeadNet*>(net)->get_proposals(N, S(stream));
+}
+int xdet_net_get_head(void* net, int N, void* stream) {
+  XDET_REQUIRE(net, "net is NULL");
+  DeviceGuard guard(static_cast<LightHeadNet*>(net)->device);
+  return static_cast<LightHeadNet*>(net)->get_head(N, S(stream));
+}
+int xdet_net_head_decode(void* net, int N, void* stream) {
+  XDET_REQUIRE(net, "net is NULL");
+  DeviceGuard guard(static_cast<LightHeadNet*>(net)->device);
+  return static_cast<LightHeadNet*>(net)->head_decode(N, S(stream));
+}
 int xdet_net_bboxes_eval(void* net, int N, const int* image_shapes, const float* bbox_img, float* det_scores,
                          float* det_boxes, void* stream) {
   XDET_REQUIRE(net && det_scores && det_boxes, "bboxes_eval: NULL argument");
+  DeviceGuard guard(static_cast<LightHeadNet*>(net)->device);
   return static_cast<LightHeadNet*>(net)->bboxes_eval(N, image_shapes, bbox_img, det_scores, det_boxes, S(stream));
 }
 
@@ -1169,27 +1230,48 @@ int xdet_net_forward(void* net, const float* images, int N, const int* image_sha
   LightHeadNet* n = static_cast<LightHeadNet*>(net);
   XDET_REQUIRE(n && images && det_scores && det_boxes, "forward: NULL argument");
   XDET_TRY(n->check(N));
+  DeviceGuard guard(n->device);
   hipStream_t s = S(stream);
   if (!use_graph) return n->forward_eager(images, N, image_shapes, bbox_img, det_scores, det_boxes, s);
   XDET_REQUIRE(s != nullptr, "graph replay needs an explicit (non-default) stream");
-  // a captured graph bakes in its pointers: key on N and require the same buffers on replay
-  auto it = n->graphs.find(N);
-  if (it == n->graphs.end() || n->graph_inputs[N] != images) {
-    if (it != n->graphs.end()) { (void)hipGraphExecDestroy(it->second); n->graphs.erase(it); }
-    hipGraph_t g;
+  // A captured graph bakes in every pointer it was recorded with, so the cache key is the whole
+  // argument tuple: a call with another input, shape, bbox or output buffer captures its own graph
+  // (double-buffered outputs keep one graph each; the cache is bounded, oldest-first eviction).
+  const GraphKey key = {{(uintptr_t)N, (uintptr_t)images, (uintptr_t)image_shapes, (uintptr_t)bbox_img,
+                         (uintptr_t)det_scores, (uintptr_t)det_boxes}};
+  auto it = n->graphs.find(key);
+  if (it == n->graphs.end()) {
+    if (n->graphs.size() >= LightHeadNet::kMaxGraphs) {
+      const GraphKey old = n->graph_order.front();
+      n->graph_order.erase(n->graph_order.begin());
+      (void)hipGraphExecDestroy(n->graphs[old]);
+      n->graphs.erase(old);
+    }
+    hipGraph_t g = nullptr;
     XDET_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    int rc = n->forward_eager(images, N, image_shapes, bbox_img, det_scores, det_boxes, s);
-    hipError_t e = hipStreamEndCapture(s, &g);
-    if (rc != XDET_OK) return rc;
-    XDET_HIP(e);
-    hipGraphExec_t ge;
-    XDET_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-    XDET_HIP(hipGraphDestroy(g));
-    n->graphs[N] = ge;
-    n->graph_inputs[N] = images;
-    it = n->graphs.find(N);
+    const int rc = n->forward_eager(images, N, image_shapes, bbox_img, det_scores, det_boxes, s);
+    const hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc != XDET_OK || e != hipSuccess) {
+      if (g) (void)hipGraphDestroy(g);
+      if (rc != XDET_OK) return rc;
+      XDET_HIP(e);
+    }
+    hipGraphExec_t ge = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    XDET_HIP(ei);
+    n->graphs[key] = ge;
+    n->graph_order.push_back(key);
+    it = n->graphs.find(key);
   }
   XDET_HIP(hipGraphLaunch(it->second, s));
+  return XDET_OK;
+}
+
+int xdet_net_graph_count(void* net, int* count) {
+  LightHeadNet* n = static_cast<LightHeadNet*>(net);
+  XDET_REQUIRE(n && count, "graph_count: NULL argument");
+  *count = (int)n->graphs.size();
   return XDET_OK;
 }
 
@@ -1232,17 +1314,23 @@ int xdet_resnet_create(void** net, int image_size, int max_batch) {
   ResNetTrunk* r = new ResNetTrunk();
   r->image_size = image_size;
   r->max_batch = max_batch;
+  XDET_HIP(hipGetDevice(&r->device));
   *net = r;
   return XDET_OK;
 }
 int xdet_resnet_set_weight(void* net, const char* name, const float* data, int ndim, const int64_t* dims) {
   return set_weight(static_cast<ResNetTrunk*>(net), name, data, ndim, dims);
 }
-int xdet_resnet_build(void* net) { XDET_REQUIRE(net, "net is NULL"); return static_cast<ResNetTrunk*>(net)->build(); }
+int xdet_resnet_build(void* net) {
+  XDET_REQUIRE(net, "net is NULL");
+  DeviceGuard guard(static_cast<ResNetTrunk*>(net)->device);
+  return static_cast<ResNetTrunk*>(net)->build();
+}
 int xdet_resnet_forward(void* net, const float* images, int N, float* out_nhwc, void* stream) {
   ResNetTrunk* r = static_cast<ResNetTrunk*>(net);
   XDET_REQUIRE(r && r->built && images, "resnet_forward: bad arguments");
   XDET_REQUIRE(N > 0 && N <= r->max_batch, "batch must be in 1..max_batch");
+  DeviceGuard guard(r->device);
   hipStream_t s = S(stream);
   XDET_TRY(launch_nchw_to_nhwc4(images, r->in4.p, N, 3, r->image_size, r->image_size, 4, s));
   XDET_TRY(r->run_stage(0, N, s));
@@ -1262,6 +1350,11 @@ int xdet_resnet_flops_per_image(void* net, double* flops) {
   *flops = r->flops;
   return XDET_OK;
 }
-int xdet_resnet_destroy(void* net) { delete static_cast<ResNetTrunk*>(net); return XDET_OK; }
+int xdet_resnet_destroy(void* net) {
+  if (!net) return XDET_OK;
+  DeviceGuard guard(static_cast<ResNetTrunk*>(net)->device);
+  delete static_cast<ResNetTrunk*>(net);
+  return XDET_OK;
+}
 
 }  // extern "C"

@@ -445,12 +445,8 @@ int launch_get_proposals(const float* objectness, const float* boxes, int N, int
   XDET_LAUNCH_CHECK();
   {
     XDET_REQUIRE((size_t)post_n * 16 <= 96 * 1024, "get_proposals: rpn_post_nms_top_n too large (max 6144)");
-    static bool attr_g = false;
-    if (!attr_g) {
-      XDET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_greedy_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      attr_g = true;
-    }
+    static DeviceOnce once;
+    XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(nms_greedy_kernel), 96 * 1024));
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(N), dim3(512), (size_t)post_n * 16, s, ws.sboxes, ws.counts, pre_n, post_n,
                        nms_thr, ws.kept);
     XDET_LAUNCH_CHECK();

@@ -103,6 +103,7 @@ SIGNATURES = {
     'xdet_net_head_decode': (c_int, [c_void_p, c_int, c_void_p]),
     'xdet_net_bboxes_eval': (c_int, [c_void_p, c_int, PI, PF, PF, PF, c_void_p]),
     'xdet_net_forward': (c_int, [c_void_p, PF, c_int, PI, PF, PF, PF, c_int, c_void_p]),
+    'xdet_net_graph_count': (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     'xdet_net_flops_per_image': (c_int, [c_void_p] + [ctypes.POINTER(c_double)] * 4),
     'xdet_profile_enable': (c_int, [c_void_p, c_int, c_int]),
     'xdet_profile_read': (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_double),
@@ -115,6 +116,15 @@ SIGNATURES = {
     'xdet_resnet_out_shape': (c_int, [c_void_p] + [ctypes.POINTER(c_int)] * 3),
     'xdet_resnet_flops_per_image': (c_int, [c_void_p, ctypes.POINTER(c_double)]),
     'xdet_resnet_destroy': (c_int, [c_void_p]),
+    'xdet_comm_init': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, ctypes.c_char_p, c_int]),
+    'xdet_comm_destroy': (c_int, [c_void_p]),
+    'xdet_comm_info': (c_int, [c_void_p] + [ctypes.POINTER(c_int)] * 4),
+    'xdet_pack_detections': (c_int, [PF, PF, c_int64, PF, c_void_p]),
+    'xdet_comm_allgather_detections': (c_int, [c_void_p, PF, PF, c_int, c_int, c_int, PF, PF,
+                                               ctypes.POINTER(c_void_p), c_int, c_int]),
+    'xdet_comm_wait': (c_int, [c_void_p, c_void_p]),
+    'xdet_comm_allreduce_max': (c_int, [c_void_p, ctypes.POINTER(c_double)]),
+    'xdet_comm_barrier': (c_int, [c_void_p]),
 }
 
 _lib = None

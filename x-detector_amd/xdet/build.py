@@ -19,6 +19,7 @@ SOURCES = [
     ('detect.hip', ['-ffp-contract=off']),
     ('preprocess.hip', ['-ffp-contract=off']),
     ('net.hip', []),
+    ('comm.hip', []),
 ]
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-result']
 
@@ -45,7 +46,7 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
     if dirty:
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)

@@ -1,13 +1,23 @@
 """Multi-GPU plumbing: one process per GPU, images sharded by rank, ONE all-gather of the
-fixed-size padded detections per step.  The reference has no distributed code
-at all (single tf.estimator session); this layer is new.
+fixed-size padded detections per step (BASELINE config 4).  The reference has no
+distributed code at all (a single tf.estimator session at batch 1,
+light_head_rfcn_eval.py:212,466-499); this layer is new.
 
-torch.distributed is used only as the rendezvous + collective transport: backend "nccl" is
-RCCL over xGMI on the GPU box, "gloo" on CPU for the world_size-2 tests.  The payload per
-image is 20 classes x 200 slots x (score + 4 box coords) x 4 B = 80 KB, so the exchange is
-latency-bound (tens of microseconds), never xGMI-link-bound.
+Transport: RCCL behind the C-ABI (xdet_comm_* in include/xdet.h, csrc/comm.hip) -- ncclAllGather
+over xGMI on the communicator's own HIP stream, so the gather of step k runs under the forward of
+step k+1.  Ranks rendezvous through a file that carries rank 0's ncclUniqueId; no PyTorch, no MPI.
+The payload per image is 20 classes x 200 slots x (score + 4 box coords) x 4 B = 80 KB, so the
+exchange is latency-bound (tens of microseconds), never xGMI-link-bound.
+
+The pure-NumPy helpers (shard_range, pack_detections, unpack_detections, gathered_layout) define
+the record layout; the device pack kernel and the tests are checked against them.
 """
+import ctypes
+import os
+
 import numpy as np
+
+RECORD = 5      # floats per detection slot: score | ymin xmin ymax xmax
 
 
 def shard_range(global_batch, rank, world):
@@ -20,8 +30,9 @@ def shard_range(global_batch, rank, world):
 
 def pack_detections(scores, boxes):
     """scores [B,C,K], boxes [B,C,K,4] -> one contiguous [B,C,K,5] record (score | box)."""
-    import torch
-    out = torch.empty(tuple(scores.shape) + (5,), dtype=scores.dtype, device=scores.device)
+    scores = np.asarray(scores, np.float32)
+    boxes = np.asarray(boxes, np.float32)
+    out = np.empty(scores.shape + (RECORD,), np.float32)
     out[..., 0] = scores
     out[..., 1:] = boxes
     return out
@@ -31,28 +42,108 @@ def unpack_detections(packed):
     return packed[..., 0], packed[..., 1:]
 
 
-def gather_detections(local_packed, world, out=None):
-    """all-gather equal-sized per-rank detection records -> [world*B, C, K, 5] on every rank."""
-    import torch
-    import torch.distributed as dist
-    if out is None:
-        out = torch.empty((world * local_packed.shape[0],) + tuple(local_packed.shape[1:]),
-                          dtype=local_packed.dtype, device=local_packed.device)
-    if world == 1 and not dist.is_initialized():
-        out.copy_(local_packed)
+def gathered_layout(world, per_rank, num_fg_classes=20, topk=200):
+    """shape of the all-gather result: rank-major, i.e. global image index = rank * per_rank + local index
+    (the contiguous-block sharding of shard_range with equal shards)."""
+    return (world * per_rank, num_fg_classes, topk, RECORD)
+
+
+def rendezvous_path(environ=None):
+    """where rank 0 publishes the ncclUniqueId.  XDET_COMM_ID_FILE if set (xdet.launch sets it);
+    under `python -m torch.distributed.run` (which only hands out RANK/WORLD_SIZE/MASTER_*) a name
+    that all workers of ONE launch agree on and that no earlier launch can have left behind: master
+    port + the launcher's pid (every worker's parent) + the restart count."""
+    env = os.environ if environ is None else environ
+    if env.get('XDET_COMM_ID_FILE'):
+        return env['XDET_COMM_ID_FILE']
+    tag = '%s_%s_%s_%s' % (env.get('MASTER_PORT', '0'), os.getppid(), env.get('TORCHELASTIC_RUN_ID', 'x'),
+                           env.get('TORCHELASTIC_RESTART_COUNT', '0'))
+    tag = ''.join(ch if ch.isalnum() or ch in '_-' else '_' for ch in tag)
+    return os.path.join(env.get('TMPDIR', '/tmp'), 'xdet_rccl_id_' + tag)
+
+
+class Communicator(object):
+    """RCCL communicator of this rank (call after the device has been selected).
+
+    allgather_detections() is asynchronous and double-buffered: the result of call k stays valid
+    until call k+2, so a consumer can read step k while step k+1 is gathered."""
+
+    def __init__(self, rank, world, id_path=None, timeout_s=120):
+        from ._lib import lib, check, c_void_p
+        self.rank, self.world = int(rank), int(world)
+        if self.world > 1 and not id_path:
+            id_path = rendezvous_path()
+        h = c_void_p()
+        check(lib().xdet_comm_init(ctypes.byref(h), self.rank, self.world,
+                                   id_path.encode() if id_path else None, int(timeout_s)))
+        self.handle = h
+        self._bufs = None
+        self._turn = 0
+        self._last = None
+
+    def info(self):
+        from ._lib import lib, check
+        v = [ctypes.c_int() for _ in range(4)]
+        check(lib().xdet_comm_info(self.handle, *[ctypes.byref(x) for x in v]))
+        return dict(zip(('rank', 'world', 'device', 'rccl_version'), [x.value for x in v]))
+
+    def _ensure(self, n_images, nc, topk):
+        from .runtime import DeviceBuffer
+        key = (n_images, nc, topk)
+        if self._bufs is None or self._bufs[0] != key:
+            slot = n_images * nc * topk * RECORD * 4
+            self._bufs = (key, DeviceBuffer(slot, zero=True),
+                          [DeviceBuffer(slot * self.world, zero=True) for _ in range(2)])
+        return self._bufs
+
+    def allgather_detections(self, det_scores_ptr, det_boxes_ptr, n_images, num_fg_classes, topk, streams=(),
+                             double_buffered=False):
+        """det_scores [B,C,K] / det_boxes [B,C,K,4] (device pointers of THIS rank's shard) -> enqueue
+        pack + ncclAllGather behind the `streams` that produce them; returns the device buffer that
+        will hold [world*B, C, K, 5].  double_buffered: the caller alternates between two det buffer
+        pairs from call to call (removes the per-step join of the producer streams)."""
+        from ._lib import lib, check, c_void_p
+        _, packed, outs = self._ensure(n_images, num_fg_classes, topk)
+        out = outs[self._turn]
+        self._turn ^= 1
+        hs = [s.handle if hasattr(s, 'handle') else s for s in streams]
+        arr = (c_void_p * max(len(hs), 1))(*[h.value if isinstance(h, c_void_p) else h for h in hs])
+        check(lib().xdet_comm_allgather_detections(self.handle, det_scores_ptr, det_boxes_ptr, n_images,
+                                                   num_fg_classes, topk, packed.ptr, out.ptr, arr, len(hs),
+                                                   1 if double_buffered else 0))
+        self._last = (out, gathered_layout(self.world, n_images, num_fg_classes, topk))
         return out
-    if dist.get_backend() == 'nccl':
-        dist.all_gather_into_tensor(out, local_packed.contiguous())
-    else:
-        parts = list(out.chunk(world, dim=0))
-        dist.all_gather(parts, local_packed.contiguous())
-    return out
 
+    def wait(self, stream=None):
+        """the host (stream=None) or `stream` waits for the last gather."""
+        from ._lib import lib, check
+        check(lib().xdet_comm_wait(self.handle, stream.handle if stream is not None else None))
 
-def max_over_ranks(value, device=None):
-    import torch
-    import torch.distributed as dist
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device or 'cpu')
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    def gathered(self):
+        """host copy of the last gather: [world*B, C, K, 5]."""
+        from .runtime import to_host
+        self.wait()
+        buf, shape = self._last
+        return to_host(buf.ptr, shape, np.float32)
+
+    def max_over_ranks(self, value):
+        from ._lib import lib, check
+        v = ctypes.c_double(float(value))
+        check(lib().xdet_comm_allreduce_max(self.handle, ctypes.byref(v)))
+        return v.value
+
+    def barrier(self):
+        from ._lib import lib, check
+        check(lib().xdet_comm_barrier(self.handle))
+
+    def close(self):
+        if getattr(self, 'handle', None) is not None:
+            from ._lib import lib
+            lib().xdet_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

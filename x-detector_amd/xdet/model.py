@@ -11,7 +11,7 @@ import ctypes
 
 import numpy as np
 
-from ._lib import lib, check, c_void_p, LightHeadConfig, XdetError
+from ._lib import lib, check, c_void_p, LightHeadConfig, XdetError, InvalidArgumentError
 from .runtime import DeviceBuffer, DeviceTensor, Stream, to_device, to_host, synchronize, _host
 
 _current = []
@@ -263,7 +263,13 @@ def get_proposals(object_score, bboxes_pred, encode_fn, rpn_pre_nms_top_n, rpn_p
     """net/xception_body.py:402-448 (eval branch) -> proposals [N,post_n,4] numpy."""
     assert not is_training, 'forward-only path'
     d = _det()
-    assert (rpn_pre_nms_top_n, rpn_post_nms_top_n) == (d.cfg.rpn_pre_nms_top_n, d.cfg.rpn_post_nms_top_n)
+    # the native net bakes these in at build time (xdet_lighthead_config): a caller porting reference code
+    # with other values must build the detector with them, not get silently different proposals
+    want = (d.cfg.rpn_pre_nms_top_n, d.cfg.rpn_post_nms_top_n, np.float32(d.cfg.rpn_nms_thres), np.float32(d.cfg.rpn_min_size))
+    got = (rpn_pre_nms_top_n, rpn_post_nms_top_n, np.float32(nms_threshold), np.float32(rpn_min_size))
+    if want != got:
+        raise InvalidArgumentError(-1, 'get_proposals: (pre_n, post_n, nms_threshold, rpn_min_size) = %r but the '
+                                       'detector was built with %r' % (got, want))
     n = object_score.shape[0]
     d.write('objectness', np.asarray(object_score, np.float32))
     d.write('rpn_boxes', np.asarray(bboxes_pred, np.float32))
@@ -278,6 +284,9 @@ def get_head(net_input, pooling_op, grid_width, grid_height, loss_func, proposal
     `pooling_op` is accepted for signature parity; the fused HIP PsRoiAlign is always used."""
     assert not is_training and not using_ohem, 'forward-only path'
     d = _det()
+    if (grid_width, grid_height) != (d.cfg.grid, d.cfg.grid) or num_classes != d.cfg.num_classes:
+        raise InvalidArgumentError(-1, 'get_head: grid %dx%d / %d classes but the detector was built with %dx%d / %d'
+                                   % (grid_width, grid_height, num_classes, d.cfg.grid, d.cfg.grid, d.cfg.num_classes))
     n = proposals_bboxes.shape[0]
     view = d.buffer('feat', n)
     if not _same(net_input, view):
