@@ -169,6 +169,13 @@ typedef struct {
 
 int xdet_net_create(void** net, const xdet_lighthead_config* cfg);
 int xdet_net_set_weight(void* net, const char* name, const float* data_host, int ndim, const int64_t* dims);
+/* options, before xdet_net_build:
+ *   "large_sep" = "auto" | "direct" | "spectral": arithmetic form of large_sep_kernel (net/xception_body.py:450-475).
+ *   direct = the (15,1)/(1,15) convs as implicit GEMMs; spectral = the same linear maps evaluated in the DFT
+ *   domain of the convolved axis (one GEMM per frequency bin, ~5x fewer MFMA FLOPs; needs a split-precision
+ *   mode and a 16/30/50 feature map); auto = spectral when max_batch * feature_map_side >= 480, else direct.
+ *   The choice is per net, never per call: results do not depend on the batch an image arrives in. */
+int xdet_net_set_option(void* net, const char* key, const char* value);
 int xdet_net_build(void* net);     /* folds BN, transposes/pads weights, allocates the workspace */
 int xdet_net_destroy(void* net);
 /* named workspace buffers (views, owned by the net): "mid","out","rpn_out","feat","objectness",

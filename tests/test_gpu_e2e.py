@@ -8,15 +8,20 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
-@pytest.fixture(scope='module', params=['f32', 'f16x3'])
+@pytest.fixture(scope='module', params=['f32', 'f16x3', 'f16x3+spectral'])
 def run(request, oracle, lh_weights):
+    """f32 = exact f32 MFMA; f16x3 = the product arithmetic with the direct large-separable convs (what a
+    small max_batch selects); f16x3+spectral = the same with the large-separable convs in the DFT domain
+    (what bench-size batches select)."""
     from xdet import weights as W
     from xdet.model import LightHeadDetector
     from xdet.runtime import set_precision
     imgs = W.synthetic_images(2, 480, seed=0)
-    set_precision(request.param)
+    prec, _, lsep = request.param.partition('+')
+    set_precision(prec)
     try:
-        det = LightHeadDetector(lh_weights, image_size=480, max_batch=2, rpn_post_nms_top_n=300)
+        det = LightHeadDetector(lh_weights, image_size=480, max_batch=2, rpn_post_nms_top_n=300,
+                                large_sep=lsep or 'direct')
     finally:
         set_precision('f32')
     got = det.forward(imgs)
@@ -127,8 +132,9 @@ def test_graph_builder_api_mirrors_reference(run, oracle, lh_weights):
         assert np.abs(c - tr['cls']).max() < 2e-4 and np.abs(r - tr['reg']).max() < 2e-4
 
 
-@pytest.mark.parametrize('size,R', [(800, 300), (480, 1000)])
-def test_other_baseline_configs(size, R, oracle, lh_weights):
+@pytest.mark.parametrize('size,R,lsep', [(800, 300, 'direct'), (480, 1000, 'direct'), (800, 300, 'spectral'),
+                                         (256, 100, 'spectral')])
+def test_other_baseline_configs(size, R, lsep, oracle, lh_weights):
     """BASELINE config 5 shape (800x800 -> 50x50 map, 55,000 anchors) and the reference's default
     rpn_post_nms_top_n=1000 (light_head_rfcn_eval.py:111), default product arithmetic (f16x3)."""
     from xdet import weights as W
@@ -137,7 +143,7 @@ def test_other_baseline_configs(size, R, oracle, lh_weights):
     imgs = W.synthetic_images(1, size, seed=size)
     set_precision('f16x3')
     try:
-        det = LightHeadDetector(lh_weights, image_size=size, max_batch=1, rpn_post_nms_top_n=R)
+        det = LightHeadDetector(lh_weights, image_size=size, max_batch=1, rpn_post_nms_top_n=R, large_sep=lsep)
     finally:
         set_precision('f32')
     got = det.forward(imgs)
@@ -155,7 +161,7 @@ def test_other_baseline_configs(size, R, oracle, lh_weights):
     assert n_same >= R - max(2, R // 100)
     total, matched, extra = match_detections(got[0], ref[0])
     print('size %d R %d: oracle detections %d matched %d extra %d' % (size, R, total, matched, extra))
-    assert total > 20
+    assert total > (20 if size >= 480 else 0)
     assert matched >= total - max(2, total // 50) and extra <= max(2, total // 50)
 
 

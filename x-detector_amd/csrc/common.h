@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 namespace xdet {
 
@@ -84,6 +85,11 @@ struct ConvParams {
   int KH, KW, stride, dil, pad_t, pad_l;
   int M;             // N*Ho*Wo
   int relu_in, relu_out;
+  // grouped GEMM (conv_mfma_dma.hip only; the frequency bins of the spectral large-separable conv): rows
+  // [g*group_rows, (g+1)*group_rows) of the M dimension use weight matrix g (wt_* + g*group_wt_stride halves)
+  // and scale/shift row g (+ g*Cout_pad).  group_rows is a multiple of every M tile; 0 = one group.
+  int group_rows;
+  long long group_wt_stride;
 };
 int launch_conv_mfma_f32(const ConvParams& p, bool small_cin, int n_tile, hipStream_t s);
 // nsplit 3 = f16x3 (hi/lo f16 operands, f32-class accuracy), 1 = plain f16 operands
@@ -102,6 +108,16 @@ int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, in
                      hipStream_t s);
 int launch_depthwise3x3_split(const float* in, const float* w9c, unsigned short* hi, unsigned short* lo, int N,
                               int H, int W, int C, int ld, int dil, int relu_in, hipStream_t s);
+
+// ---- spectral large-separable conv: DFT passes around the grouped GEMM (spectral.hip) ----
+bool spectral_supported(int F);
+int spectral_points(int F);
+void spectral_tables(int F, std::vector<float>* fwd, std::vector<float>* inv);
+void spectral_weights(const float* w, int T, int cin, int cout, int cin_ld, int cout_ld, int F, std::vector<float>* out);
+int launch_dft_fwd(const float* in, int F, int ld, int axis, int N, int m_pad, const float* tab, unsigned short* hi,
+                   unsigned short* lo, hipStream_t s);
+int launch_dft_inv(const float* Y, int F, int ldn, int C_ld, int N, int m_pad, const float* tab, const float* scale,
+                   const float* shift, int relu, float* out, int ldo, int axis, hipStream_t s);
 
 // ---- F1 pre-processing (preprocess.hip) ----------------------------------------------
 int launch_preprocess_eval(const unsigned char* img, int H, int W, float* out_chw, int S, hipStream_t s);

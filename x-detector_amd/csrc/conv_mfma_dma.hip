@@ -35,7 +35,7 @@ typedef unsigned short u16;
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(ConvParams p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(ConvParams p_in) {
   static_assert(NSTAGE == 2, "two LDS stages");
   constexpr int NW = WAVES_M * WAVES_N;          // waves per workgroup (4 or 8)
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -55,12 +55,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
   // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (private L2s): give every
   // XCD whole M-tiles, all N-tiles of one M-tile back to back, so an activation tile is pulled over
   // the fabric once and then re-read from that XCD's L2 (the weights are small and shared by all).
-  const int nby = p.Cout_pad / BN;
+  const int nby = p_in.Cout_pad / BN;
   const int slot = blockIdx.x >> 3;
   const int bx = (slot / nby) * 8 + (blockIdx.x & 7);
-  if (bx * BM >= p.M) return;
+  if (bx * BM >= p_in.M) return;
   const int m0 = bx * BM;
   const int n0 = (slot % nby) * BN;
+  ConvParams p = p_in;
+  if (p_in.group_rows) {                         // block-uniform: this tile's weight matrix / scale row
+    const int g = m0 / p_in.group_rows;
+    p.wt_hi = p_in.wt_hi + (size_t)g * p_in.group_wt_stride;
+    p.wt_lo = p_in.wt_lo ? p_in.wt_lo + (size_t)g * p_in.group_wt_stride : nullptr;
+    p.scale = p_in.scale + (size_t)g * p_in.Cout_pad;
+    p.shift = p_in.shift + (size_t)g * p_in.Cout_pad;
+  }
 
   // ---- per-lane DMA descriptors ----
   const int lr = lane >> 2;                      // row within a 16-row DMA slab

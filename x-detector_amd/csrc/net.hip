@@ -106,6 +106,7 @@ struct LayerBase {
 
 struct ConvLayer : LayerBase {
   int kh, kw, cin, cout, stride, dil, pad_mode, pad_t, pad_l, relu_out;
+  int groups = 1;     // > 1: grouped GEMM (1x1 only): weight matrix g serves rows [g*group_rows, (g+1)*group_rows)
   int cin_p, kp, cout_pad, n_tile;
   bool small_cin;
   int precision = PREC_F32;
@@ -127,9 +128,13 @@ struct ConvLayer : LayerBase {
     if (d_shift) (void)hipFree(d_shift);
   }
 
+  // groups_ > 1: w_hwio is [groups][cin][cout] (1x1), scale/shift are [groups][cout]
   int init(int kh_, int kw_, int cin_, int cout_, int stride_, int dil_, int pad_mode_, int pad_t_, int pad_l_,
-           const float* w_hwio, const float* scale, const float* shift, int relu_out_) {
+           const float* w_hwio, const float* scale, const float* shift, int relu_out_, int groups_ = 1) {
     XDET_REQUIRE(kh_ > 0 && kw_ > 0 && cin_ > 0 && cout_ > 0 && stride_ > 0 && dil_ > 0, "conv: bad geometry");
+    XDET_REQUIRE(groups_ >= 1 && (groups_ == 1 || (kh_ == 1 && kw_ == 1 && stride_ == 1 && cin_ % 32 == 0)),
+                 "conv: grouped GEMMs are 1x1, stride 1, cin % 32 == 0");
+    groups = groups_;
     XDET_REQUIRE(pad_mode_ >= 0 && pad_mode_ <= 2, "conv: pad_mode must be 0|1|2");
     XDET_REQUIRE(w_hwio != nullptr, "conv: kernel is NULL");
     kind = 1;
@@ -140,17 +145,22 @@ struct ConvLayer : LayerBase {
     kp = round_up(kh * kw * cin_p, 32);
     n_tile = round_up(cout, 64) < round_up(cout, 128) ? 64 : 128;
     cout_pad = round_up(cout, n_tile);
-    std::vector<float> wt((size_t)cout_pad * kp, 0.f), sc(cout_pad, 0.f), sh(cout_pad, 0.f);
-    for (int t = 0; t < kh * kw; ++t)
-      for (int ci = 0; ci < cin; ++ci) {
-        const float* src = w_hwio + ((size_t)t * cin + ci) * cout;
-        for (int co = 0; co < cout; ++co) wt[(size_t)co * kp + (size_t)t * cin_p + ci] = src[co];
+    const size_t G = (size_t)groups, mat = (size_t)cout_pad * kp;
+    std::vector<float> wt(G * mat, 0.f), sc(G * cout_pad, 0.f), sh(G * cout_pad, 0.f);
+    for (size_t g = 0; g < G; ++g) {
+      for (int t = 0; t < kh * kw; ++t)
+        for (int ci = 0; ci < cin; ++ci) {
+          const float* src = w_hwio + ((g * kh * kw + t) * cin + ci) * cout;
+          float* dst = &wt[g * mat + (size_t)t * cin_p + ci];
+          for (int co = 0; co < cout; ++co) dst[(size_t)co * kp] = src[co];
+        }
+      for (int co = 0; co < cout; ++co) {
+        sc[g * cout_pad + co] = scale ? scale[g * cout + co] : 1.f;
+        sh[g * cout_pad + co] = shift ? shift[g * cout + co] : 0.f;
       }
-    for (int co = 0; co < cout; ++co) {
-      sc[co] = scale ? scale[co] : 1.f;
-      sh[co] = shift ? shift[co] : 0.f;
     }
     precision = g_default_precision;
+    XDET_REQUIRE(groups == 1 || precision != PREC_F32, "conv: grouped GEMMs need a split-precision mode");
     XDET_HIP(hipGetDevice(&device));
     if (precision != PREC_F32 && !small_cin) {
       XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_zeros), 256));
@@ -161,40 +171,47 @@ struct ConvLayer : LayerBase {
     } else {
       // per-output-channel power-of-two pre-scale so that max|w| lands in [512, 1024): w_hi cannot
       // overflow f16 and w_lo (~2^-11 |w|) stays a normal f16; undone exactly in the epilogue scale
-      std::vector<unsigned short> hi(wt.size()), lo(wt.size());
-      for (int co = 0; co < cout_pad; ++co) {
+      std::vector<unsigned short> hi(wt.size()), lo(precision == PREC_F16X3 ? wt.size() : 0);
+      for (size_t gc = 0; gc < G * cout_pad; ++gc) {
+        float* row = &wt[gc * kp];
         float mx = 0.f;
-        for (int k = 0; k < kp; ++k) mx = std::max(mx, std::fabs(wt[(size_t)co * kp + k]));
+        for (int k = 0; k < kp; ++k) mx = std::max(mx, std::fabs(row[k]));
         int e = 0;
         if (mx > 0.f) (void)frexpf(mx, &e);
         const int sh_k = mx > 0.f ? 10 - e : 0;
         for (int k = 0; k < kp; ++k) {
-          const float wv = ldexpf(wt[(size_t)co * kp + k], sh_k);
+          const float wv = ldexpf(row[k], sh_k);
           const unsigned short h = f32_to_f16_rne(wv);
-          hi[(size_t)co * kp + k] = h;
-          lo[(size_t)co * kp + k] = f32_to_f16_rne(wv - f16_to_f32(h));
+          hi[gc * kp + k] = h;
+          if (precision == PREC_F16X3) lo[gc * kp + k] = f32_to_f16_rne(wv - f16_to_f32(h));
         }
-        sc[co] = ldexpf(sc[co], -sh_k);
+        sc[gc] = ldexpf(sc[gc], -sh_k);
       }
-      XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_wt_hi), hi.size() * 2));
-      XDET_HIP(hipMemcpy(d_wt_hi, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
-      if (precision == PREC_F16X3) {
-        XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_wt_lo), lo.size() * 2));
-        XDET_HIP(hipMemcpy(d_wt_lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
-      }
-      if (!small_cin) {
-        std::vector<unsigned short> hb(hi.size()), lb(lo.size());
-        for (int co = 0; co < cout_pad; ++co)
-          for (int k = 0; k < kp; ++k) {
-            const size_t d = ((size_t)(k >> 5) * cout_pad + co) * 32 + (k & 31);
-            hb[d] = hi[(size_t)co * kp + k];
-            lb[d] = lo[(size_t)co * kp + k];
-          }
-        XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_wt_hi_b), hb.size() * 2));
-        XDET_HIP(hipMemcpy(d_wt_hi_b, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+      std::vector<float>().swap(wt);
+      if (groups == 1) {      // [Cout_pad][Kp] copies: the register-staged kernel (strided / small-cin convs)
+        XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_wt_hi), hi.size() * 2));
+        XDET_HIP(hipMemcpy(d_wt_hi, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
         if (precision == PREC_F16X3) {
-          XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_wt_lo_b), lb.size() * 2));
-          XDET_HIP(hipMemcpy(d_wt_lo_b, lb.data(), lb.size() * 2, hipMemcpyHostToDevice));
+          XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_wt_lo), lo.size() * 2));
+          XDET_HIP(hipMemcpy(d_wt_lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+        }
+      }
+      if (!small_cin) {       // K-blocked [g][Kp/32][Cout_pad][32] copies: the LDS-DMA kernel
+        std::vector<unsigned short> blk(hi.size());
+        auto kblock = [&](const std::vector<unsigned short>& src) {
+          for (size_t g = 0; g < G; ++g)
+            for (int co = 0; co < cout_pad; ++co) {
+              const unsigned short* r = &src[(g * cout_pad + co) * kp];
+              for (int k = 0; k < kp; ++k) blk[g * mat + ((size_t)(k >> 5) * cout_pad + co) * 32 + (k & 31)] = r[k];
+            }
+        };
+        kblock(hi);
+        XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_wt_hi_b), blk.size() * 2));
+        XDET_HIP(hipMemcpy(d_wt_hi_b, blk.data(), blk.size() * 2, hipMemcpyHostToDevice));
+        if (precision == PREC_F16X3) {
+          kblock(lo);
+          XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_wt_lo_b), blk.size() * 2));
+          XDET_HIP(hipMemcpy(d_wt_lo_b, blk.data(), blk.size() * 2, hipMemcpyHostToDevice));
         }
       }
     }
@@ -228,7 +245,7 @@ struct ConvLayer : LayerBase {
               hipStream_t s, const unsigned short* in_hi = nullptr, const unsigned short* in_lo = nullptr,
               const unsigned short* zeros = nullptr, unsigned short* out_hi = nullptr,
               unsigned short* out_lo = nullptr, int planes_relu = 0, const float* pl_scale = nullptr,
-              const float* pl_shift = nullptr) const {
+              const float* pl_shift = nullptr, int group_rows = 0) const {
     XDET_REQUIRE(ldi == ld_in(), "conv: ld_in must be round_up(cin,32) (4 for cin<=4)");
     XDET_REQUIRE(ldo == ld_out(), "conv: ld_out must be round_up(cout,32)");
     ConvParams p;
@@ -243,6 +260,13 @@ struct ConvLayer : LayerBase {
     p.in_hi = in_hi; p.in_lo = in_lo; p.zeros = zeros;
     p.out_hi = precision == PREC_F32 ? nullptr : out_hi; p.out_lo = out_lo; p.planes_relu = planes_relu;
     p.pl_scale = pl_scale; p.pl_shift = pl_shift;
+    p.group_rows = 0; p.group_wt_stride = 0;
+    if (groups > 1) {
+      XDET_REQUIRE(in_hi && group_rows > 0 && group_rows % 256 == 0 && (int64_t)group_rows * groups == p.M,
+                   "conv(grouped): M must be groups * group_rows, group_rows a multiple of 256, input as planes");
+      p.group_rows = group_rows;
+      p.group_wt_stride = (long long)cout_pad * kp;
+    }
     if (precision == PREC_F32) return launch_conv_mfma_f32(p, small_cin, n_tile, s);
     if (in_hi) {   // A operand already split into f16 planes by its producer: LDS-DMA kernel
       XDET_REQUIRE(!small_cin && relu_in == 0, "conv(dma): needs >= 32 input channels and no ReLU-on-load");
@@ -554,6 +578,8 @@ struct LightHeadNet : Plan {
   int* def_shapes = nullptr;
   float* def_bbox = nullptr;
   int fmap = 0, n_anchor = 0;
+  int large_sep_mode = 0;               // 0 = auto, 1 = direct (15,1)/(1,15) convs, 2 = spectral (DFT-domain GEMMs)
+  bool large_sep_spectral = false;      // decided at build
   hipStream_t aux = nullptr;            // side stream of the RPN/proposal branch
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   static constexpr size_t kMaxGraphs = 8;
@@ -602,7 +628,14 @@ struct LightHeadNet : Plan {
     XDET_TRY(sep_bn("block13_sepconv1", eps, ST_BODY, x, 728, 1, 1, 0, nullptr, &a));
     XDET_TRY(sep_bn("block13_sepconv2", eps, ST_BODY, a, 1024, 1, 1, 0, &r, &b2));
     XDET_TRY(sep_bn("block14_sepconv1", eps, ST_BODY, b2, 1536, 0, 2, 1, nullptr, &c3));   // :354-364
-    emit_planes_next = 1;   // feeds the large-separable (15,1) conv
+    // The large-separable convs run either as direct implicit GEMMs over split planes or in the DFT domain
+    // (spectral.hip: ~5x fewer MFMA FLOPs, but one GEMM per frequency bin with M = N*fmap rows, so it only
+    // pays with enough images per call).  Decided per NET (not per call), so that an image's result never
+    // depends on the batch it arrives in.
+    large_sep_spectral = g_default_precision != PREC_F32 && spectral_supported(c3.H) && c3.H == c3.W &&
+                         (large_sep_mode == 2 || (large_sep_mode == 0 && (int64_t)max_batch * c3.H >= 480));
+    if (large_sep_mode == 2) XDET_REQUIRE(large_sep_spectral, "large_sep=spectral needs a split-precision mode and a 16/30/50 feature map");
+    emit_planes_next = large_sep_spectral ? 0 : 1;   // the direct (15,1) conv takes planes; the DFT pass reads f32
     XDET_TRY(sep_bn("block14_sepconv2", eps, ST_BODY, c3, 2048, 0, 2, 1, nullptr, &d4));   // :366-376
     out = d4;
     fmap = out.H;
@@ -677,6 +710,100 @@ struct LightHeadNet : Plan {
     return XDET_OK;
   }
 
+  // net/xception_body.py:450-475 in the DFT domain of the convolved axis (spectral.hip): per frequency bin one
+  // real GEMM [N*F, 2*Cin] x [2*Cin, 2*Cout] on the split-precision MFMA kernel (grouped launch), a forward
+  // DFT pass in front and an inverse pass (+bias / +BN+ReLU) behind each of the two convolutions
+  int build_large_sep_spectral() {
+    const int mid = 256, co = cfg.bank * cfg.grid * cfg.grid, F = out.H, NB = spectral_points(F) / 2;
+    const int cin = out.C, cin_ld = out.ld, mid2 = 2 * mid, co_ld = round_up(co, 32);
+    const HostTensor *a0, *a0b, *a1, *a1b, *c0, *c0b, *c1, *c1b;
+    XDET_TRY(need("large_sep_feature/Branch_0/conv2d/kernel", &a0, {15, 1, cin, mid}));
+    XDET_TRY(need("large_sep_feature/Branch_0/conv2d/bias", &a0b, {mid}));
+    XDET_TRY(need("large_sep_feature/Branch_1/conv2d/kernel", &a1, {15, 1, cin, mid}));
+    XDET_TRY(need("large_sep_feature/Branch_1/conv2d/bias", &a1b, {mid}));
+    XDET_TRY(need("large_sep_feature/Branch_0/conv2d_1/kernel", &c0, {1, 15, mid, co}));
+    XDET_TRY(need("large_sep_feature/Branch_0/conv2d_1/bias", &c0b, {co}));
+    XDET_TRY(need("large_sep_feature/Branch_1/conv2d_1/kernel", &c1, {1, 15, mid, co}));
+    XDET_TRY(need("large_sep_feature/Branch_1/conv2d_1/bias", &c1b, {co}));
+    // the same branch fusion as the direct form: (15,1) with 2*mid outputs, (1,15) over the stacked channels
+    std::vector<float> ka((size_t)15 * cin * mid2), kb((size_t)15 * mid2 * co), ba(mid2), ones(std::max(mid2, co_ld), 1.f);
+    for (size_t tc = 0; tc < (size_t)15 * cin; ++tc) {
+      memcpy(&ka[tc * mid2], &a0->v[tc * mid], mid * sizeof(float));
+      memcpy(&ka[tc * mid2 + mid], &a1->v[tc * mid], mid * sizeof(float));
+    }
+    for (int j = 0; j < mid; ++j) { ba[j] = a0b->v[j]; ba[mid + j] = a1b->v[j]; }
+    for (int tap = 0; tap < 15; ++tap)
+      for (int ci = 0; ci < mid; ++ci) {
+        memcpy(&kb[((size_t)tap * mid2 + ci) * co], &c0->v[((size_t)tap * mid + ci) * co], co * sizeof(float));
+        memcpy(&kb[((size_t)tap * mid2 + mid + ci) * co], &c1->v[((size_t)tap * mid + ci) * co], co * sizeof(float));
+      }
+    std::vector<float> bsum(co), sc, sh;
+    for (int j = 0; j < co; ++j) bsum[j] = c0b->v[j] + c1b->v[j];
+    XDET_TRY(fold_bn("large_sep_feature/batch_normalization", co, 1e-5f, bsum.data(), &sc, &sh));
+    sc.resize(co_ld, 0.f);
+    sh.resize(co_ld, 0.f);
+    ConvLayer* LA = keep(new ConvLayer());
+    ConvLayer* LB = keep(new ConvLayer());
+    {
+      std::vector<float> wa;
+      spectral_weights(ka.data(), 15, cin, mid2, cin_ld, mid2, F, &wa);
+      XDET_TRY(LA->init(1, 1, 2 * cin_ld, 2 * mid2, 1, 1, 0, 0, 0, wa.data(), nullptr, nullptr, 0, NB));
+    }
+    {
+      std::vector<float> wb;
+      spectral_weights(kb.data(), 15, mid2, co, mid2, co_ld, F, &wb);
+      XDET_TRY(LB->init(1, 1, 2 * mid2, 2 * co_ld, 1, 1, 0, 0, 0, wb.data(), nullptr, nullptr, 0, NB));
+    }
+    std::vector<float> tf, ti;
+    spectral_tables(F, &tf, &ti);
+    float *d_tf, *d_ti, *d_ones, *d_ba, *d_sc, *d_sh;
+    auto up = [&](const std::vector<float>& h, float** d) {
+      XDET_TRY(alloc_bytes(h.size() * 4, reinterpret_cast<void**>(d), false));
+      XDET_HIP(hipMemcpy(*d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+      return (int)XDET_OK;
+    };
+    XDET_TRY(up(tf, &d_tf)); XDET_TRY(up(ti, &d_ti)); XDET_TRY(up(ones, &d_ones)); XDET_TRY(up(ba, &d_ba));
+    XDET_TRY(up(sc, &d_sc)); XDET_TRY(up(sh, &d_sh));
+    // workspace, sized for max_batch: rows of every bin are padded to a whole number of 256-row GEMM tiles
+    const size_t mp_max = (size_t)round_up(max_batch * F, 256), rows = (size_t)NB * mp_max;
+    unsigned short *xa_hi, *xa_lo, *xb_hi, *xb_lo;
+    float *y1, *tmid, *y2;
+    XDET_TRY(alloc_bytes(rows * 2 * cin_ld * 2 + 512, reinterpret_cast<void**>(&xa_hi)));
+    XDET_TRY(alloc_bytes(rows * 2 * cin_ld * 2 + 512, reinterpret_cast<void**>(&xa_lo)));
+    XDET_TRY(alloc_bytes(rows * 2 * mid2 * 2 + 512, reinterpret_cast<void**>(&xb_hi)));
+    XDET_TRY(alloc_bytes(rows * 2 * mid2 * 2 + 512, reinterpret_cast<void**>(&xb_lo)));
+    XDET_TRY(alloc_bytes(rows * 2 * mid2 * 4 + 512, reinterpret_cast<void**>(&y1)));
+    XDET_TRY(alloc_bytes((size_t)max_batch * F * F * mid2 * 4 + 512, reinterpret_cast<void**>(&tmid)));
+    XDET_TRY(alloc_bytes(rows * 2 * co_ld * 4 + 512, reinterpret_cast<void**>(&y2)));
+    XDET_TRY(new_buf(F, F, co, &feat));
+    const Buf o = out, ft = feat;
+    const std::string pre = "large_sep_feature/Branch_0+1/";
+    const double fl_a = 2.0 * F * F * (double)cin * mid2 * 15, fl_b = 2.0 * F * F * (double)mid2 * co * 15;
+    auto mpad = [F](int N) { return round_up(N * F, 256); };
+    // flops < 0 marks an auxiliary pass of a contraction: its time counts with the conv kernels, it has no FLOPs of its own
+    ops.push_back({pre + "conv2d/dft_y", ST_LSEP, -1.0, [=](int N, hipStream_t s) {
+                     return launch_dft_fwd(o.p, F, o.ld, 0, N, mpad(N), d_tf, xa_hi, xa_lo, s);
+                   }});
+    ops.push_back({pre + "conv2d [spectral]", ST_LSEP, fl_a, [=](int N, hipStream_t s) {
+                     return LA->forward(nullptr, 1, 1, NB * mpad(N), 2 * cin_ld, y1, 2 * mid2, nullptr, 0, s, xa_hi, xa_lo,
+                                        LA->d_zeros, nullptr, nullptr, 0, nullptr, nullptr, mpad(N));
+                   }});
+    ops.push_back({pre + "conv2d/idft_y+bias", ST_LSEP, -1.0, [=](int N, hipStream_t s) {
+                     return launch_dft_inv(y1, F, 2 * mid2, mid2, N, mpad(N), d_ti, d_ones, d_ba, 0, tmid, mid2, 0, s);
+                   }});
+    ops.push_back({pre + "conv2d_1/dft_x", ST_LSEP, -1.0, [=](int N, hipStream_t s) {
+                     return launch_dft_fwd(tmid, F, mid2, 1, N, mpad(N), d_tf, xb_hi, xb_lo, s);
+                   }});
+    ops.push_back({pre + "conv2d_1 [spectral]", ST_LSEP, fl_b, [=](int N, hipStream_t s) {
+                     return LB->forward(nullptr, 1, 1, NB * mpad(N), 2 * mid2, y2, 2 * co_ld, nullptr, 0, s, xb_hi, xb_lo,
+                                        LB->d_zeros, nullptr, nullptr, 0, nullptr, nullptr, mpad(N));
+                   }});
+    ops.push_back({pre + "conv2d_1/idft_x+bn+relu", ST_LSEP, -1.0, [=](int N, hipStream_t s) {
+                     return launch_dft_inv(y2, F, 2 * co_ld, co_ld, N, mpad(N), d_ti, d_sc, d_sh, 1, ft.p, ft.ld, 1, s);
+                   }});
+    return XDET_OK;
+  }
+
   int build_head() {
     const int R = cfg.rpn_post_nms_top_n, C = cfg.bank * cfg.grid * cfg.grid, nc = cfg.num_classes;
     const HostTensor *k0, *b0, *k1, *b1, *k2, *b2;
@@ -713,7 +840,7 @@ struct LightHeadNet : Plan {
     max_batch = cfg.max_batch;
     XDET_TRY(build_body());
     XDET_TRY(build_rpn());
-    XDET_TRY(build_large_sep());
+    XDET_TRY(large_sep_spectral ? build_large_sep_spectral() : build_large_sep());
     XDET_TRY(build_head());
     const int B = max_batch, A = cfg.num_anchors, R = cfg.rpn_post_nms_top_n;
     n_anchor = fmap * fmap * A;
@@ -957,7 +1084,7 @@ int ResNetTrunk::build() {
       x = y3;
     }
   XDET_TRY(add_bn_relu(bname(), x, &outb));
-  for (const Op& op : ops) flops += op.flops;
+  for (const Op& op : ops) flops += std::max(op.flops, 0.0);
   w.clear();
   built = true;
   return XDET_OK;
@@ -1136,6 +1263,19 @@ int xdet_net_create(void** net, const xdet_lighthead_config* cfg) {
 int xdet_net_set_weight(void* net, const char* name, const float* data, int ndim, const int64_t* dims) {
   return set_weight(static_cast<LightHeadNet*>(net), name, data, ndim, dims);
 }
+int xdet_net_set_option(void* net, const char* key, const char* value) {
+  LightHeadNet* n = static_cast<LightHeadNet*>(net);
+  XDET_REQUIRE(n && key && value, "set_option: NULL argument");
+  XDET_REQUIRE(!n->built, "set_option: the net is already built");
+  const std::string k(key), v(value);
+  if (k == "large_sep") {
+    XDET_REQUIRE(v == "auto" || v == "direct" || v == "spectral", "large_sep must be auto | direct | spectral");
+    n->large_sep_mode = v == "auto" ? 0 : v == "direct" ? 1 : 2;
+    return XDET_OK;
+  }
+  set_last_error("unknown option: " + k);
+  return XDET_ERR_INVALID_ARG;
+}
 int xdet_net_build(void* net) {
   XDET_REQUIRE(net, "net is NULL");
   DeviceGuard guard(static_cast<LightHeadNet*>(net)->device);
@@ -1279,7 +1419,7 @@ int xdet_net_flops_per_image(void* net, double* backbone, double* rpn, double* l
   LightHeadNet* n = static_cast<LightHeadNet*>(net);
   XDET_REQUIRE(n && n->built, "net not built");
   double f[4] = {0, 0, 0, 0};
-  for (const Op& op : n->ops) f[op.stage] += op.flops;
+  for (const Op& op : n->ops) f[op.stage] += std::max(op.flops, 0.0);
   if (backbone) *backbone = f[ST_BODY];
   if (rpn) *rpn = f[ST_RPN];
   if (large_sep) *large_sep = f[ST_LSEP];

@@ -90,6 +90,7 @@ SIGNATURES = {
                                  PF, PF, c_void_p]),
     'xdet_net_create': (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(LightHeadConfig)]),
     'xdet_net_set_weight': (c_int, [c_void_p, ctypes.c_char_p, PF, c_int, ctypes.POINTER(c_int64)]),
+    'xdet_net_set_option': (c_int, [c_void_p, ctypes.c_char_p, ctypes.c_char_p]),
     'xdet_net_build': (c_int, [c_void_p]),
     'xdet_net_destroy': (c_int, [c_void_p]),
     'xdet_net_buffer': (c_int, [c_void_p, ctypes.c_char_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64 * 4),

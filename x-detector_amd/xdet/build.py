@@ -14,6 +14,7 @@ SOURCES = [
     ('conv_mfma_split.hip', []),
     ('conv_mfma_dma.hip', []),
     ('elementwise.hip', []),
+    ('spectral.hip', []),
     ('psroialign.hip', ['-ffp-contract=off']),
     ('proposals.hip', ['-ffp-contract=off']),
     ('detect.hip', ['-ffp-contract=off']),
