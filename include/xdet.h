@@ -114,6 +114,15 @@ int xdet_layer_destroy(void* layer);
 int xdet_depthwise_create(void** layer, int C, int dilation, const float* dw_kernel_host);
 int xdet_depthwise_forward(void* layer, const float* in, int N, int H, int W, int ld, float* out, int relu_in,
                            void* stream);
+/* relu_separable_bn_block as ONE kernel (net/xception_body.py:220-234: (ReLU ->) depthwise 3x3 -> pointwise 1x1 ->
+ * BN, "nothing in between"): the depthwise result stays on the CU instead of crossing HBM as split planes.
+ * dw_layer from xdet_depthwise_create (dilation 1), pw_layer a 1x1 stride-1 layer from xdet_conv_create in a
+ * split-precision mode (its scale/shift = the folded BN, relu_out as created); <= 256 input channels
+ * (multiple of 32) and 128 or 256 outputs; in/out NHWC f32.  Bit-identical to xdet_depthwise_forward ->
+ * xdet_split_f32 -> xdet_conv_forward_planes.  Inside a net the entry-flow blocks use it
+ * (option "sepconv" = "fused" (default) | "split"). */
+int xdet_sepconv_fused_forward(void* dw_layer, void* pw_layer, const float* in, int N, int H, int W, int ld_in, float* out,
+                               int ld_out, int relu_in, void* stream);
 /* tf.layers.max_pooling2d(3,2,'same') + tf.add(residual) (net/xception_body.py:281-286) */
 int xdet_maxpool3x3s2_add(const float* in, const float* residual, float* out, int N, int H, int W, int C, int ld,
                           void* stream);
@@ -174,7 +183,8 @@ int xdet_net_set_weight(void* net, const char* name, const float* data_host, int
  *   direct = the (15,1)/(1,15) convs as implicit GEMMs; spectral = the same linear maps evaluated in the DFT
  *   domain of the convolved axis (one GEMM per frequency bin, ~5x fewer MFMA FLOPs; needs a split-precision
  *   mode and a 16/30/50 feature map); auto = spectral when max_batch * feature_map_side >= 480, else direct.
- *   The choice is per net, never per call: results do not depend on the batch an image arrives in. */
+ *   The choice is per net, never per call: results do not depend on the batch an image arrives in.
+ *   "sepconv" = "fused" | "split": entry-flow separable blocks as one kernel (default) or depthwise + pointwise. */
 int xdet_net_set_option(void* net, const char* key, const char* value);
 int xdet_net_build(void* net);     /* folds BN, transposes/pads weights, allocates the workspace */
 int xdet_net_destroy(void* net);

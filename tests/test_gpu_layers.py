@@ -128,6 +128,48 @@ def test_depthwise_tile_edges(N, H, W, C, oracle):
     close(y, ref, 1e-6)
 
 
+SEP_CASES = [
+    # (N, H, W, cin, cout, relu_in, relu_out): the entry-flow layers and the tile edges of the fused kernel
+    (2, 237, 237, 64, 128, False, False),     # block2_sepconv1 (no leading ReLU)
+    (1, 237, 237, 128, 128, True, False),     # block2_sepconv2
+    (2, 119, 119, 128, 256, True, False),     # block3_sepconv1 (two 128-wide passes)
+    (1, 119, 119, 256, 256, True, True),      # block3_sepconv2 (+ ReLU epilogue)
+    (3, 30, 30, 32, 128, True, False),        # W == tile width
+    (2, 31, 61, 96, 128, False, True),        # W = 2 tiles + 1, H % 4 = 3
+    (1, 4, 1, 64, 128, True, False),          # one pixel column
+    (5, 9, 29, 160, 256, True, False),        # several images per workgroup walk
+]
+
+
+@pytest.mark.parametrize('case', SEP_CASES)
+@pytest.mark.parametrize('prec', ['f16x3', 'f16'])
+def test_fused_separable_block(case, prec, oracle):
+    """the one-kernel separable block against the oracle, and bit for bit against the two-kernel form"""
+    from xdet.ops import SeparableConvBN
+    from xdet.runtime import DeviceTensor, set_precision
+    N, H, W, cin, cout, relu_in, relu_out = case
+    rng = np.random.default_rng(H * 7 + W * 3 + cin)
+    x = rng.standard_normal((N, H, W, cin)).astype(np.float32)
+    dk = rng.standard_normal((3, 3, cin, 1)).astype(np.float32) / 3
+    pk = (rng.standard_normal((1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.standard_normal(cout).astype(np.float32)
+    set_precision(prec)
+    try:
+        op = SeparableConvBN(dk, pk, scale, shift, relu=relu_out)
+    finally:
+        set_precision('f32')
+    xd = DeviceTensor.from_numpy(x)
+    y_fused = op(xd, relu_in=relu_in, fused=True).numpy()
+    y_split = op(xd, relu_in=relu_in, fused=False).numpy()
+    assert np.array_equal(y_fused, y_split)
+    if prec == 'f16x3':
+        ref = oracle.separable_conv2d(np.maximum(x, 0) if relu_in else x, dk, pk) * scale + shift
+        if relu_out:
+            ref = np.maximum(ref, 0)
+        close(y_fused, ref, 3e-5)
+
+
 @pytest.mark.parametrize('H,W', [(237, 237), (119, 119), (60, 60), (7, 10)])
 def test_maxpool_same_padding_asymmetry(H, W, oracle):
     """TF SAME puts the odd padding pixel at the bottom/right: 60->30 pads 0/1, 237->119 pads 1/1."""

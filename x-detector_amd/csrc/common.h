@@ -119,6 +119,12 @@ int launch_dft_fwd(const float* in, int F, int ld, int axis, int N, int m_pad, c
 int launch_dft_inv(const float* Y, int F, int ldn, int C_ld, int N, int m_pad, const float* tab, const float* scale,
                    const float* shift, int relu, float* out, int ldo, int axis, hipStream_t s);
 
+// ---- fused separable block of the entry flow (sepconv_fused.hip) ----
+bool sepconv_fused_supported(int cin_ld, int cout_pad, int dil);
+int launch_sepconv_fused(const float* in, const float* w9c, const unsigned short* wt_hi_blocked,
+                         const unsigned short* wt_lo_blocked, const float* scale, const float* shift, float* out, int N,
+                         int H, int W, int ld, int ldo, int cout_pad, int relu_in, int relu_out, hipStream_t s);
+
 // ---- F1 pre-processing (preprocess.hip) ----------------------------------------------
 int launch_preprocess_eval(const unsigned char* img, int H, int W, float* out_chw, int S, hipStream_t s);
 

@@ -57,18 +57,30 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
   // the fabric once and then re-read from that XCD's L2 (the weights are small and shared by all).
   const int nby = p_in.Cout_pad / BN;
   const int slot = blockIdx.x >> 3;
-  const int bx = (slot / nby) * 8 + (blockIdx.x & 7);
-  if (bx * BM >= p_in.M) return;
-  const int m0 = bx * BM;
-  const int n0 = (slot % nby) * BN;
+  int bx, n0;
   ConvParams p = p_in;
-  if (p_in.group_rows) {                         // block-uniform: this tile's weight matrix / scale row
-    const int g = m0 / p_in.group_rows;
+  if (p_in.group_rows) {
+    // Grouped GEMM (frequency bins): every group has its own weight matrix, so ALL tiles of a group go to
+    // ONE XCD -- its L2 then holds that group's weights and activations once, instead of eight L2s each
+    // pulling every group's weights over the fabric.  Workgroups are dealt round-robin to the XCDs:
+    // blockIdx & 7 is the XCD, group = 8 * round + XCD, tiles of the group in slot order (N fastest).
+    const int mt = p_in.group_rows / BM;           // M tiles per group
+    const int tpg = mt * nby;
+    const int g = (slot / tpg) * 8 + (blockIdx.x & 7);
+    const int w = slot - (slot / tpg) * tpg;
+    if ((int64_t)g * p_in.group_rows >= p_in.M) return;
+    bx = g * mt + w / nby;
+    n0 = (w % nby) * BN;
     p.wt_hi = p_in.wt_hi + (size_t)g * p_in.group_wt_stride;
     p.wt_lo = p_in.wt_lo ? p_in.wt_lo + (size_t)g * p_in.group_wt_stride : nullptr;
     p.scale = p_in.scale + (size_t)g * p_in.Cout_pad;
     p.shift = p_in.shift + (size_t)g * p_in.Cout_pad;
+  } else {
+    bx = (slot / nby) * 8 + (blockIdx.x & 7);
+    if (bx * BM >= p_in.M) return;
+    n0 = (slot % nby) * BN;
   }
+  const int m0 = bx * BM;
 
   // ---- per-lane DMA descriptors ----
   const int lr = lane >> 2;                      // row within a 16-row DMA slab
@@ -262,6 +274,10 @@ static int launch_d(const ConvParams& p, hipStream_t s) {
   static DeviceOnce once;
   XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
   dim3 grid((unsigned)(cdiv(cdiv(p.M, BM), 8) * 8 * (p.Cout_pad / BN)));
+  if (p.group_rows) {
+    const int64_t groups = p.M / p.group_rows, tpg = (int64_t)(p.group_rows / BM) * (p.Cout_pad / BN);
+    grid = dim3((unsigned)(cdiv(groups, 8) * 8 * tpg));
+  }
   hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, p);
   XDET_LAUNCH_CHECK();
   return XDET_OK;

@@ -414,6 +414,7 @@ struct Plan {
   // a following BN+ReLU pre-activation folded into this conv's epilogue.
   int emit_planes_next = 0;
   const float *emit_bn_scale = nullptr, *emit_bn_shift = nullptr;
+  bool fuse_sepconv = true;      // option "sepconv" = "fused" | "split"
   int add_conv(const std::string& name, int stage, const Buf& in_, ConvLayer* L, const Buf* res, int relu_in, Buf* out) {
     Buf in = in_;
     const int emit = L->precision == PREC_F32 ? 0 : emit_planes_next;
@@ -522,6 +523,19 @@ struct Plan {
     XDET_TRY(fold_bn(name + "_bn", cout, eps, nullptr, &sc, &sh));
     ConvLayer* L = keep(new ConvLayer());
     XDET_TRY(L->init(1, 1, in.C, cout, 1, 1, 1, 0, 0, pk->v.data(), sc.data(), sh.data(), relu_out));
+    // Entry-flow shapes (<= 256 input channels, 128 / 256 outputs, dilation 1, no residual, f32 consumers only):
+    // ONE fused kernel, the depthwise result never leaves the CU (sepconv_fused.hip); bit-identical to the
+    // two-kernel form below, which the wide 30x30 layers keep (their GEMM needs the big MFMA tiles).
+    if (fuse_sepconv && L->dma_capable() && !res && emit_planes_next == 0 && !in.no_f32 &&
+        sepconv_fused_supported(in.ld, L->cout_pad, dilation) && L->cout_pad == L->ld_out()) {
+      XDET_TRY(new_buf(in.H, in.W, cout, out));
+      const Buf i = in, o = *out;
+      ops.push_back({name + "/fused_dw+pw", stage, L->flops(in.H, in.W), [=](int N, hipStream_t s) {
+                       return launch_sepconv_fused(i.p, D->d_w, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale, L->d_shift, o.p, N,
+                                                   i.H, i.W, i.ld, o.ld, L->cout_pad, pre_relu, L->relu_out, s);
+                     }});
+      return XDET_OK;
+    }
     Buf t;
     XDET_TRY(add_dw(name + "/depthwise", stage, in, D, pre_relu, &t, /*planes_only=*/L->dma_capable()));
     return add_conv(name + "/pointwise", stage, t, L, res, 0, out);
@@ -931,20 +945,29 @@ struct LightHeadNet : Plan {
                     hipStream_t s) {
     XDET_TRY(xception_body(images, N, s));
     // fork: the RPN branch (3x3 conv, 1x1 heads, decode, top-k, NMS -- mostly small latency-bound
-    // launches) runs on a side stream under the large-separable convs, which depend only on `out`
-    if (!aux) {
-      XDET_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-      XDET_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-      XDET_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    // launches) runs on a side stream under the large-separable convs, which depend only on `out`.
+    // While per-op profiling is on, the branch stays on the main stream: an event pair around a launch that
+    // shares the chip with the other branch's kernels would time the sharing, not the kernel.
+    if (profiling) {
+      XDET_TRY(run_stage(ST_RPN, N, s));
+      XDET_TRY(rpn_decode(N, s));
+      XDET_TRY(get_proposals(N, s));
+      XDET_TRY(run_stage(ST_LSEP, N, s));
+    } else {
+      if (!aux) {
+        XDET_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        XDET_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        XDET_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+      }
+      XDET_HIP(hipEventRecord(ev_fork, s));
+      XDET_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+      XDET_TRY(run_stage(ST_RPN, N, aux));
+      XDET_TRY(rpn_decode(N, aux));
+      XDET_TRY(get_proposals(N, aux));
+      XDET_HIP(hipEventRecord(ev_join, aux));
+      XDET_TRY(run_stage(ST_LSEP, N, s));
+      XDET_HIP(hipStreamWaitEvent(s, ev_join, 0));   // join before the head consumes the proposals
     }
-    XDET_HIP(hipEventRecord(ev_fork, s));
-    XDET_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
-    XDET_TRY(run_stage(ST_RPN, N, aux));
-    XDET_TRY(rpn_decode(N, aux));
-    XDET_TRY(get_proposals(N, aux));
-    XDET_HIP(hipEventRecord(ev_join, aux));
-    XDET_TRY(run_stage(ST_LSEP, N, s));
-    XDET_HIP(hipStreamWaitEvent(s, ev_join, 0));   // join before the head consumes the proposals
     XDET_TRY(get_head(N, s));
     XDET_TRY(head_decode(N, s));
     return bboxes_eval(N, shapes, bbox, ds, db, s);
@@ -1199,6 +1222,22 @@ int xdet_depthwise_forward(void* layer, const float* in, int N, int H, int W, in
   DeviceGuard guard(b->device);
   return static_cast<DepthwiseLayer*>(b)->forward(in, N, H, W, ld, out, relu_in, S(stream));
 }
+int xdet_sepconv_fused_forward(void* dw_layer, void* pw_layer, const float* in, int N, int H, int W, int ld_in, float* out,
+                               int ld_out, int relu_in, void* stream) {
+  LayerBase* a = static_cast<LayerBase*>(dw_layer);
+  LayerBase* b = static_cast<LayerBase*>(pw_layer);
+  XDET_REQUIRE(a && a->kind == 2 && b && b->kind == 1, "sepconv_fused: need a depthwise and a conv layer");
+  DepthwiseLayer* D = static_cast<DepthwiseLayer*>(a);
+  ConvLayer* L = static_cast<ConvLayer*>(b);
+  XDET_REQUIRE(L->dma_capable() && L->kh == 1 && L->kw == 1 && L->stride == 1 && L->groups == 1,
+               "sepconv_fused: the pointwise layer must be a 1x1 stride-1 conv created in a split-precision mode");
+  XDET_REQUIRE(D->ld == ld_in && L->ld_in() == ld_in && L->ld_out() == ld_out && L->cout_pad == ld_out &&
+                   sepconv_fused_supported(ld_in, L->cout_pad, D->dil),
+               "sepconv_fused: needs <= 256 input channels (multiple of 32), 128 or 256 outputs, dilation 1");
+  DeviceGuard guard(L->device);
+  return launch_sepconv_fused(in, D->d_w, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale, L->d_shift, out, N, H, W, ld_in, ld_out,
+                              L->cout_pad, relu_in, L->relu_out, S(stream));
+}
 int xdet_maxpool3x3s2_add(const float* in, const float* residual, float* out, int N, int H, int W, int C, int ld,
                           void* stream) {
   int Ho, Wo, pt, pl;
@@ -1271,6 +1310,11 @@ int xdet_net_set_option(void* net, const char* key, const char* value) {
   if (k == "large_sep") {
     XDET_REQUIRE(v == "auto" || v == "direct" || v == "spectral", "large_sep must be auto | direct | spectral");
     n->large_sep_mode = v == "auto" ? 0 : v == "direct" ? 1 : 2;
+    return XDET_OK;
+  }
+  if (k == "sepconv") {
+    XDET_REQUIRE(v == "fused" || v == "split", "sepconv must be fused | split");
+    n->fuse_sepconv = v == "fused";
     return XDET_OK;
   }
   set_last_error("unknown option: " + k);

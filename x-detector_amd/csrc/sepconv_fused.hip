@@ -1,0 +1,337 @@
+// Fused separable block for the entry flow: (ReLU ->) depthwise 3x3 -> pointwise 1x1 -> BN (-> ReLU) in ONE
+// kernel, "nothing in between" (net/xception_body.py:220-234).  The two-kernel form moves the depthwise result
+// through HBM as split f16 planes (4 B written + 4 B read per element); at 237x237 / 119x119 with 64..256
+// channels those layers are HBM-bound, so the round trip is a third of their time.  Here the depthwise output
+// never leaves the CU:
+//
+//   patch of the f32 input (6 x 32 pixels x 32 channels)  --buffer_load ... lds (zero fill = SAME padding)-->  LDS
+//   3x3 stencil in VALU (same FMA order as depthwise3x3_tile_kernel) -> hi/lo f16 -> LDS A tile [128 px][32 ch]
+//   A x W (K-blocked f16 hi/lo weights straight from L2 into registers)  --3 x v_mfma_f32_32x32x16_f16-->  acc
+//   after the last channel chunk: y = acc * scale + shift (folded BN), optional ReLU, f32 NHWC store
+//   (straight from the accumulators: no LDS bounce, the next tile's patch is already in flight)
+//
+// A workgroup (4 waves) walks tiles of 4 rows x 30 pixels (a 128-row GEMM tile with 8 idle rows: 30 + 2 halo
+// pixels are exactly four 1 KB DMA pieces) x 128 output channels; channel chunks of 32 are the K steps.  The
+// patch of the next (tile, chunk) is in flight while the current one is filtered and multiplied; ~73 KB of LDS
+// -> two workgroups per CU cover each other's barriers.  Arithmetic and accumulation order are exactly those
+// of depthwise3x3_tile_kernel + split + conv_dma_f16_kernel, so the result is bit-identical to the two-kernel
+// form (tests/test_gpu_layers.py).  Cout = 256 runs as two 128-wide passes over the same patch (second pass
+// from L2); wider layers (728) stay on the two-kernel path.
+#include "common.h"
+
+namespace xdet {
+
+typedef float sf_f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 sf_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sf_f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+constexpr int SF_R = 4, SF_X = 30, SF_P = 32;       // tile rows, tile width, patch pitch (pixels)
+constexpr int SF_ROWS = SF_R + 2;                   // patch rows
+constexpr int SF_PATCH_F = SF_ROWS * SF_P * 32;     // floats per patch buffer (24 KB)
+constexpr int SF_KMAX = 256;                        // input channels (dw taps live in LDS)
+constexpr int SF_BN = 128;                          // output channels per pass
+constexpr int SF_NJ = SF_ROWS * (SF_P / 8) / 4;     // DMA pieces per wave per chunk (6)
+
+struct SepFusedParams {
+  const float* in;       // NHWC f32, channel stride ld (= padded Cin, multiple of 32)
+  const float* w9c;      // depthwise taps [9][ld]
+  const u16* wt_hi;      // pointwise weights, K-blocked [ld/32][Cout_pad][32] f16 (pre-scaled hi / lo)
+  const u16* wt_lo;
+  const float* scale;    // [Cout_pad] folded BN (and weight pre-scale)
+  const float* shift;
+  float* out;            // NHWC f32, channel stride ldo
+  int N, H, W, ld, ldo, Cout_pad, relu_in, relu_out;
+  int TY, TX, NT, ntiles, tiles_per_block;
+};
+
+// LDS accesses issued while the patch prefetch (an LDS-writing DMA) is in flight.  The compiler cannot tell
+// that they never alias the DMA's target buffer and would drain vmcnt(0) in front of every one of them
+// (stalling on the prefetch each chunk), so they are issued as inline asm with explicit lgkmcnt waits.
+typedef __attribute__((address_space(3))) void* sf_lds_ptr;
+__device__ __forceinline__ unsigned sf_lds_addr(const void* p) {
+  return (unsigned)(size_t)(sf_lds_ptr)(p);
+}
+__device__ __forceinline__ void sf_ds_write_b64(unsigned addr, uint2 v) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+typedef float sf_f32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ sf_f32x4 sf_ds_read_f4(unsigned addr) {
+  sf_f32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ sf_f16x8 sf_ds_read_b128(unsigned addr) {
+  sf_f16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+
+template <bool SPLIT3>
+__global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p) {
+  __shared__ __attribute__((aligned(16))) float s_patch[2][SF_PATCH_F];
+  __shared__ __attribute__((aligned(16))) u16 s_a[2 * 128 * 32];        // A tile: hi rows, then lo rows (16 KB)
+  __shared__ __attribute__((aligned(16))) float s_w[9 * SF_KMAX];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t_begin = blockIdx.x * p.tiles_per_block;
+  const int t_end = min(p.ntiles, t_begin + p.tiles_per_block);
+  if (t_begin >= t_end) return;
+  const int KC = p.ld >> 5;                       // channel chunks = K steps
+
+  for (int i = tid; i < 9 * p.ld; i += 256) s_w[i] = p.w9c[i];
+
+  // ---- tile walk: N-pass fastest (same patch again, from L2), then ty, tx, image ----
+  struct Coord { int nt, ty, tx, n; };
+  auto advance = [&](Coord& c) {
+    if (++c.nt == p.NT) { c.nt = 0; if (++c.ty == p.TY) { c.ty = 0; if (++c.tx == p.TX) { c.tx = 0; ++c.n; } } }
+  };
+  Coord cur;
+  {
+    int q = t_begin;
+    cur.nt = q % p.NT; q /= p.NT;
+    cur.ty = q % p.TY; q /= p.TY;
+    cur.tx = q % p.TX;
+    cur.n = q / p.TX;
+  }
+
+  // ---- DMA descriptors (tile independent): piece i = wave + 4*jj moves 8 pixels x 128 B of patch row rr ----
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.ld * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.out, 0, (int)(unsigned)std::min<size_t>((size_t)p.N * p.H * p.W * p.ldo * 4, 0xffffffffull), 0x00020000);
+  // Offsets are rebuilt from wave-uniform (scalar) parts + one per-lane register each time: keeping six per-lane
+  // descriptors resident cost 12 VGPRs the stencil needs.  `live == false` issues the same six instructions
+  // with every lane out of bounds (zero fill): an unconditional instruction count keeps the compiler's vmcnt
+  // bookkeeping exact, so waiting for the weights (issued earlier) never waits for the prefetch.
+  const int px8 = lane >> 3;
+  const int lane_off = (px8 * p.ld + (lane & 7) * 4) * 4;                            // bytes
+  auto issue = [&](const Coord& c, int chunk, int buf, bool live) {
+    const int y0 = c.ty * SF_R, x0 = c.tx * SF_X;
+    const int tile_base = ((((c.n * p.H + y0) * p.W + x0) * p.ld) + chunk * 32) * 4;   // bytes, < 2^31 (host check)
+#pragma unroll
+    for (int jj = 0; jj < SF_NJ; ++jj) {
+      const int i = wave + 4 * jj;
+      const int rr = i >> 2, seg = i & 3;                                            // wave-uniform
+      const bool rok = live && (unsigned)(y0 + rr - 1) < (unsigned)p.H;
+      const bool ok = rok && (unsigned)(x0 + seg * 8 - 1 + px8) < (unsigned)p.W;
+      const int soff = tile_base + ((rr - 1) * p.W + seg * 8 - 1) * p.ld * 4;
+      const unsigned voff = ok ? (unsigned)(soff + lane_off) : 0xffffffffu;          // out of bounds -> zeros
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsrc, (__attribute__((address_space(3))) void*)(&s_patch[buf][(rr * SF_P + seg * 8) * 32]), 16, voff, 0, 0, 0);
+    }
+  };
+
+  // ---- roles ----
+  const int c4 = lane & 7, strip = lane >> 3;     // depthwise: wave = tile row, 4 pixels x 4 channels per lane
+  const int frow = lane & 31, fh = lane >> 5;     // MFMA fragments
+  const int wm = wave >> 1, wn = wave & 1;        // 2 x 2 waves over the 128 x 128 tile (64 x 64 each)
+  unsigned a_rd[2][2];                            // LDS byte address of this lane's A fragment [ks][i] (hi; lo = +8192)
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rt = wm * 64 + i * 32 + frow;
+      a_rd[ks][i] = sf_lds_addr(s_a) + (unsigned)(rt * 32 + (((ks * 2 + fh) ^ ((rt >> 2) & 3)) << 3)) * 2u;
+    }
+  // depthwise: this lane's 4 output pixels of tile row `wave` start at pxb.  Strips 0..6 own pixels 4*strip..+3;
+  // the tile is 30 wide, so strip 7 recomputes 26..29 (26, 27 duplicate strip 6's values) instead of reaching
+  // past the patch; rows 30, 31 of the A tile are never written and feed only masked output rows.
+  const int pxb = min(strip * 4, SF_X - 4);
+  const unsigned a_base = sf_lds_addr(s_a);
+
+  sf_f32x16 acc[2][2];
+  int buf = 0;
+  issue(cur, 0, 0, true);
+  for (int t = t_begin; t < t_end; ++t) {
+    Coord nxt = cur;
+    advance(nxt);
+    const int y0 = cur.ty * SF_R, x0 = cur.tx * SF_X, n0 = cur.nt * SF_BN;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // folded-BN scale/shift of this lane's two output channels: requested here, so that they are older than every
+    // prefetch of the tile and using them in the epilogue never waits for a DMA (vmcnt retires in order)
+    float esc[2], esh[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      esc[j] = p.scale[n0 + wn * 64 + j * 32 + frow];
+      esh[j] = p.shift[n0 + wn * 64 + j * 32 + frow];
+    }
+
+    for (int chunk = 0; chunk < KC; ++chunk, buf ^= 1) {
+      // patch(chunk) has landed (vmcnt(0): the DMA's LDS writes retire through vmcnt) and every wave is done with
+      // the A tile and the other patch buffer.  Explicit: the compiler sees no LDS read of s_patch (they are asm)
+      // and would not wait for the DMA at a plain __syncthreads().
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // -- this chunk's pointwise weights: L2 -> registers, issued BEFORE the DMA so that waiting for them
+      //    (vmcnt retires in order) does not wait for the prefetch --
+      sf_f16x8 bh[2][2], bl[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const size_t o = ((size_t)chunk * p.Cout_pad + (n0 + wn * 64 + j * 32 + frow)) * 32 + (ks * 2 + fh) * 8;
+          bh[ks][j] = *reinterpret_cast<const sf_f16x8*>(p.wt_hi + o);
+          if (SPLIT3) bl[ks][j] = *reinterpret_cast<const sf_f16x8*>(p.wt_lo + o);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const bool more = chunk + 1 < KC;
+        issue(more ? cur : nxt, more ? chunk + 1 : 0, buf ^ 1, more || t + 1 < t_end);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // -- depthwise 3x3, one patch row (6 pixels x 4 channels) and its three taps at a time; per output the FMA
+      //    order is ky, kx ascending = depthwise3x3_tile_kernel's --
+      const float lo_clip = p.relu_in ? 0.f : -INFINITY;
+      const unsigned t_addr = sf_lds_addr(&s_patch[buf][0]) + (unsigned)(((wave * SF_P + pxb) * 32 + c4 * 4) * 4);
+      const unsigned w_addr = sf_lds_addr(s_w) + (unsigned)((chunk * 32 + c4 * 4) * 4);
+      sf_f32x4 a[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] = (sf_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        sf_f32x4 col[6], ww[3];
+        const unsigned ra = t_addr + ky * (SF_P * 32 * 4);
+        col[0] = sf_ds_read_f4<0>(ra);   col[1] = sf_ds_read_f4<128>(ra); col[2] = sf_ds_read_f4<256>(ra);
+        col[3] = sf_ds_read_f4<384>(ra); col[4] = sf_ds_read_f4<512>(ra); col[5] = sf_ds_read_f4<640>(ra);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) ww[kx] = sf_ds_read_f4<0>(w_addr + (unsigned)((ky * 3 + kx) * p.ld * 4));
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(col[0]), "+v"(col[1]), "+v"(col[2]), "+v"(col[3]), "+v"(col[4]), "+v"(col[5]), "+v"(ww[0]),
+                       "+v"(ww[1]), "+v"(ww[2])::"memory");
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          col[k].x = fmaxf(col[k].x, lo_clip); col[k].y = fmaxf(col[k].y, lo_clip);
+          col[k].z = fmaxf(col[k].z, lo_clip); col[k].w = fmaxf(col[k].w, lo_clip);
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            a[k].x = fmaf(col[k + kx].x, ww[kx].x, a[k].x); a[k].y = fmaf(col[k + kx].y, ww[kx].y, a[k].y);
+            a[k].z = fmaf(col[k + kx].z, ww[kx].z, a[k].z); a[k].w = fmaf(col[k + kx].w, ww[kx].w, a[k].w);
+          }
+      }
+      // -- split into f16 hi/lo, A tile rows wave*32 + pxb + k (chunk-permuted like the conv kernel's DMA layout) --
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = wave * 32 + pxb + k;
+        const unsigned wa = a_base + (unsigned)(row * 32 + (((c4 >> 1) ^ ((row >> 2) & 3)) << 3) + (c4 & 1) * 4) * 2u;
+        const _Float16 h0 = (_Float16)a[k].x, h1 = (_Float16)a[k].y, h2 = (_Float16)a[k].z, h3 = (_Float16)a[k].w;
+        sf_f16x4 hv = {h0, h1, h2, h3};
+        sf_ds_write_b64(wa, *reinterpret_cast<uint2*>(&hv));
+        if (SPLIT3) {
+          sf_f16x4 lv = {(_Float16)(a[k].x - (float)h0), (_Float16)(a[k].y - (float)h1), (_Float16)(a[k].z - (float)h2),
+                         (_Float16)(a[k].w - (float)h3)};
+          sf_ds_write_b64(wa + 128 * 64, *reinterpret_cast<uint2*>(&lv));
+        }
+      }
+      // A tile visible to the workgroup: LDS writes only (lgkmcnt) -- the prefetch DMA stays in flight
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // -- pointwise: two 16-deep halves, products in the conv kernel's order (lo*hi, hi*lo, hi*hi) --
+      sf_f16x8 ah[2][2], al[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ah[ks][i] = sf_ds_read_b128<0>(a_rd[ks][i]);
+          if (SPLIT3) al[ks][i] = sf_ds_read_b128<128 * 64>(a_rd[ks][i]);
+        }
+      // one wait for all eight reads; the operands pass through it so that no MFMA can be scheduled above it
+      if (SPLIT3)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ah[0][0]), "+v"(ah[0][1]), "+v"(ah[1][0]), "+v"(ah[1][1]), "+v"(al[0][0]), "+v"(al[0][1]),
+                       "+v"(al[1][0]), "+v"(al[1][1])::"memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0][0]), "+v"(ah[0][1]), "+v"(ah[1][0]), "+v"(ah[1][1])::"memory");
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (SPLIT3) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+      }
+    }
+
+    // ---- epilogue: straight from the accumulators (no LDS: the next tile's patch is already in flight).  A lane
+    // holds one output channel (column frow) of 16 pixels of one tile row; lanes 0..31 of a store cover 128
+    // contiguous bytes.  Raw buffer stores: the row offset rides in the scalar offset, pixels outside the tile /
+    // image get an out-of-range lane offset (dropped by the bounds check) -- no branches, no 64-bit pointers. ----
+    const int lim = min(SF_X, p.W - x0) - 4 * fh;            // this lane's pixels are c + 4*fh, c = 0..3, 8..11, 16.., 24..
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int y = y0 + wm * 2 + i;                         // tile row of this 32-row accumulator block
+      if (y >= p.H) continue;                                // wave-uniform
+      const unsigned row_off = (unsigned)((((size_t)cur.n * p.H + y) * p.W + x0) * p.ldo * 4);   // < 2^32 (host check)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int co = n0 + wn * 64 + j * 32 + frow;
+        const unsigned lane_off = co < p.ldo ? (unsigned)((4 * fh * p.ldo + co) * 4) : 0xffffffffu;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          float v = fmaf(acc[i][j][r], esc[j], esh[j]);
+          if (p.relu_out) v = fmaxf(v, 0.f);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, c < lim ? lane_off : 0xffffffffu, row_off + c * p.ldo * 4, 0);
+        }
+      }
+    }
+    cur = nxt;
+  }
+}
+
+bool sepconv_fused_supported(int cin_ld, int cout_pad, int dil) {
+  return dil == 1 && cin_ld % 32 == 0 && cin_ld <= SF_KMAX && cout_pad % SF_BN == 0 && cout_pad <= 256;
+}
+
+// One launch per image range whose input stays below 2 GiB (32-bit buffer offsets of the LDS DMA).
+int launch_sepconv_fused(const float* in, const float* w9c, const unsigned short* wt_hi_blocked,
+                         const unsigned short* wt_lo_blocked, const float* scale, const float* shift, float* out, int N,
+                         int H, int W, int ld, int ldo, int cout_pad, int relu_in, int relu_out, hipStream_t s) {
+  XDET_REQUIRE(sepconv_fused_supported(ld, cout_pad, 1), "sepconv_fused: unsupported channel counts");
+  XDET_REQUIRE(in && w9c && wt_hi_blocked && scale && shift && out, "sepconv_fused: NULL argument");
+  const size_t per_image = (size_t)H * W * std::max(ld, ldo) * 4;   // input offsets are signed 32-bit, output unsigned
+  XDET_REQUIRE(per_image < ((size_t)1 << 31), "sepconv_fused: one image exceeds 2 GiB");
+  const int n_max = (int)std::max<size_t>(1, (((size_t)1 << 31) - 1) / per_image);
+  for (int nb = 0; nb < N; nb += n_max) {
+    const int n = std::min(n_max, N - nb);
+    SepFusedParams p;
+    p.in = in + (size_t)nb * H * W * ld;
+    p.w9c = w9c; p.wt_hi = wt_hi_blocked; p.wt_lo = wt_lo_blocked; p.scale = scale; p.shift = shift;
+    p.out = out + (size_t)nb * H * W * ldo;
+    p.N = n; p.H = H; p.W = W; p.ld = ld; p.ldo = ldo; p.Cout_pad = cout_pad; p.relu_in = relu_in; p.relu_out = relu_out;
+    p.TY = (int)cdiv(H, SF_R); p.TX = (int)cdiv(W, SF_X); p.NT = cout_pad / SF_BN;
+    const int64_t nt = (int64_t)n * p.TY * p.TX * p.NT;
+    p.ntiles = (int)nt;
+    const int blocks = (int)std::min<int64_t>(nt, 512);          // two workgroups per CU
+    p.tiles_per_block = (int)cdiv(nt, blocks);
+    const dim3 g((unsigned)cdiv(nt, p.tiles_per_block));
+    if (wt_lo_blocked) hipLaunchKernelGGL((sepconv_fused_kernel<true>), g, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((sepconv_fused_kernel<false>), g, dim3(256), 0, s, p);
+    XDET_LAUNCH_CHECK();
+  }
+  return XDET_OK;
+}
+
+}  // namespace xdet

@@ -15,6 +15,7 @@ SOURCES = [
     ('conv_mfma_dma.hip', []),
     ('elementwise.hip', []),
     ('spectral.hip', []),
+    ('sepconv_fused.hip', []),
     ('psroialign.hip', ['-ffp-contract=off']),
     ('proposals.hip', ['-ffp-contract=off']),
     ('detect.hip', ['-ffp-contract=off']),

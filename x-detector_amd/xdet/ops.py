@@ -153,6 +153,26 @@ class DepthwiseConv2D(object):
             pass
 
 
+class SeparableConvBN(object):
+    """relu_separable_bn_block (net/xception_body.py:220-234): (ReLU ->) depthwise 3x3 -> pointwise 1x1 -> BN
+    (folded into scale/shift) (-> ReLU), stride 1, SAME.  fused=True runs the one-kernel form
+    (xdet_sepconv_fused_forward; split-precision modes, <= 256 input channels, 128 / 256 outputs), fused=False
+    depthwise -> split planes -> pointwise, the form the wide layers of a net use; both give the same bits."""
+    def __init__(self, dw_kernel, pw_kernel, scale=None, shift=None, relu=False, dilation=1):
+        self.dw = DepthwiseConv2D(dw_kernel, dilation)
+        self.pw = Conv2D(pw_kernel, 1, 'SAME', 1, scale, shift, relu)
+
+    def __call__(self, x, relu_in=False, fused=True, stream=None):
+        N, H, W, C = x.shape
+        if not fused:
+            return self.pw(self.dw(x, relu_in=relu_in, stream=stream), stream=stream, planes=True)
+        out = DeviceTensor.empty((N, H, W, self.pw.cout))
+        check(lib().xdet_sepconv_fused_forward(self.dw.handle, self.pw.handle, x.ptr, N, H, W, x.ld, out.ptr, out.ld,
+                                               1 if relu_in else 0, stream.handle if stream else None))
+        synchronize(stream)
+        return out
+
+
 def max_pool_3x3_s2_same_add(x, residual=None, stream=None):
     N, H, W, C = x.shape
     out = DeviceTensor.empty((N, -(-H // 2), -(-W // 2), C))
