@@ -71,6 +71,9 @@ def parse():
     ap.add_argument('--comm', action='store_true',
                     help='create the RCCL communicator and all-gather the detections every step even at one rank '
                          '(always on for N > 1 and under torch.distributed.run)')
+    ap.add_argument('--serial-rpn', action='store_true',
+                    help='keep the RPN / proposal branch on the main stream (default: side stream under the '
+                         'large-separable convs): per-kernel rocprofv3 durations without cross-stream sharing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=12, help='images of the bounded CPU-oracle sample')
     ap.add_argument('--ops', action='store_true', help='also print the per-op table to stderr')
@@ -236,7 +239,8 @@ def main():
         if B % ways:
             raise SystemExit('--batch must be a multiple of --ways')
         sb = B // ways                               # images per sub-batch / net instance
-        nets = [LightHeadDetector(weights, image_size=480, max_batch=sb, rpn_post_nms_top_n=args.proposals)
+        nets = [LightHeadDetector(weights, image_size=480, max_batch=sb, rpn_post_nms_top_n=args.proposals,
+                                  rpn_stream='main' if args.serial_rpn else 'side')
                 for _ in range(ways)]
         net = nets[0]
         kind = 0

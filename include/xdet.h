@@ -184,7 +184,9 @@ int xdet_net_set_weight(void* net, const char* name, const float* data_host, int
  *   domain of the convolved axis (one GEMM per frequency bin, ~5x fewer MFMA FLOPs; needs a split-precision
  *   mode and a 16/30/50 feature map); auto = spectral when max_batch * feature_map_side >= 480, else direct.
  *   The choice is per net, never per call: results do not depend on the batch an image arrives in.
- *   "sepconv" = "fused" | "split": entry-flow separable blocks as one kernel (default) or depthwise + pointwise. */
+ *   "sepconv" = "fused" | "split": entry-flow separable blocks as one kernel (default) or depthwise + pointwise.
+ *   "rpn_stream" = "side" | "main": the RPN / proposal branch forks onto a side stream under the large-separable
+ *   convs (default) or stays on the caller's stream (per-kernel profiles without cross-stream sharing). */
 int xdet_net_set_option(void* net, const char* key, const char* value);
 int xdet_net_build(void* net);     /* folds BN, transposes/pads weights, allocates the workspace */
 int xdet_net_destroy(void* net);

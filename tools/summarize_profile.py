@@ -8,6 +8,14 @@ Writes profiles/<tag>_kernel_stats.csv (verbatim `--kernel-trace --stats` summar
 profiles/<tag>_pmc_traffic.csv (per-kernel FETCH_SIZE / WRITE_SIZE from the separate --pmc
 passes) and profiles/<tag>_summary.json (what bench.py quotes as roofline.traffic).
 
+Optional --mfma / --active dirs: separate --pmc passes of SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE; the
+summary then carries per kernel the summed counters and mfma_busy_frac = MFMA_BUSY / ((GUI_ACTIVE / 8) * 1024 SIMDs)
+(MI355X_MICROARCH.md: the counter ticks 32 cycles per v_mfma_f32_32x32x16 on the SIMD that executes it, summed
+over the 256 CUs x 4 SIMDs; rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs, i.e. 8 x the elapsed
+cycles -- both calibrated on the RPN 3x3 conv: 3.69e7 MFMAs x 32 = 1.18e9 expected, 1.14e9 counted; 1.0 ms at
+~2 GHz = 2.0e6 cycles, 15.9e6 counted), which bench.py quotes next to its arithmetic mfma_util.  source_hash identifies the kernel sources
+(bench.kernel_source_hash) so a stale summary is never quoted.
+
 HBM bytes follow MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are reported in KiB-units of
 1024 B; on gfx950 FETCH_SIZE under-counts wide coalesced reads by exactly 2x, so read bytes =
 2 * FETCH_SIZE * 1024 (applied to the 16-B-per-lane streaming kernels here); WRITE_SIZE is taken
@@ -19,6 +27,7 @@ import glob
 import json
 import os
 import shutil
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -45,6 +54,8 @@ def main():
     ap.add_argument('--stats', required=True)
     ap.add_argument('--fetch')
     ap.add_argument('--write')
+    ap.add_argument('--mfma')
+    ap.add_argument('--active')
     ap.add_argument('--tag', required=True)
     ap.add_argument('--note', default='')
     a = ap.parse_args()
@@ -69,12 +80,20 @@ def main():
             wtr = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
             wtr.writeheader()
             wtr.writerows(rows)
-    summ = {'tag': a.tag, 'command': a.note, 'kernels': {}}
+    sys.path.insert(0, ROOT)
+    import bench
+    summ = {'tag': a.tag, 'command': a.note, 'source_hash': bench.kernel_source_hash(), 'kernels': {}}
+    mf = pmc(a.mfma) if a.mfma else {}
+    ga = pmc(a.active) if a.active else {}
     for k, r in stats.items():
         e = {'calls': int(r['Calls']), 'avg_us': round(float(r['AverageNs']) / 1e3, 2), 'pct': float(r['Percentage'])}
         for row in rows:
             if row['kernel'] == k:
                 e['hbm_bytes_per_launch'] = row['hbm_bytes_per_launch']
+        if k in mf and k in ga and ga[k][1] > 0:
+            e['mfma_busy_cycles'] = mf[k][1]
+            e['gui_active_cycles'] = ga[k][1] * mf[k][0] / max(ga[k][0], 1)      # same number of launches
+            e['mfma_busy_frac'] = round(e['mfma_busy_cycles'] / (e['gui_active_cycles'] / 8.0 * 1024.0), 4)
         summ['kernels'][k] = e
     json.dump(summ, open(os.path.join(out, a.tag + '_summary.json'), 'w'), indent=1, sort_keys=True)
     print(json.dumps(summ, indent=1)[:1500])

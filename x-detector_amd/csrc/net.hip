@@ -594,6 +594,7 @@ struct LightHeadNet : Plan {
   int fmap = 0, n_anchor = 0;
   int large_sep_mode = 0;               // 0 = auto, 1 = direct (15,1)/(1,15) convs, 2 = spectral (DFT-domain GEMMs)
   bool large_sep_spectral = false;      // decided at build
+  bool rpn_side_stream = true;          // option "rpn_stream" = "side" | "main"
   hipStream_t aux = nullptr;            // side stream of the RPN/proposal branch
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   static constexpr size_t kMaxGraphs = 8;
@@ -948,7 +949,7 @@ struct LightHeadNet : Plan {
     // launches) runs on a side stream under the large-separable convs, which depend only on `out`.
     // While per-op profiling is on, the branch stays on the main stream: an event pair around a launch that
     // shares the chip with the other branch's kernels would time the sharing, not the kernel.
-    if (profiling) {
+    if (profiling || !rpn_side_stream) {
       XDET_TRY(run_stage(ST_RPN, N, s));
       XDET_TRY(rpn_decode(N, s));
       XDET_TRY(get_proposals(N, s));
@@ -1310,6 +1311,11 @@ int xdet_net_set_option(void* net, const char* key, const char* value) {
   if (k == "large_sep") {
     XDET_REQUIRE(v == "auto" || v == "direct" || v == "spectral", "large_sep must be auto | direct | spectral");
     n->large_sep_mode = v == "auto" ? 0 : v == "direct" ? 1 : 2;
+    return XDET_OK;
+  }
+  if (k == "rpn_stream") {
+    XDET_REQUIRE(v == "side" || v == "main", "rpn_stream must be side | main");
+    n->rpn_side_stream = v == "side";
     return XDET_OK;
   }
   if (k == "sepconv") {

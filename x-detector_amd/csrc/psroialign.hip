@@ -30,11 +30,16 @@ __global__ __launch_bounds__(256) void psroialign_fwd_kernel(const float* __rest
                                                              int corners) {
   const int bank = C / (gw * gh);
   const int lane = threadIdx.x & 63;
-  const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int64_t n_waves = (int64_t)N * R;
-  if (wave_id >= n_waves) return;
-  const int64_t nr = wave_id;          // n*R + r
-  const int64_t n = nr / R;
+  // XCD-aware ROI order.  Workgroups are dealt round-robin to the 8 XCDs (private L2s); with ROIs numbered
+  // straight through, every XCD ended up sampling every image's feature map (7x the map bytes over the fabric).
+  // Here image n belongs to XCD n & 7: that XCD's workgroups walk the image's ROI blocks back to back, so a map
+  // (1.8 MB at 30x30x490) crosses the fabric once and every further sample of it is an L2 hit.
+  const int bpi = (R + 3) >> 2;                        // workgroups (4 ROIs each) per image
+  const int slot = blockIdx.x >> 3;
+  const int64_t n = (int64_t)(slot / bpi) * 8 + (blockIdx.x & 7);
+  const int r_roi = (slot % bpi) * 4 + (threadIdx.x >> 6);
+  if (n >= N || r_roi >= R) return;
+  const int64_t nr = n * R + r_roi;
   const float* roi = rois + nr * 4;
   float r0 = roi[0], r1 = roi[1], r2 = roi[2], r3 = roi[3];
   if (corners) {   // _point2center, net/xception_body.py:215-218
@@ -117,9 +122,9 @@ int launch_psroialign(const float* feat, const float* rois, float* pooled, int32
   XDET_REQUIRE(C % (gw * gh) == 0, "channels must be divisible by grid_dim_width * grid_dim_height");
   XDET_REQUIRE(layout == 0 || layout == 1, "feat_layout must be 0 (NCHW) or 1 (NHWC)");
   XDET_REQUIRE(ldc >= C && out_ld >= C, "channel strides must be >= C");
-  const int64_t n_waves = (int64_t)N * R;
-  if (n_waves == 0) return XDET_OK;
-  hipLaunchKernelGGL(psroialign_fwd_kernel, dim3((unsigned)cdiv(n_waves, 4)), dim3(256), 0, s, feat, rois, pooled,
+  if ((int64_t)N * R == 0) return XDET_OK;
+  const int64_t blocks = cdiv(N, 8) * 8 * cdiv(R, 4);   // image n on XCD n & 7 (see the kernel)
+  hipLaunchKernelGGL(psroialign_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, feat, rois, pooled,
                      index, N, C, H, W, R, gw, gh, use_max, layout, layout == 0 ? C : ldc, out_ld,
                      rois_are_corners);
   XDET_LAUNCH_CHECK();

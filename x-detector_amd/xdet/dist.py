@@ -74,8 +74,18 @@ class Communicator(object):
         if self.world > 1 and not id_path:
             id_path = rendezvous_path()
         h = c_void_p()
-        check(lib().xdet_comm_init(ctypes.byref(h), self.rank, self.world,
-                                   id_path.encode() if id_path else None, int(timeout_s)))
+        # librccl prints a version banner to STDOUT when it initialises; a caller that promises "one JSON line on
+        # stdout" (bench.py) must not inherit it: fd 1 points at stderr for the duration of the init
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            check(lib().xdet_comm_init(ctypes.byref(h), self.rank, self.world,
+                                       id_path.encode() if id_path else None, int(timeout_s)))
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
         self.handle = h
         self._bufs = None
         self._turn = 0
