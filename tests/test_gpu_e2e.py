@@ -153,16 +153,36 @@ def test_other_baseline_configs(size, R, lsep, oracle, lh_weights):
     assert tr['feat'].shape == (1, fm, fm, 490)
     assert rel_err(det.buffer('feat', 1).numpy(), tr['feat']) < 1e-4
     props = det.flat('proposals', (1, R, 4))
-    # proposals as sets: with up to 5000 candidates walked, an IoU that sits within float noise of the
-    # 0.7 threshold may legitimately flip one NMS decision; count instead of demanding identity
+    # proposals as sets (two scores within float noise may swap places in the order): every proposal of the
+    # oracle's set is in the GPU's set; a mismatch is only admissible where an NMS decision sat on the threshold
     d = np.abs(props[0][:, None, :] - tr['proposals'][0][None, :, :]).max(-1)
     n_same = int((d.min(1) < TOL).sum())
-    print('size %d R %d: proposals with a match in the oracle set: %d / %d' % (size, R, n_same, R))
-    assert n_same >= R - max(2, R // 100)
+    print('size %d R %d [%s]: proposals with a match in the oracle set: %d / %d' % (size, R, lsep, n_same, R))
+    if n_same != R:
+        explain_proposal_mismatch(oracle, tr, props[0])
     total, matched, extra = match_detections(got[0], ref[0])
-    print('size %d R %d: oracle detections %d matched %d extra %d' % (size, R, total, matched, extra))
+    print('size %d R %d [%s]: oracle detections %d matched %d extra %d' % (size, R, lsep, total, matched, extra))
     assert total > (20 if size >= 480 else 0)
-    assert matched >= total - max(2, total // 50) and extra <= max(2, total // 50)
+    if n_same == R:
+        assert matched == total and extra == 0, (matched, total, extra)
+    else:       # one flipped keep/suppress decision changes a handful of head inputs
+        assert matched >= total - max(2, total // 50) and extra <= max(2, total // 50)
+
+
+def explain_proposal_mismatch(oracle, tr, gpu_props):
+    """A proposal set may differ from the oracle's ONLY through an NMS decision that sits on the 0.7 threshold:
+    a GPU-only box must have, among the oracle's proposals, a partner whose IoU with it is within 1e-5 of the
+    threshold (the suppressor that won on one side and lost on the other).  Anything else is a real bug."""
+    ref = tr['proposals'][0]
+    d = np.abs(gpu_props[:, None, :] - ref[None, :, :]).max(-1)
+    only_gpu = gpu_props[d.min(1) >= TOL]
+    assert 0 < len(only_gpu) <= 3, len(only_gpu)
+    for b in only_gpu:
+        both = np.concatenate([b[None], ref])
+        ious = np.array([oracle.iou_tf(both, 0, j) for j in range(1, len(both))])
+        near = np.abs(ious - 0.7).min()
+        print('  GPU-only proposal %s: closest oracle-side IoU to the 0.7 threshold: |IoU - 0.7| = %.2e' % (b, near))
+        assert near < 1e-5, near
 
 
 def test_net_misuse_is_reported_not_executed(lh_weights):

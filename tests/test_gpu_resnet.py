@@ -11,17 +11,18 @@ def test_resnet50_trunk_matches_oracle(oracle, precision):
     from xdet.resnet import ResNet50Trunk
     from xdet.runtime import set_precision
     w = W.make_resnet50_weights(4321)
-    imgs = W.synthetic_images(2, 480, seed=1)
+    imgs = W.synthetic_images(8, 480, seed=1)                 # BASELINE config 2: batch 8 of 480x480
     set_precision(precision)
     try:
-        net = ResNet50Trunk(w, image_size=480, max_batch=2)
+        net = ResNet50Trunk(w, image_size=480, max_batch=8)
     finally:
         set_precision('f32')
     y = net.forward(imgs)
     ref = oracle.resnet50_trunk(np.transpose(imgs, (0, 2, 3, 1)), w)
-    assert y.shape == ref.shape == (2, 15, 15, 2048)          # total stride 32 as written in the file
-    err = float(np.abs(y - ref).max())
-    assert err <= 1e-3 * max(1.0, float(np.abs(ref).max())), err
+    assert y.shape == ref.shape == (8, 15, 15, 2048)          # total stride 32 as written in the file
+    err = float(np.abs(y - ref).max()) / max(1.0, float(np.abs(ref).max()))
+    print('resnet50 trunk [%s], batch 8: max error relative to the output scale %.2e' % (precision, err))
+    assert err <= 1e-4, err                                   # 50 stacked layers, same bar as the Xception features
     assert abs(net.flops_per_image() - 37.5e9) < 0.6e9
 
 
@@ -33,4 +34,4 @@ def test_resnet50_small_image_and_batch_tail(oracle):
     net = ResNet50Trunk(w, image_size=96, max_batch=4)
     y = net.forward(imgs)                                      # N=3 < max_batch
     ref = oracle.resnet50_trunk(np.transpose(imgs, (0, 2, 3, 1)), w)
-    assert np.abs(y - ref).max() <= 1e-3 * max(1.0, float(np.abs(ref).max()))
+    assert np.abs(y - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max()))

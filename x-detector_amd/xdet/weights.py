@@ -233,5 +233,40 @@ def load_weights_npz(path, model_scope='xception_lighthead', **kw):
     return got
 
 
+def load_weights_tf_checkpoint(prefix, model_scope='xception_lighthead', verify_crc=False, **kw):
+    """Load the detector's weights straight from a TensorFlow V2 checkpoint (`<prefix>.index` +
+    `<prefix>.data-0000x-of-0000y`, e.g. the published `model.ckpt-122320`; light_head_rfcn_eval.py:499,
+    light_head_simple_demo.py:195) -- no TensorFlow needed (xdet/tf_checkpoint.py parses the bundle).  Same rules as
+    load_weights_npz: `<model_scope>/` is stripped, optimizer slots / global_step are ignored
+    (utility/train_helper.py:74-94 restores only the model variables), names and shapes are checked."""
+    from .tf_checkpoint import CheckpointReader
+    want = lighthead_variable_shapes(**kw)
+    rd = CheckpointReader(prefix)
+    got = {}
+    for full in rd.entries:
+        name = full
+        if model_scope and name.startswith(model_scope + '/'):
+            name = name[len(model_scope) + 1:]
+        if name in want:
+            a = rd.get_tensor(full, verify_crc=verify_crc)
+            if a.dtype != np.float32:
+                raise ValueError('variable %s is %s, expected float32' % (full, a.dtype))
+            if tuple(a.shape) != want[name]:
+                raise ValueError('variable %s has shape %s, expected %s' % (name, a.shape, want[name]))
+            got[name] = a
+    missing = sorted(set(want) - set(got))
+    if missing:
+        raise KeyError('checkpoint is missing %d variables, e.g. %s' % (len(missing), missing[:3]))
+    return got
+
+
+def save_weights_tf_checkpoint(prefix, weights, model_scope='xception_lighthead', global_step=None):
+    from .tf_checkpoint import write_checkpoint
+    t = {'%s/%s' % (model_scope, k): np.asarray(v, np.float32) for k, v in weights.items()}
+    if global_step is not None:
+        t['global_step'] = np.asarray(global_step, np.int64)
+    return write_checkpoint(prefix, t)
+
+
 def save_weights_npz(path, weights, model_scope='xception_lighthead'):
     np.savez(path, **{'%s/%s:0' % (model_scope, k): v for k, v in weights.items()})
