@@ -104,3 +104,41 @@ def test_bboxes_draw_on_img():
     assert np.array_equal(img[50, 20], col) and np.array_equal(img[50, 100], col)       # left / right edges
     assert not img[50, 60].any()                                                          # interior untouched
     assert not img[:, 110:].any()                                                         # class 0 and the thin box skipped
+
+
+def test_against_the_references_own_voc_eval():
+    """F4 pinned on reference-generated vectors: tests/golden/voc_eval_golden.npz holds a synthetic VOC-style set and
+    what the reference's NumPy evaluation (voc_eval.py:98-265, run verbatim by tests/golden/make_voc_eval_golden.py)
+    made of it.  The streaming matcher + PR/AP functions here must reproduce its recall / precision curves and both
+    APs.  (Boxes are pixel (xmin, ymin, xmax, ymax) there, (ymin, xmin, ymax, xmax) here: IoU does not care.)"""
+    import os
+    from xdet import evaluation as E
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'voc_eval_golden.npz'))
+    gt = g['gt']
+    n_img = int(gt[:, 0].max()) + 1
+    for ci, cls in enumerate(g['classes']):
+        label = ci + 1
+        det = g['%s_det' % cls]
+        acc = E.StreamingTpFp()
+        all_s, all_tp, all_fp, npos = [], [], [], 0
+        for im in range(n_img):
+            rows = gt[gt[:, 0] == im]
+            glabels, gdiff = rows[:, 1].astype(int), rows[:, 2].astype(int)
+            gboxes = rows[:, [4, 3, 6, 5]]
+            d = det[det[:, 0] == im]
+            d = d[np.argsort(-d[:, 1], kind='stable')]                    # per image in score order, as bboxes_eval emits
+            acc.update_image({label: (d[:, 1], d[:, [3, 2, 5, 4]])}, glabels, gboxes, gdiff, 0.5)
+            n, tp, fp = E.bboxes_matching(label, d[:, 1], d[:, [3, 2, 5, 4]], glabels, gboxes, gdiff, 0.5)
+            npos += n
+            all_s.append(d[:, 1]); all_tp.append(tp); all_fp.append(fp)
+        # the reference's curves have one point per detection, also for the ignored ones (matched to a `difficult`
+        # object: neither tp nor fp): rebuild exactly that from the matcher's per-image flags
+        order = np.argsort(-np.concatenate(all_s))
+        ctp = np.cumsum(np.concatenate(all_tp)[order].astype(np.float64))
+        cfp = np.cumsum(np.concatenate(all_fp)[order].astype(np.float64))
+        assert npos == acc.nobjects[label]
+        assert np.allclose(ctp / npos, g['%s_rec' % cls], atol=1e-12), cls
+        assert np.allclose(ctp / np.maximum(ctp + cfp, np.finfo(np.float64).eps), g['%s_prec' % cls], atol=1e-12), cls
+        ap07, ap12 = acc.average_precisions()
+        assert abs(ap07[label] - float(g['%s_ap07' % cls])) < 1e-12, (cls, ap07[label])
+        assert abs(ap12[label] - float(g['%s_ap12' % cls])) < 1e-12, (cls, ap12[label])
