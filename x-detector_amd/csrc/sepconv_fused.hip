@@ -10,7 +10,7 @@
 //   after the last channel chunk: y = acc * scale + shift (folded BN), optional ReLU, f32 NHWC store
 //   (straight from the accumulators: no LDS bounce, the next tile's patch is already in flight)
 //
-// A workgroup (4 waves) walks tiles of 4 rows x 30 pixels (a 128-row GEMM tile with 8 idle rows: 30 + 2 halo
+// A workgroup (4 waves) works on tiles of 4 rows x 30 pixels (a 128-row GEMM tile with 8 idle rows: 30 + 2 halo
 // pixels are exactly four 1 KB DMA pieces) x 128 output channels; channel chunks of 32 are the K steps.  The
 // patch of the next (tile, chunk) is in flight while the current one is filtered and multiplied; ~73 KB of LDS
 // -> two workgroups per CU cover each other's barriers.  Arithmetic and accumulation order are exactly those
@@ -78,8 +78,16 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int t_begin = blockIdx.x * p.tiles_per_block;
-  const int t_end = min(p.ntiles, t_begin + p.tiles_per_block);
+  // Tile schedule.  Workgroups are dealt round-robin to the 8 XCDs (private 4 MB L2s).  XCD x owns the contiguous
+  // tile band [x*per_xcd, (x+1)*per_xcd); its resident workgroups take the band's tiles in an interleaved order
+  // (workgroup j: tiles j, j+G, j+2G, ...), so at any moment one XCD works on ~G CONSECUTIVE tiles: vertical
+  // neighbours (shared halo rows) and the two 128-channel passes of a tile read the same input lines within
+  // microseconds of each other and meet in that XCD's L2.  (A workgroup walking consecutive tiles by itself found
+  // its halo rows evicted by the time it came back to them: 1.6x / 3.1x input bytes over the fabric.)
+  const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, G = gridDim.x >> 3;
+  const int per_xcd = (p.ntiles + 7) >> 3;
+  const int t_begin = xcd * per_xcd + wg;
+  const int t_end = min(p.ntiles, (xcd + 1) * per_xcd);
   if (t_begin >= t_end) return;
   const int KC = p.ld >> 5;                       // channel chunks = K steps
 
@@ -87,19 +95,18 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
 
   // ---- tile walk: N-pass fastest (same patch again, from L2), then ty, tx, image ----
   struct Coord { int nt, ty, tx, n; };
-  auto advance = [&](Coord& c) {
-    if (++c.nt == p.NT) { c.nt = 0; if (++c.ty == p.TY) { c.ty = 0; if (++c.tx == p.TX) { c.tx = 0; ++c.n; } } }
+  auto decode = [&](int q) {
+    Coord c;
+    c.nt = q % p.NT; q /= p.NT;
+    c.ty = q % p.TY; q /= p.TY;
+    c.tx = q % p.TX;
+    c.n = q / p.TX;
+    return c;
   };
-  Coord cur;
-  {
-    int q = t_begin;
-    cur.nt = q % p.NT; q /= p.NT;
-    cur.ty = q % p.TY; q /= p.TY;
-    cur.tx = q % p.TX;
-    cur.n = q / p.TX;
-  }
+  Coord cur = decode(t_begin);
 
-  // ---- DMA descriptors (tile independent): piece i = wave + 4*jj moves 8 pixels x 128 B of patch row rr ----
+  // ---- DMA descriptors: piece i = wave + 4*jj moves 8 pixels x 128 B of patch row rr (raw buffer loads over the
+  //      whole input tensor; a lane that must read padding is sent out of bounds and gets zeros) ----
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.ld * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -147,9 +154,8 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
   sf_f32x16 acc[2][2];
   int buf = 0;
   issue(cur, 0, 0, true);
-  for (int t = t_begin; t < t_end; ++t) {
-    Coord nxt = cur;
-    advance(nxt);
+  for (int t = t_begin; t < t_end; t += G) {
+    const Coord nxt = decode(min(t + G, p.ntiles - 1));
     const int y0 = cur.ty * SF_R, x0 = cur.tx * SF_X, n0 = cur.nt * SF_BN;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
       __builtin_amdgcn_sched_barrier(0);
       {
         const bool more = chunk + 1 < KC;
-        issue(more ? cur : nxt, more ? chunk + 1 : 0, buf ^ 1, more || t + 1 < t_end);
+        issue(more ? cur : nxt, more ? chunk + 1 : 0, buf ^ 1, more || t + G < t_end);
       }
       __builtin_amdgcn_sched_barrier(0);
       // -- depthwise 3x3, one patch row (6 pixels x 4 channels) and its three taps at a time; per output the FMA
@@ -324,9 +330,9 @@ int launch_sepconv_fused(const float* in, const float* w9c, const unsigned short
     p.TY = (int)cdiv(H, SF_R); p.TX = (int)cdiv(W, SF_X); p.NT = cout_pad / SF_BN;
     const int64_t nt = (int64_t)n * p.TY * p.TX * p.NT;
     p.ntiles = (int)nt;
-    const int blocks = (int)std::min<int64_t>(nt, 512);          // two workgroups per CU
-    p.tiles_per_block = (int)cdiv(nt, blocks);
-    const dim3 g((unsigned)cdiv(nt, p.tiles_per_block));
+    p.tiles_per_block = 0;
+    // two workgroups per CU (LDS); a multiple of 8 so that every XCD gets the same number
+    const dim3 g((unsigned)std::min<int64_t>(512, cdiv(nt, 8) * 8));
     if (wt_lo_blocked) hipLaunchKernelGGL((sepconv_fused_kernel<true>), g, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((sepconv_fused_kernel<false>), g, dim3(256), 0, s, p);
     XDET_LAUNCH_CHECK();

@@ -84,6 +84,10 @@ class Communicator(object):
             check(lib().xdet_comm_init(ctypes.byref(h), self.rank, self.world,
                                        id_path.encode() if id_path else None, int(timeout_s)))
         finally:
+            try:
+                ctypes.CDLL(None).fflush(None)     # the banner sits in libc's stdout buffer until flushed
+            except Exception:
+                pass
             os.dup2(saved, 1)
             os.close(saved)
         self.handle = h
