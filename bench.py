@@ -158,8 +158,13 @@ def cpu_baseline(args, weights):
             cores = max([d.get('num_threads', 1) for d in threadpool_info()] or [os.cpu_count()])
         except Exception:
             cores = os.cpu_count()
-    return {'value': round(n / dt, 3), 'unit': 'images/sec', 'cores': int(cores), 'kind': 'port', 'sample': what,
-            'host': {'nproc': os.cpu_count(), 'cpu': cpu_model()}}
+    out = {'value': round(n / dt, 3), 'unit': 'images/sec', 'cores': int(cores), 'kind': 'port', 'sample': what,
+           'host': {'nproc': os.cpu_count(), 'cpu': cpu_model()}}
+    if args.workload == 'lighthead' and getattr(O, '_fast_cache', None):
+        tun = getattr(next(iter(O._fast_cache.values())), 'tuning', None)
+        if tun:
+            out['thread_sweep_s_per_image'] = {str(k): round(v, 3) for k, v in tun.items()}
+    return out
 
 
 def counters_from_profiles(precision, src_hash):

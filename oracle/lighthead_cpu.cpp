@@ -503,6 +503,7 @@ int lhcpu_forward(void* net, const float* images_nchw, int N, float* det_scores,
   return 0;
 }
 int lhcpu_threads(void) { return omp_get_max_threads(); }
+void lhcpu_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 void lhcpu_destroy(void* net) { delete static_cast<Net*>(net); }
 
 }  // extern "C"

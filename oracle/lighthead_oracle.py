@@ -416,6 +416,9 @@ class CppForward(object):
     def __init__(self, w, image_size=480, rpn_post_nms_top_n=300):
         global _cpp
         if _cpp is None:
+            # a blocked OpenMP thread should sleep, not spin: the box may expose more hardware threads than the
+            # container may use (256 on the GPU box), and spinning waiters then starve the workers
+            os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')
             _cpp = ctypes.CDLL(build_cpp_baseline())
             _cpp.lhcpu_create.restype = ctypes.c_void_p
             _cpp.lhcpu_error.restype = ctypes.c_char_p
@@ -428,6 +431,25 @@ class CppForward(object):
             raise RuntimeError(_cpp.lhcpu_error(self.h).decode())
         self.S = image_size
         self.threads = int(_cpp.lhcpu_threads())
+
+    def set_threads(self, n):
+        _cpp.lhcpu_set_threads(int(n))
+        self.threads = int(_cpp.lhcpu_threads())
+
+    def tune_threads(self, image, candidates=(16, 32, 64, 128, 256)):
+        """pick the OpenMP thread count that runs one forward fastest on THIS box (a CPU baseline should be the
+        box's best, not whatever omp_get_max_threads() reports inside a container); returns {threads: seconds}"""
+        import time
+        hw = os.cpu_count() or 1
+        seen = {}
+        for n in sorted(set(min(c, hw) for c in candidates)):
+            self.set_threads(n)
+            self(image)
+            t = time.time()
+            self(image)
+            seen[n] = time.time() - t
+        self.set_threads(min(seen, key=seen.get))
+        return seen
 
     def __call__(self, images_nchw):
         x = np.ascontiguousarray(images_nchw, np.float32)
@@ -455,7 +477,9 @@ def lighthead_forward_fast(images_nchw, w, rpn_post_nms_top_n=300):
     key = (id(w), int(rpn_post_nms_top_n), int(images_nchw.shape[2]))
     if key not in _fast_cache:
         _fast_cache.clear()
-        _fast_cache[key] = CppForward(w, images_nchw.shape[2], rpn_post_nms_top_n)
+        f = CppForward(w, images_nchw.shape[2], rpn_post_nms_top_n)
+        f.tuning = f.tune_threads(images_nchw[:1])
+        _fast_cache[key] = f
     return _fast_cache[key](images_nchw)
 
 

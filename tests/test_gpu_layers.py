@@ -185,12 +185,16 @@ def test_maxpool_same_padding_asymmetry(H, W, oracle):
     assert np.array_equal(y0, ref)
 
 
-@pytest.mark.parametrize('mag', [1e-4, 1e-2, 1.0, 1e2, 2e4])
-def test_split_precision_holds_across_activation_magnitudes(mag, oracle):
-    """x = hi + lo with f16 parts: hi overflows above 65504 and lo goes subnormal below ~0.1.  Inside this network
-    activations are O(1)..O(100) (BN after every contraction, DFT bins <= 30x the signal); this pins what the f16x3
-    path does away from that range: f32-class relative accuracy from 1e-4 to 2e4 (the MFMA consumes f16 subnormals,
-    so a small lo degrades gracefully to an ABSOLUTE error of ~2^-25 per element)."""
+@pytest.mark.parametrize('mag', [1e-4, 1e-2, 1.0, 1e2, 3e3, 2e4])
+def test_split_precision_across_activation_magnitudes(mag, oracle):
+    """x = hi + lo with f16 parts.  Inside this network activations are O(1)..O(100) (BN after every contraction, DFT
+    bins <= 30x the signal); this pins what the f16x3 path does away from that range:
+      * 1e-2 .. 3e3 (elements up to ~1e4): f32-class accuracy relative to the output scale;
+      * a tensor that is small as a whole (1e-4): lo = x - hi falls below f16's normal range (2^-14) and degrades
+        gracefully to an ABSOLUTE error of ~2^-25 per element -- ~2e-4 relative for such a tensor;
+      * elements beyond f16's 65504: hi overflows and the result is not finite.  No layer of the net comes near
+        either end with BN-normalised activations; a checkpoint that does needs a power-of-two activation
+        pre-scale in the producing epilogue (not built)."""
     from xdet.ops import Conv2D
     from xdet.runtime import DeviceTensor, set_precision
     rng = np.random.default_rng(17)
@@ -202,7 +206,10 @@ def test_split_precision_holds_across_activation_magnitudes(mag, oracle):
         y = Conv2D(k, 1, 'SAME')(DeviceTensor.from_numpy(x), planes=True).numpy()
     finally:
         set_precision('f32')
+    if np.abs(x).max() > 65504:
+        assert not np.isfinite(y).all()                    # documented: overflow is loud (inf / nan), never silent
+        return
     err = float(np.abs(y - ref).max()) / float(np.abs(ref).max())
     print('activation magnitude %g: f16x3 error relative to the output scale %.2e' % (mag, err))
     assert np.isfinite(y).all()
-    assert err < 1e-4, err
+    assert err < (1e-3 if mag < 1e-3 else 3e-5), err
