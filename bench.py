@@ -76,6 +76,7 @@ def parse():
                          'large-separable convs): per-kernel rocprofv3 durations without cross-stream sharing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=200, help='images of the bounded CPU-baseline sample (~10-20 s)')
+    ap.add_argument('--cpu-batch', type=int, default=8, help='images per call of the C++ CPU baseline')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='time budget of the CPU-baseline sample')
     ap.add_argument('--ops', action='store_true', help='also print the per-op table to stderr')
     ap.add_argument('--no-parity', action='store_true', help='skip the live f16x3-vs-f32 GPU cross-check')
@@ -128,16 +129,17 @@ def cpu_baseline(args, weights):
     if args.workload == 'lighthead':
         fwd = getattr(O, 'lighthead_forward_fast', None) or O.lighthead_forward
         how = getattr(O, 'FAST_PATH_DESCRIPTION', 'NumPy fp32 + OpenBLAS')
-        imgs = W.synthetic_images(1, 480, seed=11)
-        fwd(imgs, weights, rpn_post_nms_top_n=args.proposals)      # warm-up (page-in, weight packing, thread pool)
+        cb = max(1, args.cpu_batch)                                # images per call: more parallel work per layer
+        imgs = W.synthetic_images(cb, 480, seed=11)
+        fwd(imgs, weights, rpn_post_nms_top_n=args.proposals)      # warm-up (page-in, weight packing, thread sweep)
         t = time.time()
         done = 0
         while done < n and (done < 3 or time.time() - t < args.cpu_seconds):     # bounded sample: ~cpu_seconds of CPU work
-            fwd(W.synthetic_images(1, 480, seed=20 + done), weights, rpn_post_nms_top_n=args.proposals)
-            done += 1
+            fwd(W.synthetic_images(cb, 480, seed=20 + done), weights, rpn_post_nms_top_n=args.proposals)
+            done += cb
         dt = time.time() - t
         n = done
-        what = '%d x one 480x480 image through the full forward (R=%d), %s' % (n, args.proposals, how)
+        what = '%d 480x480 images (batches of %d) through the full forward (R=%d), %s' % (n, cb, args.proposals, how)
     else:
         x = np.transpose(W.synthetic_images(1, 480, seed=11), (0, 2, 3, 1))
         O.resnet50_trunk(x, weights)

@@ -478,7 +478,7 @@ def lighthead_forward_fast(images_nchw, w, rpn_post_nms_top_n=300):
     if key not in _fast_cache:
         _fast_cache.clear()
         f = CppForward(w, images_nchw.shape[2], rpn_post_nms_top_n)
-        f.tuning = f.tune_threads(images_nchw[:1])
+        f.tuning = f.tune_threads(images_nchw)
         _fast_cache[key] = f
     return _fast_cache[key](images_nchw)
 
