@@ -76,6 +76,15 @@ __global__ __launch_bounds__(256) void psroialign_fwd_kernel(const float* __rest
   const double half_w = (double)step_w / 2.;
   const double half_h = (double)step_h / 2.;
 
+  // The kernel is VALU-bound (a per-sample f64 blend plus index arithmetic; fetch traffic and load count were
+  // both ruled out by measurement), so everything that does not depend on the sample row is hoisted: 32-bit element
+  // offsets from a per-image base pointer, and the x geometry of a bin's <= JMAX sample columns (integer columns,
+  // fractions and their double-precision weights 1.-fx / fx) once per element instead of once per sample.  Every
+  // expression keeps the reference's typing and order: (1.-fx)*(1.-fy)*f00 + (1.-fx)*fy*f10 + fx*(1.-fy)*f01 in
+  // double, fx*fy*f11 in float, summed left to right.
+  constexpr int JMAX = 8;
+  const int sy = layout == 0 ? W : W * ldc, sx = layout == 0 ? 1 : ldc, sc = layout == 0 ? H * W : 1;
+  const float* __restrict__ fimg = feat + (size_t)n * H * W * ldc;       // NCHW: ldc == C
   for (int e = lane; e < C; e += 64) {
     const int pos = e / bank;
     const int row = pos / gw;
@@ -85,25 +94,65 @@ __global__ __launch_bounds__(256) void psroialign_fwd_kernel(const float* __rest
     const float y0 = ymin + bin_h * (float)row;
     float acc = use_max ? -FLT_MAX : 0.f;
     int arg = 0;
-    for (int i = 0; i < n_h; ++i) {
-      const float y = (float)((double)(y0 + step_h * (float)i) + half_h);
-      const int iy = (int)y;
-      const float fy = y - (float)iy;
-      const int iy1 = min(iy + 1, H - 1);
-      for (int j = 0; j < n_w; ++j) {
-        const float x = (float)((double)(x0 + step_w * (float)j) + half_w);
-        const int ix = (int)x;
-        const float fx = x - (float)ix;
-        const int ix1 = min(ix + 1, W - 1);
-        const double v = (1. - fx) * (1. - fy) * feat_at(feat, layout, ldc, H, W, n, c_in, iy, ix) +
-                         (1. - fx) * fy * feat_at(feat, layout, ldc, H, W, n, c_in, iy1, ix) +
-                         fx * (1. - fy) * feat_at(feat, layout, ldc, H, W, n, c_in, iy, ix1) +
-                         fx * fy * feat_at(feat, layout, ldc, H, W, n, c_in, iy1, ix1);
-        const float t = (float)v;
-        if (use_max) {
-          if (acc < t) { acc = t; arg = n_w * i + j; }
-        } else {
-          acc += t;
+    if (n_w <= JMAX) {
+      const int coff = c_in * sc;
+      int xo0[JMAX], xo1[JMAX];
+      float fxs[JMAX];
+      double wx0[JMAX], wx1[JMAX];
+#pragma unroll
+      for (int j = 0; j < JMAX; ++j) {
+        if (j < n_w) {                   // wave-uniform
+          const float x = (float)((double)(x0 + step_w * (float)j) + half_w);
+          const int ix = (int)x;
+          const float fx = x - (float)ix;
+          xo0[j] = ix * sx + coff;
+          xo1[j] = min(ix + 1, W - 1) * sx + coff;
+          fxs[j] = fx;
+          wx0[j] = 1. - fx;
+          wx1[j] = fx;
+        }
+      }
+      for (int i = 0; i < n_h; ++i) {
+        const float y = (float)((double)(y0 + step_h * (float)i) + half_h);
+        const int iy = (int)y;
+        const float fy = y - (float)iy;
+        const int yo0 = iy * sy, yo1 = min(iy + 1, H - 1) * sy;
+        const double wy0 = 1. - fy, wy1 = fy;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+          if (j < n_w) {
+            const float f00 = fimg[yo0 + xo0[j]], f10 = fimg[yo1 + xo0[j]], f01 = fimg[yo0 + xo1[j]], f11 = fimg[yo1 + xo1[j]];
+            const double v = wx0[j] * wy0 * f00 + wx0[j] * wy1 * f10 + wx1[j] * wy0 * f01 + fxs[j] * fy * f11;
+            const float t = (float)v;
+            if (use_max) {
+              if (acc < t) { acc = t; arg = n_w * i + j; }
+            } else {
+              acc += t;
+            }
+          }
+        }
+      }
+    } else {
+      for (int i = 0; i < n_h; ++i) {
+        const float y = (float)((double)(y0 + step_h * (float)i) + half_h);
+        const int iy = (int)y;
+        const float fy = y - (float)iy;
+        const int iy1 = min(iy + 1, H - 1);
+        for (int j = 0; j < n_w; ++j) {
+          const float x = (float)((double)(x0 + step_w * (float)j) + half_w);
+          const int ix = (int)x;
+          const float fx = x - (float)ix;
+          const int ix1 = min(ix + 1, W - 1);
+          const double v = (1. - fx) * (1. - fy) * feat_at(feat, layout, ldc, H, W, n, c_in, iy, ix) +
+                           (1. - fx) * fy * feat_at(feat, layout, ldc, H, W, n, c_in, iy1, ix) +
+                           fx * (1. - fy) * feat_at(feat, layout, ldc, H, W, n, c_in, iy, ix1) +
+                           fx * fy * feat_at(feat, layout, ldc, H, W, n, c_in, iy1, ix1);
+          const float t = (float)v;
+          if (use_max) {
+            if (acc < t) { acc = t; arg = n_w * i + j; }
+          } else {
+            acc += t;
+          }
         }
       }
     }
