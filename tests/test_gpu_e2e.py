@@ -87,6 +87,52 @@ def match_detections(got, ref, tol=TOL):
     return total, matched, extra
 
 
+def iou(a, b):
+    ih = max(min(a[2], b[2]) - max(a[0], b[0]), 0.0)
+    iw = max(min(a[3], b[3]) - max(a[1], b[1]), 0.0)
+    ua = (a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - ih * iw
+    return ih * iw / ua if ua > 0 else 0.0
+
+
+def assert_match_or_score_tie(got, ref, nms_thr=0.3, tol=TOL, tie=2e-5):
+    """Every oracle detection must be matched by a distinct GPU detection within `tol` and vice versa -- EXCEPT in a
+    class list where the greedy per-class NMS met a score tie: two overlapping candidates (IoU > nms_thr) whose scores
+    differ by less than the float noise of the scores (`tie`; the feature maps agree to ~1e-5) may be visited in
+    either order, the first one suppresses the other, and the keep set behind them changes.  Such a list is accepted
+    only if that pair is actually found (an oracle-only and a GPU-only detection with near-equal scores that suppress
+    each other) and every other differing detection overlaps a differing detection of the other side (knock-on of
+    the swap).  Returns (total, matched, lists explained by a tie)."""
+    total = matched = ties = 0
+    for c in ref:
+        gs, gb = got[c]
+        rs, rb = ref[c]
+        kg, kr = int((gs > 0).sum()), int((rs > 0).sum())
+        assert np.all(gs[kg:] == 0) and np.all(gb[kg:] == 0)
+        used = np.zeros(kg, bool)
+        un = []
+        for j in range(kr):
+            d = np.where(used, np.inf, np.maximum(np.abs(gs[:kg] - rs[j]), np.abs(gb[:kg] - rb[j]).max(1))) if kg else np.array([np.inf])
+            if d.min() < tol:
+                used[int(d.argmin())] = True
+                matched += 1
+            else:
+                un.append(j)
+        ex = [k for k in range(kg) if not used[k]]
+        total += kr
+        if not un and not ex:
+            continue
+        seeds = [(j, k) for j in un for k in ex if abs(float(rs[j]) - float(gs[k])) < tie and iou(rb[j], gb[k]) > nms_thr]
+        assert seeds, ('class %d differs without a score tie' % c, [(float(rs[j]), rb[j].tolist()) for j in un],
+                       [(float(gs[k]), gb[k].tolist()) for k in ex])
+        assert len(un) + len(ex) <= 8, (c, len(un), len(ex))
+        for j in un:
+            assert any(iou(rb[j], gb[k]) > nms_thr for k in ex), (c, 'oracle-only detection not explained', float(rs[j]))
+        for k in ex:
+            assert any(iou(gb[k], rb[j]) > nms_thr for j in un), (c, 'gpu-only detection not explained', float(gs[k]))
+        ties += 1
+    return total, matched, ties
+
+
 def test_detections_within_1e3(run):
     det, got, ref, tr, _ = run
     total = matched = extra = 0

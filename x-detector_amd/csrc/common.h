@@ -104,6 +104,8 @@ int launch_depthwise3x3(const float* in, const float* w9c, float* out, int N, in
 int launch_maxpool3x3s2_add(const float* in, const float* res, float* out, int N, int H, int W, int C, int ld,
                             int Ho, int Wo, int pad_t, int pad_l, hipStream_t s);
 int launch_relu_copy(const float* in, float* out, int64_t n, hipStream_t s);
+int launch_stem_conv3x3s2(const float* in_nchw, const float* w27x32, const float* scale, const float* shift,
+                          unsigned short* hi, unsigned short* lo, int N, int S, hipStream_t s);
 int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, int64_t n_pix, int ld, int relu,
                      hipStream_t s);
 int launch_depthwise3x3_split(const float* in, const float* w9c, unsigned short* hi, unsigned short* lo, int N,

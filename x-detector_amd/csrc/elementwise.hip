@@ -456,4 +456,68 @@ int launch_relu_copy(const float* in, float* out, int64_t n, hipStream_t s) {
   return XDET_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Stem conv of the Xception entry (block1_conv1, net/xception_body.py:243-250): 3x3 / stride 2 / VALID, 3 -> 32
+// channels, inference BN + ReLU, straight from the NCHW network input to the split f16 planes its only consumer
+// (block1_conv2 on the LDS-DMA path) reads.  K = 27: no matrix-core shape fits, and the generic small-cin MFMA
+// kernel spent its time gathering 16-byte NHWC4 pixels (16 TFLOP/s, 0.38 ms per 64 images) behind a separate
+// NCHW -> NHWC4 pass.  Here one thread owns one output pixel and all 32 channels: 27 coalesced loads (lanes =
+// consecutive output columns, stride-2 input columns), 864 f32 FMAs against weights that are wave-uniform and come
+// through the scalar cache, exact f32 accumulation in (ky, kx, ci) order, then hi/lo f16: each lane writes its
+// pixel's 64 contiguous bytes per plane.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_conv3x3s2_kernel(const float* __restrict__ in_nchw,
+                                                             const float* __restrict__ w /*[27][32], k = (ky*3+kx)*3+ci*/,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+                                                             int N, int S, int Ho, int Wo) {
+  const int64_t total = (int64_t)N * Ho * Wo;
+  const int64_t pix = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (pix >= total) return;
+  const int n = (int)(pix / ((int64_t)Ho * Wo));
+  const int rem = (int)(pix - (int64_t)n * Ho * Wo);
+  const int oy = rem / Wo, ox = rem - oy * Wo;
+  const float* base = in_nchw + (size_t)n * 3 * S * S + (size_t)(oy * 2) * S + ox * 2;
+  float acc[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) {
+        const float x = base[(size_t)ci * S * S + ky * S + kx];
+        const float* wk = w + ((ky * 3 + kx) * 3 + ci) * 32;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) acc[c] = fmaf(x, wk[c], acc[c]);
+      }
+  const size_t o = ((size_t)(pix >> 4) << 9) + ((pix & 15) << 5);          // [pix/16][1][16][32]
+#pragma unroll
+  for (int c8 = 0; c8 < 4; ++c8) {
+    _Float16 h[8], l[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = c8 * 8 + k;
+      const float v = fmaxf(fmaf(acc[c], scale[c], shift[c]), 0.f);
+      h[k] = (_Float16)v;
+      l[k] = (_Float16)(v - (float)h[k]);
+    }
+    *reinterpret_cast<uint4*>(hi + o + c8 * 8) = *reinterpret_cast<uint4*>(h);
+    *reinterpret_cast<uint4*>(lo + o + c8 * 8) = *reinterpret_cast<uint4*>(l);
+  }
+}
+
+int launch_stem_conv3x3s2(const float* in_nchw, const float* w27x32, const float* scale, const float* shift,
+                          unsigned short* hi, unsigned short* lo, int N, int S, hipStream_t s) {
+  const int Ho = (S - 3) / 2 + 1;
+  const int64_t total = (int64_t)N * Ho * Ho;
+  if (total == 0) return XDET_OK;
+  hipLaunchKernelGGL(stem_conv3x3s2_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, in_nchw, w27x32, scale, shift,
+                     hi, lo, N, S, Ho, Ho);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
 }  // namespace xdet

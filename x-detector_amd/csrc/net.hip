@@ -595,6 +595,8 @@ struct LightHeadNet : Plan {
   int large_sep_mode = 0;               // 0 = auto, 1 = direct (15,1)/(1,15) convs, 2 = spectral (DFT-domain GEMMs)
   bool large_sep_spectral = false;      // decided at build
   bool rpn_side_stream = true;          // option "rpn_stream" = "side" | "main"
+  bool stem_direct = false;             // block1_conv1 as the dedicated NCHW -> planes kernel
+  const float* cur_images = nullptr;
   hipStream_t aux = nullptr;            // side stream of the RPN/proposal branch
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   static constexpr size_t kMaxGraphs = 8;
@@ -611,8 +613,32 @@ struct LightHeadNet : Plan {
     in4.H = S; in4.W = S; in4.C = 3;
     XDET_TRY(new_buf(S, S, 3, &in4));
     Buf x, r, t;
-    emit_planes_next = 3;   // feeds block1_conv2 (LDS-DMA path) only
-    XDET_TRY(conv_bn("block1_conv1", "block1_conv1_bn", eps, ST_BODY, in4, 3, 32, 2, 0, 1, nullptr, 0, &x));
+    if (g_default_precision != PREC_F32) {
+      // stem conv straight from the NCHW input to the planes block1_conv2 reads (elementwise.hip): K = 27 fits no
+      // matrix-core shape, a VALU kernel with scalar-cache weights is HBM-bound instead of gather-bound
+      const HostTensor* kt;
+      XDET_TRY(need("block1_conv1/kernel", &kt, {3, 3, 3, 32}));
+      std::vector<float> sc, sh;
+      XDET_TRY(fold_bn("block1_conv1_bn", 32, eps, nullptr, &sc, &sh));
+      float *d_w, *d_sc, *d_sh;
+      XDET_TRY(alloc_bytes(kt->v.size() * 4, reinterpret_cast<void**>(&d_w), false));
+      XDET_TRY(alloc_bytes(32 * 4, reinterpret_cast<void**>(&d_sc), false));
+      XDET_TRY(alloc_bytes(32 * 4, reinterpret_cast<void**>(&d_sh), false));
+      XDET_HIP(hipMemcpy(d_w, kt->v.data(), kt->v.size() * 4, hipMemcpyHostToDevice));
+      XDET_HIP(hipMemcpy(d_sc, sc.data(), 32 * 4, hipMemcpyHostToDevice));
+      XDET_HIP(hipMemcpy(d_sh, sh.data(), 32 * 4, hipMemcpyHostToDevice));
+      x = Buf();
+      x.H = x.W = (S - 3) / 2 + 1; x.C = 32; x.ld = 32; x.no_f32 = true;
+      XDET_TRY(new_planes(&x));
+      const Buf o = x;
+      stem_direct = true;
+      ops.push_back({"block1_conv1 [stem, NCHW in]", ST_BODY, 2.0 * o.H * o.W * 27.0 * 32.0, [=](int N, hipStream_t st) {
+                       return launch_stem_conv3x3s2(cur_images, d_w, d_sc, d_sh, o.hi, o.lo, N, S, st);
+                     }});
+    } else {
+      emit_planes_next = 3;   // feeds block1_conv2 (LDS-DMA path) only
+      XDET_TRY(conv_bn("block1_conv1", "block1_conv1_bn", eps, ST_BODY, in4, 3, 32, 2, 0, 1, nullptr, 0, &x));
+    }
     XDET_TRY(conv_bn("block1_conv2", "block1_conv2_bn", eps, ST_BODY, x, 3, 64, 1, 0, 1, nullptr, 0, &t));
     x = t;
     struct Blk { const char* res; const char* bn; const char* s1; const char* s2; int c; int first_relu; };
@@ -911,7 +937,8 @@ struct LightHeadNet : Plan {
   int xception_body(const float* images, int N, hipStream_t s) {
     XDET_TRY(check(N));
     XDET_REQUIRE(images != nullptr, "images is NULL");
-    XDET_TRY(launch_nchw_to_nhwc4(images, in4.p, N, 3, cfg.image_size, cfg.image_size, 4, s));
+    cur_images = images;         // the stem op reads the NCHW input directly (graphs are keyed on this pointer)
+    if (!stem_direct) XDET_TRY(launch_nchw_to_nhwc4(images, in4.p, N, 3, cfg.image_size, cfg.image_size, 4, s));
     return run_stage(ST_BODY, N, s);
   }
   int rpn_decode(int N, hipStream_t s) {
