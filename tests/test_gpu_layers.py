@@ -213,3 +213,30 @@ def test_split_precision_across_activation_magnitudes(mag, oracle):
     print('activation magnitude %g: f16x3 error relative to the output scale %.2e' % (mag, err))
     assert np.isfinite(y).all()
     assert err < (1e-3 if mag < 1e-3 else 3e-5), err
+
+
+def test_fused_separable_block_beyond_2gib():
+    """75 images of 237 x 237 x 128 are 2.16 GB in and 2.16 GB out: the fused kernel's LDS DMA uses 32-bit buffer
+    offsets, so the launcher cuts the batch into image ranges below 2 GiB (74 + 1 here).  Both forms must still agree
+    bit for bit, including across the cut."""
+    from xdet.ops import SeparableConvBN
+    from xdet.runtime import DeviceTensor, set_precision
+    N, H, W, cin, cout = 75, 237, 237, 128, 128
+    rng = np.random.default_rng(5)
+    one = rng.standard_normal((3, H, W, cin)).astype(np.float32)
+    x = np.concatenate([one] * 25)                       # 75 images from 3 distinct ones: the answer must repeat too
+    dk = rng.standard_normal((3, 3, cin, 1)).astype(np.float32) / 3
+    pk = (rng.standard_normal((1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    set_precision('f16x3')
+    try:
+        op = SeparableConvBN(dk, pk, None, None, relu=False)
+    finally:
+        set_precision('f32')
+    xd = DeviceTensor.from_numpy(x)
+    del x
+    y = op(xd, relu_in=True, fused=True).numpy()
+    assert np.isfinite(y).all()
+    for k in range(1, 25):
+        assert np.array_equal(y[3 * k:3 * k + 3], y[:3]), k      # images 72..74 and 75th sit across / behind the cut
+    y3 = op(DeviceTensor.from_numpy(one), relu_in=True, fused=False).numpy()
+    assert np.array_equal(y[:3], y3)
