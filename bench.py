@@ -103,11 +103,14 @@ def read_profile(handle, kind):
     cnt = (ctypes.c_int * maxo)()
     fl = (ctypes.c_double * maxo)()
     check(lib().xdet_profile_read(handle, kind, maxo, ctypes.byref(n), ms, cnt, fl))
+    issued = (ctypes.c_double * maxo)()
+    n2 = ctypes.c_int()
+    check(lib().xdet_profile_mfma_flops(handle, kind, maxo, ctypes.byref(n2), issued))
     rows = []
     buf = ctypes.create_string_buffer(256)
     for i in range(n.value):
         check(lib().xdet_profile_op_name(handle, kind, i, buf, 256))
-        rows.append((buf.value.decode(), ms[i], cnt[i], fl[i]))
+        rows.append((buf.value.decode(), ms[i], cnt[i], fl[i], issued[i]))
     return rows
 
 
@@ -193,7 +196,7 @@ def counters_from_profiles(precision, src_hash):
                 busy += e['mfma_busy_cycles']
                 act += e['gui_active_cycles']
         if cnt:
-            return {'traffic': int(tot / cnt), 'mfma_busy_frac': round(busy / act, 4) if act else None,
+            return {'traffic': int(tot / cnt), 'mfma_busy_frac': round(busy / (act / 8.0 * 1024.0), 4) if act else None,
                     'file': os.path.relpath(path, ROOT)}
     return None
 
@@ -370,9 +373,11 @@ def main():
     if rank == 0:
         ms_per_step = dt / K * 1e3
         value = world * B * K / dt
-        conv_ms = sum(r[1] for r in rows if r[3] > 0)
-        conv_launches = sum(r[2] for r in rows if r[3] > 0)
-        conv_flops = sum(r[3] * r[2] for r in rows if r[3] > 0) * sb    # flops are per image, a launch covers one sub-batch
+        # contraction ops: flops > 0; their auxiliary passes (DFT around a spectral GEMM): flops < 0 -- time counts, no FLOPs
+        conv_ms = sum(r[1] for r in rows if r[3] != 0)
+        conv_launches = sum(r[2] for r in rows if r[3] != 0)
+        conv_flops = sum(max(r[3], 0.0) * r[2] for r in rows) * sb      # flops are per image, a launch covers one sub-batch
+        issued_flops = sum(r[4] * r[2] for r in rows if r[3] != 0) * sb  # what the matrix cores actually executed
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == 'f32' else PEAK_F16_MFMA_TFLOPS
         nprod = 3 if args.precision == 'f16x3' else 1
         roof = None
@@ -384,9 +389,10 @@ def main():
             ctr = counters_from_profiles(args.precision, src) if default_cfg else None
             roof = {'bound': 'mfma', 'kernel': kname, 'achieved': round(ach, 2),
                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                    'mfma_issued_tflops': round(ach * nprod, 2),
-                    'mfma_util': round(ach * nprod / peak, 4),
-                    'mfma_util_how': 'issued MFMA FLOPs (%d products per algorithmic product) / peak' % nprod,
+                    'mfma_issued_tflops': round(issued_flops / (conv_ms * 1e-3) / 1e12, 2),
+                    'mfma_util': round(issued_flops / (conv_ms * 1e-3) / 1e12 / peak, 4),
+                    'mfma_util_how': 'FLOPs executed on the matrix cores (%d products per term; the spectral GEMMs execute '
+                                     '~5x fewer than their algorithmic count x %d) / conv kernel time / peak' % (nprod, nprod),
                     'mfma_busy_frac_pmc': ctr['mfma_busy_frac'] if ctr else None,
                     'traffic': ctr['traffic'] if ctr else None,
                     'traffic_unit': ('HBM bytes per conv launch (PMC FETCH_SIZE x2 + WRITE_SIZE), from %s, same kernel '
@@ -442,7 +448,7 @@ def main():
             out['cpu_baseline'] = None
         if args.ops and rows:
             tot = sum(r[1] for r in rows)
-            for name, ms, cnt, f in sorted(rows, key=lambda r: -r[1]):
+            for name, ms, cnt, f, _ in sorted(rows, key=lambda r: -r[1]):
                 tf = (f * sb * cnt / (ms * 1e-3) / 1e12) if (ms > 0 and f > 0) else 0
                 sys.stderr.write('%-52s %8.3f ms/step %5.1f%%  %7.1f TFLOP/s\n' % (name, ms / K, 100 * ms / tot, tf))
             sys.stderr.write('planned ops %.3f ms/step of %.3f ms/step\n' % (tot / K, ms_per_step))

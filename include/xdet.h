@@ -226,6 +226,10 @@ int xdet_net_flops_per_image(void* net, double* backbone, double* rpn, double* l
 int xdet_profile_enable(void* net, int net_kind, int enable);
 int xdet_profile_read(void* net, int net_kind, int max_ops, int* n_ops, double* ms, int* launches, double* flops);
 int xdet_profile_op_name(void* net, int net_kind, int op, char* buf, int buflen);
+/* per planned op: FLOPs it EXECUTES on the matrix cores per image (every split-precision product counted; less than
+ * 3 x algorithmic for the spectral GEMMs, 0 for VALU ops).  A negative `flops` from xdet_profile_read marks an
+ * auxiliary pass (DFT) of the contraction in front of / behind it. */
+int xdet_profile_mfma_flops(void* net, int net_kind, int max_ops, int* n_ops, double* issued_flops_per_image);
 
 /* ---- A13: ResNet-50 v2 trunk (net/resnet_v2.py:311-345), BASELINE config 2 --------------- */
 int xdet_resnet_create(void** net, int image_size, int max_batch);

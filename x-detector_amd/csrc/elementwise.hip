@@ -391,6 +391,48 @@ int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, in
   return XDET_OK;
 }
 
+// Every second pixel of every second row -> split planes of the [N, ceil(H/2), ceil(W/2), ld] tensor: the A operand
+// of a 1x1 / stride-2 SAME convolution (the residual projections conv2d_1..3, net/xception_body.py:261-266): a 1x1
+// kernel needs no padding, output (oy, ox) reads input (2 oy, 2 ox).  The subsampled tensor is a quarter of the
+// input, and the projection then runs on the LDS-DMA GEMM instead of gathering strided rows through registers.
+__global__ __launch_bounds__(256) void split_f32_subsample2_kernel(const float* __restrict__ in,
+                                                                   unsigned short* __restrict__ hi,
+                                                                   unsigned short* __restrict__ lo, int N, int H, int W,
+                                                                   int Ho, int Wo, int ld) {
+  const int c32n = ld >> 5;
+  const int64_t n_pix = (int64_t)N * Ho * Wo;
+  const int64_t n8 = ((n_pix + 15) >> 4) * c32n * 64;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t blk = i >> 6;
+    const int64_t grp = blk / c32n;
+    const int cc = (int)(blk - grp * c32n);
+    const int64_t pix = grp * 16 + ((i >> 2) & 15);
+    if (pix >= n_pix) continue;
+    const int n = (int)(pix / ((int64_t)Ho * Wo));
+    const int rem = (int)(pix - (int64_t)n * Ho * Wo);
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    const float* src = in + (((size_t)n * H + 2 * oy) * W + 2 * ox) * ld + cc * 32 + (i & 3) * 8;
+    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    f16x8e h, l;
+    split8(a, b, &h, &l);
+    *reinterpret_cast<f16x8e*>(hi + i * 8) = h;
+    *reinterpret_cast<f16x8e*>(lo + i * 8) = l;
+  }
+}
+
+int launch_split_f32_subsample2(const float* in, unsigned short* hi, unsigned short* lo, int N, int H, int W, int ld,
+                                hipStream_t s) {
+  XDET_REQUIRE(ld > 0 && ld % 32 == 0, "split: channel stride must be a multiple of 32");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int64_t n_pix = (int64_t)N * Ho * Wo;
+  if (n_pix == 0) return XDET_OK;
+  const int64_t n = cdiv(n_pix, 16) * 16 * ld;
+  const int blocks = (int)std::min<int64_t>(cdiv(n / 8, 256), 256 * 32);
+  hipLaunchKernelGGL(split_f32_subsample2_kernel, dim3(blocks), dim3(256), 0, s, in, hi, lo, N, H, W, Ho, Wo, ld);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
 // grid.x = N*Ho output rows, grid.y covers Wo * ld/4 items; one thread = 4 channels of one output pixel
 __global__ __launch_bounds__(256) void maxpool3x3s2_add_kernel(const float* __restrict__ in,
                                                                const float* __restrict__ res,

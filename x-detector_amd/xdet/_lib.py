@@ -110,6 +110,7 @@ SIGNATURES = {
     'xdet_profile_enable': (c_int, [c_void_p, c_int, c_int]),
     'xdet_profile_read': (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_double),
                                   ctypes.POINTER(c_int), ctypes.POINTER(c_double)]),
+    'xdet_profile_mfma_flops': (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_double)]),
     'xdet_profile_op_name': (c_int, [c_void_p, c_int, c_int, ctypes.c_char_p, c_int]),
     'xdet_resnet_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int]),
     'xdet_resnet_set_weight': (c_int, [c_void_p, ctypes.c_char_p, PF, c_int, ctypes.POINTER(c_int64)]),
