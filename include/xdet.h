@@ -182,7 +182,7 @@ int xdet_net_set_weight(void* net, const char* name, const float* data_host, int
  *   "large_sep" = "auto" | "direct" | "spectral": arithmetic form of large_sep_kernel (net/xception_body.py:450-475).
  *   direct = the (15,1)/(1,15) convs as implicit GEMMs; spectral = the same linear maps evaluated in the DFT
  *   domain of the convolved axis (one GEMM per frequency bin, ~5x fewer MFMA FLOPs; needs a split-precision
- *   mode and a 16/30/50 feature map); auto = spectral when max_batch * feature_map_side >= 480, else direct.
+ *   mode and a 16/30/50 feature map); auto = spectral whenever those hold, else direct.
  *   The choice is per net, never per call: results do not depend on the batch an image arrives in.
  *   "sepconv" = "fused" | "split": entry-flow separable blocks as one kernel (default) or depthwise + pointwise.
  *   "rpn_stream" = "side" | "main": the RPN / proposal branch forks onto a side stream under the large-separable

@@ -302,6 +302,7 @@ int launch_conv_mfma_dma(const ConvParams& p, int n_tile, int nsplit, hipStream_
     const bool full_rounds = b256 >= 240 && (b256 % 256 == 0 || b256 % 256 >= 240);
     if (p.Cout_pad % 256 == 0 && (b256 >= 512 || full_rounds || (b256 >= 200 && nk >= 40))) tile = 2;
     else if (b128n >= 170) tile = 1;
+    if (p.group_rows && p.group_rows % 256 != 0) tile = 0;      // a group must be whole M tiles
     if (tile == 2) return launch_d<256, 256, 2, 4, 3>(p, s);
     if (tile == 1) return launch_d<256, 128, 4, 2, 3>(p, s);
   }

@@ -262,8 +262,8 @@ struct ConvLayer : LayerBase {
     p.pl_scale = pl_scale; p.pl_shift = pl_shift;
     p.group_rows = 0; p.group_wt_stride = 0;
     if (groups > 1) {
-      XDET_REQUIRE(in_hi && group_rows > 0 && group_rows % 256 == 0 && (int64_t)group_rows * groups == p.M,
-                   "conv(grouped): M must be groups * group_rows, group_rows a multiple of 256, input as planes");
+      XDET_REQUIRE(in_hi && group_rows > 0 && group_rows % 128 == 0 && (int64_t)group_rows * groups == p.M,
+                   "conv(grouped): M must be groups * group_rows, group_rows a multiple of 128, input as planes");
       p.group_rows = group_rows;
       p.group_wt_stride = (long long)cout_pad * kp;
     }
@@ -691,11 +691,12 @@ struct LightHeadNet : Plan {
     XDET_TRY(sep_bn("block13_sepconv2", eps, ST_BODY, a, 1024, 1, 1, 0, &r, &b2));
     XDET_TRY(sep_bn("block14_sepconv1", eps, ST_BODY, b2, 1536, 0, 2, 1, nullptr, &c3));   // :354-364
     // The large-separable convs run either as direct implicit GEMMs over split planes or in the DFT domain
-    // (spectral.hip: ~5x fewer MFMA FLOPs, but one GEMM per frequency bin with M = N*fmap rows, so it only
-    // pays with enough images per call).  Decided per NET (not per call), so that an image's result never
-    // depends on the batch it arrives in.
-    large_sep_spectral = g_default_precision != PREC_F32 && spectral_supported(c3.H) && c3.H == c3.W &&
-                         (large_sep_mode == 2 || (large_sep_mode == 0 && (int64_t)max_batch * c3.H >= 480));
+    // (spectral.hip: ~5x fewer MFMA FLOPs; one GEMM per frequency bin with M = N*fmap rows).  The spectral form
+    // wins at every batch size -- at one image the direct (15,1) conv is a 900-row GEMM with K = 30,720 on 32
+    // workgroups (0.9 ms), the 22 bins are 176 workgroups with K = 4,096 -- so `auto` takes it whenever the
+    // feature-map size has a transform instantiated.  Decided per NET, never per call: an image's result
+    // does not depend on the batch it arrives in.
+    large_sep_spectral = g_default_precision != PREC_F32 && spectral_supported(c3.H) && c3.H == c3.W && large_sep_mode != 1;
     if (large_sep_mode == 2) XDET_REQUIRE(large_sep_spectral, "large_sep=spectral needs a split-precision mode and a 16/30/50 feature map");
     emit_planes_next = large_sep_spectral ? 0 : 1;   // the direct (15,1) conv takes planes; the DFT pass reads f32
     XDET_TRY(sep_bn("block14_sepconv2", eps, ST_BODY, c3, 2048, 0, 2, 1, nullptr, &d4));   // :366-376
@@ -841,7 +842,8 @@ struct LightHeadNet : Plan {
     const Buf o = out, ft = feat;
     const std::string pre = "large_sep_feature/Branch_0+1/";
     const double fl_a = 2.0 * F * F * (double)cin * mid2 * 15, fl_b = 2.0 * F * F * (double)mid2 * co * 15;
-    auto mpad = [F](int N) { return round_up(N * F, 256); };
+    // rows per bin: whole 256-row GEMM tiles; a single image or two (N*F <= 128) get the 128-row tile instead
+    auto mpad = [F](int N) { return N * F <= 128 ? 128 : round_up(N * F, 256); };
     // flops < 0 marks an auxiliary pass of a contraction: its time counts with the conv kernels, it has no FLOPs of its own
     ops.push_back({pre + "conv2d/dft_y", ST_LSEP, -1.0, [=](int N, hipStream_t s) {
                      return launch_dft_fwd(o.p, F, o.ld, 0, N, mpad(N), d_tf, xa_hi, xa_lo, s);
