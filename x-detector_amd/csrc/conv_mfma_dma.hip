@@ -306,8 +306,13 @@ int launch_conv_mfma_dma(const ConvParams& p, int n_tile, int nsplit, hipStream_
     if (tile == 2) return launch_d<256, 256, 2, 4, 3>(p, s);
     if (tile == 1) return launch_d<256, 128, 4, 2, 3>(p, s);
   }
-  if (n_tile == 128)
+  if (n_tile == 128) {
+    // small batches: 128 x 128 tiles leave most of the 256 CUs idle (a 900-row layer is 8 x 4..6 workgroups); halve
+    // the N tile to double the workgroup count -- per-element K order is unchanged, so results stay bit-identical
+    const int64_t b128 = cdiv(p.M, 128) * (p.Cout_pad / 128);
+    if (nsplit == 3 && b128 < 128 && (!p.group_rows || p.group_rows % 128 == 0)) return launch_d<128, 64, 4, 1, 3>(p, s);
     return nsplit == 1 ? launch_d<128, 128, 2, 2, 1>(p, s) : launch_d<128, 128, 2, 2, 3>(p, s);
+  }
   if (n_tile == 64) return nsplit == 1 ? launch_d<128, 64, 4, 1, 1>(p, s) : launch_d<128, 64, 4, 1, 3>(p, s);
   set_last_error("conv(dma): unsupported N tile");
   return XDET_ERR_UNSUPPORTED;
