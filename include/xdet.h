@@ -117,13 +117,12 @@ int xdet_depthwise_forward(void* layer, const float* in, int N, int H, int W, in
 /* relu_separable_bn_block as ONE kernel (net/xception_body.py:220-234: (ReLU ->) depthwise 3x3 -> pointwise 1x1 ->
  * BN, "nothing in between"): the depthwise result stays on the CU instead of crossing HBM as split planes.
  * dw_layer from xdet_depthwise_create (dilation 1), pw_layer a 1x1 stride-1 layer from xdet_conv_create in a
- * split-precision mode (its scale/shift = the folded BN, relu_out as created); in/out NHWC f32, residual
- * (may be NULL) shaped like out.  Two kernels behind it: the entry-flow shapes (<= 256 input channels, 128 or 256
- * outputs, any map size, no residual) and the "wide" one for maps at most 30 pixels wide with up to 1024 input
- * channels and a 256-multiple of padded outputs (the 728-channel layers).  Bit-identical to xdet_depthwise_forward
- * -> xdet_split_f32 -> xdet_conv_forward_planes.  Inside a net: options "sepconv" / "sepconv_wide" = "fused" | "split". */
+ * split-precision mode (its scale/shift = the folded BN, relu_out as created); <= 256 input channels
+ * (multiple of 32) and 128 or 256 outputs; in/out NHWC f32.  Bit-identical to xdet_depthwise_forward ->
+ * xdet_split_f32 -> xdet_conv_forward_planes.  Inside a net the entry-flow blocks use it
+ * (option "sepconv" = "fused" (default) | "split"). */
 int xdet_sepconv_fused_forward(void* dw_layer, void* pw_layer, const float* in, int N, int H, int W, int ld_in, float* out,
-                               int ld_out, const float* residual, int relu_in, void* stream);
+                               int ld_out, int relu_in, void* stream);
 /* tf.layers.max_pooling2d(3,2,'same') + tf.add(residual) (net/xception_body.py:281-286) */
 int xdet_maxpool3x3s2_add(const float* in, const float* residual, float* out, int N, int H, int W, int C, int ld,
                           void* stream);

@@ -129,12 +129,6 @@ int launch_sepconv_fused(const float* in, const float* w9c, const unsigned short
                          const unsigned short* wt_lo_blocked, const float* scale, const float* shift, float* out, int N,
                          int H, int W, int ld, int ldo, int cout_pad, int relu_in, int relu_out, hipStream_t s);
 
-bool sepconv_wide_supported(int cin_ld, int cout_pad, int dil, int H, int W);
-int launch_sepconv_wide(const float* in, const float* w9c, const unsigned short* wt_hi_blocked,
-                        const unsigned short* wt_lo_blocked, const float* scale, const float* shift, const float* res,
-                        float* out, int N, int H, int W, int ld, int ldo, int cout_pad, int relu_in, int relu_out,
-                        hipStream_t s);
-
 // ---- F1 pre-processing (preprocess.hip) ----------------------------------------------
 int launch_preprocess_eval(const unsigned char* img, int H, int W, float* out_chw, int S, hipStream_t s);
 

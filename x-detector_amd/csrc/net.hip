@@ -418,7 +418,6 @@ struct Plan {
   const float *emit_bn_scale = nullptr, *emit_bn_shift = nullptr;
   bool fuse_sepconv = true;      // option "sepconv" = "fused" | "split"
   bool subsample_projections = true;
-  bool fuse_sepconv_wide = true;     // option "sepconv_wide" = "fused" | "split"
   int add_conv(const std::string& name, int stage, const Buf& in_, ConvLayer* L, const Buf* res, int relu_in, Buf* out) {
     Buf in = in_;
     const int emit = L->precision == PREC_F32 ? 0 : emit_planes_next;
@@ -552,20 +551,6 @@ struct Plan {
       ops.push_back({name + "/fused_dw+pw", stage, L->flops(in.H, in.W), [=](int N, hipStream_t s) {
                        return launch_sepconv_fused(i.p, D->d_w, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale, L->d_shift, o.p, N,
                                                    i.H, i.W, i.ld, o.ld, L->cout_pad, pre_relu, L->relu_out, s);
-                     }});
-      return XDET_OK;
-    }
-    // 30 x 30 layers with a 256-multiple of output channels (the 26 separable blocks of the middle / exit flow):
-    // the wide fused kernel (one workgroup = 256 pixels x 256 channels, residual in its epilogue)
-    if (fuse_sepconv_wide && L->dma_capable() && emit_planes_next == 0 && !in.no_f32 && in.ld > 256 &&
-        sepconv_wide_supported(in.ld, L->cout_pad, dilation, in.H, in.W)) {
-      XDET_TRY(new_buf(in.H, in.W, cout, out));
-      if (res) XDET_REQUIRE(res->H == in.H && res->W == in.W && res->ld == out->ld && !res->no_f32, "plan: residual shape mismatch");
-      const Buf i = in, o = *out;
-      const float* rp = res ? res->p : nullptr;
-      ops.push_back({name + "/fused_dw+pw [wide]", stage, L->flops(in.H, in.W), [=](int N, hipStream_t s) {
-                       return launch_sepconv_wide(i.p, D->d_w, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale, L->d_shift, rp, o.p, N,
-                                                  i.H, i.W, i.ld, o.ld, L->cout_pad, pre_relu, L->relu_out, s);
                      }});
       return XDET_OK;
     }
@@ -1291,7 +1276,7 @@ int xdet_depthwise_forward(void* layer, const float* in, int N, int H, int W, in
   return static_cast<DepthwiseLayer*>(b)->forward(in, N, H, W, ld, out, relu_in, S(stream));
 }
 int xdet_sepconv_fused_forward(void* dw_layer, void* pw_layer, const float* in, int N, int H, int W, int ld_in, float* out,
-                               int ld_out, const float* residual, int relu_in, void* stream) {
+                               int ld_out, int relu_in, void* stream) {
   LayerBase* a = static_cast<LayerBase*>(dw_layer);
   LayerBase* b = static_cast<LayerBase*>(pw_layer);
   XDET_REQUIRE(a && a->kind == 2 && b && b->kind == 1, "sepconv_fused: need a depthwise and a conv layer");
@@ -1299,16 +1284,12 @@ int xdet_sepconv_fused_forward(void* dw_layer, void* pw_layer, const float* in, 
   ConvLayer* L = static_cast<ConvLayer*>(b);
   XDET_REQUIRE(L->dma_capable() && L->kh == 1 && L->kw == 1 && L->stride == 1 && L->groups == 1,
                "sepconv_fused: the pointwise layer must be a 1x1 stride-1 conv created in a split-precision mode");
-  XDET_REQUIRE(D->ld == ld_in && L->ld_in() == ld_in && L->ld_out() == ld_out, "sepconv_fused: channel strides do not match the layers");
+  XDET_REQUIRE(D->ld == ld_in && L->ld_in() == ld_in && L->ld_out() == ld_out && L->cout_pad == ld_out &&
+                   sepconv_fused_supported(ld_in, L->cout_pad, D->dil),
+               "sepconv_fused: needs <= 256 input channels (multiple of 32), 128 or 256 outputs, dilation 1");
   DeviceGuard guard(L->device);
-  if (!residual && L->cout_pad == ld_out && sepconv_fused_supported(ld_in, L->cout_pad, D->dil))
-    return launch_sepconv_fused(in, D->d_w, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale, L->d_shift, out, N, H, W, ld_in, ld_out,
-                                L->cout_pad, relu_in, L->relu_out, S(stream));
-  XDET_REQUIRE(sepconv_wide_supported(ld_in, L->cout_pad, D->dil, H, W),
-               "sepconv_fused: needs dilation 1 and either <= 256 input channels with 128 / 256 outputs, or a map at most "
-               "30 pixels wide with a multiple of 256 (padded) outputs");
-  return launch_sepconv_wide(in, D->d_w, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale, L->d_shift, residual, out, N, H, W, ld_in,
-                             ld_out, L->cout_pad, relu_in, L->relu_out, S(stream));
+  return launch_sepconv_fused(in, D->d_w, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale, L->d_shift, out, N, H, W, ld_in, ld_out,
+                              L->cout_pad, relu_in, L->relu_out, S(stream));
 }
 int xdet_maxpool3x3s2_add(const float* in, const float* residual, float* out, int N, int H, int W, int C, int ld,
                           void* stream) {
@@ -1392,11 +1373,6 @@ int xdet_net_set_option(void* net, const char* key, const char* value) {
   if (k == "sepconv") {
     XDET_REQUIRE(v == "fused" || v == "split", "sepconv must be fused | split");
     n->fuse_sepconv = v == "fused";
-    return XDET_OK;
-  }
-  if (k == "sepconv_wide") {
-    XDET_REQUIRE(v == "fused" || v == "split", "sepconv_wide must be fused | split");
-    n->fuse_sepconv_wide = v == "fused";
     return XDET_OK;
   }
   set_last_error("unknown option: " + k);

@@ -307,288 +307,6 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// The same block for the 30 x 30 layers of the middle / exit flow (728 -> 728 / 1024 channels): "wide" variant.
-// Their pointwise GEMM is MFMA-bound and needs big tiles, so here ONE workgroup of 4 waves (one per SIMD, the whole
-// 512-register file each) owns a 256-pixel x 256-channel output tile: tile = 8 image rows x 30 pixels (a tile never
-// spans two images, so SAME padding is again the DMA's bounds-check zero fill; 4 tiles per 30-row image, the last
-// with 6 live rows), patch = 10 rows x 32 pixels x 32 channels (40 KB, double buffered), A tile 256 x 32 hi/lo
-// (32 KB), depthwise taps for up to 1024 channels (36 KB): 148 KB of LDS.  Per 32-channel chunk a lane filters
-// 8 pixels x 4 channels (30 patch reads for 8 outputs) and then issues 96 MFMAs (wave tile 128 x 128) against
-// weights loaded from L2 into registers one 16-deep half ahead.  The three 256-wide N passes of a tile run on
-// neighbouring workgroups of the same XCD at the same time (interleaved schedule) and share the patch in L2.
-// Optional residual (block*_sepconv3 / block13_sepconv2) and ReLU in the epilogue.  Same arithmetic and order as
-// depthwise3x3_tile_kernel + conv_dma_f16_kernel: bit-identical.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int SW_R = 8, SW_ROWS = SW_R + 2, SW_PATCH_F = SW_ROWS * SF_P * 32, SW_KMAX = 1024, SW_BN = 256;
-constexpr int SW_NJ = SW_ROWS * (SF_P / 8) / 4;     // DMA pieces per wave per chunk (10)
-
-struct SepWideParams {
-  const float* in; const float* w9c; const u16* wt_hi; const u16* wt_lo; const float* scale; const float* shift;
-  const float* res;      // optional residual, layout of out
-  float* out;
-  int N, H, W, ld, ldo, Cout_pad, relu_in, relu_out;
-  int TY, TX, NT, ntiles;
-};
-
-template <bool SPLIT3>
-__global__ __launch_bounds__(256, 1) void sepconv_wide_kernel(SepWideParams p) {
-  __shared__ __attribute__((aligned(16))) float s_patch[2][SW_PATCH_F];
-  __shared__ __attribute__((aligned(16))) u16 s_a[2 * 256 * 32];
-  __shared__ __attribute__((aligned(16))) float s_w[9 * SW_KMAX];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, G = gridDim.x >> 3;
-  const int per_xcd = (p.ntiles + 7) >> 3;
-  const int t_begin = xcd * per_xcd + wg;
-  const int t_end = min(p.ntiles, (xcd + 1) * per_xcd);
-  if (t_begin >= t_end) return;
-  const int KC = p.ld >> 5;
-
-  for (int i = tid; i < 9 * p.ld; i += 256) s_w[i] = p.w9c[i];
-
-  struct Coord { int nt, ty, tx, n; };
-  auto decode = [&](int q) {
-    Coord c;
-    c.nt = q % p.NT; q /= p.NT;
-    c.ty = q % p.TY; q /= p.TY;
-    c.tx = q % p.TX;
-    c.n = q / p.TX;
-    return c;
-  };
-  Coord cur = decode(t_begin);
-
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.ld * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-      p.out, 0, (int)(unsigned)std::min<size_t>((size_t)p.N * p.H * p.W * p.ldo * 4, 0xffffffffull), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.res ? p.res : p.out), 0,
-      (int)(unsigned)std::min<size_t>((size_t)p.N * p.H * p.W * p.ldo * 4, 0xffffffffull), 0x00020000);
-  const int px8 = lane >> 3;
-  const int lane_off = (px8 * p.ld + (lane & 7) * 4) * 4;
-  auto issue = [&](const Coord& c, int chunk, int buf, bool live) {
-    const int y0 = c.ty * SW_R, x0 = c.tx * SF_X;
-    const int tile_base = ((((c.n * p.H + y0) * p.W + x0) * p.ld) + chunk * 32) * 4;
-#pragma unroll
-    for (int jj = 0; jj < SW_NJ; ++jj) {
-      const int i = wave + 4 * jj;
-      const int rr = i >> 2, seg = i & 3;
-      const bool rok = live && (unsigned)(y0 + rr - 1) < (unsigned)p.H;
-      const bool ok = rok && (unsigned)(x0 + seg * 8 - 1 + px8) < (unsigned)p.W;
-      const int soff = tile_base + ((rr - 1) * p.W + seg * 8 - 1) * p.ld * 4;
-      const unsigned voff = ok ? (unsigned)(soff + lane_off) : 0xffffffffu;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsrc, (__attribute__((address_space(3))) void*)(&s_patch[buf][(rr * SF_P + seg * 8) * 32]), 16, voff, 0, 0, 0);
-    }
-  };
-
-  // depthwise role: a wave filters two tile rows; lane = (row-in-pair, strip of 8 pixels, 4 channels)
-  const int c4 = lane & 7, strip = (lane >> 3) & 3, drow = wave * 2 + (lane >> 5);
-  const int pxb = min(strip * 8, SF_X - 8);        // strips 0, 8, 16, 22 (22, 23 recomputed): nothing reaches past the patch
-  // MFMA role: 2 x 2 waves, each 128 x 128
-  const int frow = lane & 31, fh = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-  const unsigned a_base = sf_lds_addr(s_a);
-  unsigned a_rd[2][4];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rt = wm * 128 + i * 32 + frow;
-      a_rd[ks][i] = a_base + (unsigned)(rt * 32 + (((ks * 2 + fh) ^ ((rt >> 2) & 3)) << 3)) * 2u;
-    }
-
-  sf_f32x16 acc[4][4];
-  int buf = 0;
-  issue(cur, 0, 0, true);
-  for (int t = t_begin; t < t_end; t += G) {
-    const Coord nxt = decode(min(t + G, p.ntiles - 1));
-    const int y0 = cur.ty * SW_R, x0 = cur.tx * SF_X, n0 = cur.nt * SW_BN;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float esc[4], esh[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      esc[j] = p.scale[n0 + wn * 128 + j * 32 + frow];
-      esh[j] = p.shift[n0 + wn * 128 + j * 32 + frow];
-    }
-
-    for (int chunk = 0; chunk < KC; ++chunk, buf ^= 1) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // patch landed, A tile free
-      // weights of the first 16-deep half, requested before the prefetch (vmcnt retires in order)
-      sf_f16x8 bh[2][4], bl[2][4];
-      const size_t wrow = ((size_t)chunk * p.Cout_pad + (n0 + wn * 128 + frow)) * 32 + fh * 8;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const size_t o = wrow + (size_t)j * 32 * 32 + ks * 16;
-          bh[ks][j] = *reinterpret_cast<const sf_f16x8*>(p.wt_hi + o);
-          if (SPLIT3) bl[ks][j] = *reinterpret_cast<const sf_f16x8*>(p.wt_lo + o);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        const bool more = chunk + 1 < KC;
-        issue(more ? cur : nxt, more ? chunk + 1 : 0, buf ^ 1, more || t + G < t_end);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // -- depthwise: 8 pixels x 4 channels per lane, one patch row (10 pixels) and its three taps at a time --
-      const float lo_clip = p.relu_in ? 0.f : -INFINITY;
-      const unsigned t_addr = sf_lds_addr(&s_patch[buf][0]) + (unsigned)(((drow * SF_P + pxb) * 32 + c4 * 4) * 4);
-      const unsigned w_addr = sf_lds_addr(s_w) + (unsigned)((chunk * 32 + c4 * 4) * 4);
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {        // two passes of 4 pixels: 52 live registers instead of 84
-        sf_f32x4 a[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) a[k] = (sf_f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          sf_f32x4 col[6], ww[3];
-          const unsigned ra = t_addr + ky * (SF_P * 32 * 4) + half * 512;
-          col[0] = sf_ds_read_f4<0>(ra);   col[1] = sf_ds_read_f4<128>(ra); col[2] = sf_ds_read_f4<256>(ra);
-          col[3] = sf_ds_read_f4<384>(ra); col[4] = sf_ds_read_f4<512>(ra); col[5] = sf_ds_read_f4<640>(ra);
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) ww[kx] = sf_ds_read_f4<0>(w_addr + (unsigned)((ky * 3 + kx) * p.ld * 4));
-          asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+v"(col[0]), "+v"(col[1]), "+v"(col[2]), "+v"(col[3]), "+v"(col[4]), "+v"(col[5]), "+v"(ww[0]),
-                         "+v"(ww[1]), "+v"(ww[2])::"memory");
-#pragma unroll
-          for (int k = 0; k < 6; ++k) {
-            col[k].x = fmaxf(col[k].x, lo_clip); col[k].y = fmaxf(col[k].y, lo_clip);
-            col[k].z = fmaxf(col[k].z, lo_clip); col[k].w = fmaxf(col[k].w, lo_clip);
-          }
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              a[k].x = fmaf(col[k + kx].x, ww[kx].x, a[k].x); a[k].y = fmaf(col[k + kx].y, ww[kx].y, a[k].y);
-              a[k].z = fmaf(col[k + kx].z, ww[kx].z, a[k].z); a[k].w = fmaf(col[k + kx].w, ww[kx].w, a[k].w);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int row = drow * 32 + pxb + half * 4 + k;
-          const unsigned wa = a_base + (unsigned)(row * 32 + (((c4 >> 1) ^ ((row >> 2) & 3)) << 3) + (c4 & 1) * 4) * 2u;
-          const _Float16 h0 = (_Float16)a[k].x, h1 = (_Float16)a[k].y, h2 = (_Float16)a[k].z, h3 = (_Float16)a[k].w;
-          sf_f16x4 hv = {h0, h1, h2, h3};
-          sf_ds_write_b64(wa, *reinterpret_cast<uint2*>(&hv));
-          if (SPLIT3) {
-            sf_f16x4 lv = {(_Float16)(a[k].x - (float)h0), (_Float16)(a[k].y - (float)h1), (_Float16)(a[k].z - (float)h2),
-                           (_Float16)(a[k].w - (float)h3)};
-            sf_ds_write_b64(wa + 256 * 64, *reinterpret_cast<uint2*>(&lv));
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // A tile visible; the prefetch stays in flight
-      // -- pointwise: one set of A fragments per 16-deep half (an MFMA reads its operands when it issues, so the
-      //    second half's reads may land in the same registers once the first half's MFMAs have issued) --
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        sf_f16x8 ah[4], al[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          ah[i] = sf_ds_read_b128<0>(a_rd[ks][i]);
-          if (SPLIT3) al[i] = sf_ds_read_b128<256 * 64>(a_rd[ks][i]);
-        }
-        if (SPLIT3)
-          asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), "+v"(al[0]), "+v"(al[1]), "+v"(al[2]),
-                         "+v"(al[3])::"memory");
-        else
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3])::"memory");
-        if (SPLIT3) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[ks][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[ks][j], acc[i][j], 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[ks][j], acc[i][j], 0, 0, 0);
-      }
-    }
-
-    // ---- epilogue: accumulator block (i, j) = tile row wm*4 + i, 32 output channels; raw buffer loads / stores ----
-    const int lim = min(SF_X, p.W - x0) - 4 * fh;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int y = y0 + wm * 4 + i;
-      if (y >= p.H) continue;                                // wave-uniform
-      const unsigned row_off = (unsigned)((((size_t)cur.n * p.H + y) * p.W + x0) * p.ldo * 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int co = n0 + wn * 128 + j * 32 + frow;
-        const unsigned lane_off2 = co < p.ldo ? (unsigned)((4 * fh * p.ldo + co) * 4) : 0xffffffffu;
-        float rv[16];
-        if (p.res) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int c = (r & 3) + 8 * (r >> 2);
-            rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, c < lim ? lane_off2 : 0xffffffffu,
-                                                                                  row_off + c * p.ldo * 4, 0));
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int c = (r & 3) + 8 * (r >> 2);
-          float v = fmaf(acc[i][j][r], esc[j], esh[j]);
-          if (p.res) v += rv[r];
-          if (p.relu_out) v = fmaxf(v, 0.f);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, c < lim ? lane_off2 : 0xffffffffu,
-                                                row_off + c * p.ldo * 4, 0);
-        }
-      }
-    }
-    cur = nxt;
-  }
-}
-
-bool sepconv_wide_supported(int cin_ld, int cout_pad, int dil, int H, int W) {
-  return dil == 1 && cin_ld % 32 == 0 && cin_ld <= SW_KMAX && cout_pad % SW_BN == 0 && W <= SF_X && H >= 1;
-}
-
-int launch_sepconv_wide(const float* in, const float* w9c, const unsigned short* wt_hi_blocked,
-                        const unsigned short* wt_lo_blocked, const float* scale, const float* shift, const float* res,
-                        float* out, int N, int H, int W, int ld, int ldo, int cout_pad, int relu_in, int relu_out,
-                        hipStream_t s) {
-  XDET_REQUIRE(sepconv_wide_supported(ld, cout_pad, 1, H, W), "sepconv_wide: unsupported shape");
-  XDET_REQUIRE(in && w9c && wt_hi_blocked && scale && shift && out, "sepconv_wide: NULL argument");
-  const size_t per_image = (size_t)H * W * std::max(ld, ldo) * 4;
-  const int n_max = (int)std::max<size_t>(1, (((size_t)1 << 31) - 1) / per_image);
-  for (int nb = 0; nb < N; nb += n_max) {
-    const int n = std::min(n_max, N - nb);
-    SepWideParams p;
-    p.in = in + (size_t)nb * H * W * ld;
-    p.w9c = w9c; p.wt_hi = wt_hi_blocked; p.wt_lo = wt_lo_blocked; p.scale = scale; p.shift = shift;
-    p.res = res ? res + (size_t)nb * H * W * ldo : nullptr;
-    p.out = out + (size_t)nb * H * W * ldo;
-    p.N = n; p.H = H; p.W = W; p.ld = ld; p.ldo = ldo; p.Cout_pad = cout_pad; p.relu_in = relu_in; p.relu_out = relu_out;
-    p.TY = (int)cdiv(H, SW_R); p.TX = (int)cdiv(W, SF_X); p.NT = cout_pad / SW_BN;
-    const int64_t nt = (int64_t)n * p.TY * p.TX * p.NT;
-    p.ntiles = (int)nt;
-    const dim3 g((unsigned)std::min<int64_t>(256, cdiv(nt, 8) * 8));        // one workgroup per CU
-    if (wt_lo_blocked) hipLaunchKernelGGL((sepconv_wide_kernel<true>), g, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((sepconv_wide_kernel<false>), g, dim3(256), 0, s, p);
-    XDET_LAUNCH_CHECK();
-  }
-  return XDET_OK;
-}
-
 bool sepconv_fused_supported(int cin_ld, int cout_pad, int dil) {
   return dil == 1 && cin_ld % 32 == 0 && cin_ld <= SF_KMAX && cout_pad % SF_BN == 0 && cout_pad <= 256;
 }

@@ -162,14 +162,13 @@ class SeparableConvBN(object):
         self.dw = DepthwiseConv2D(dw_kernel, dilation)
         self.pw = Conv2D(pw_kernel, 1, 'SAME', 1, scale, shift, relu)
 
-    def __call__(self, x, relu_in=False, fused=True, residual=None, stream=None):
+    def __call__(self, x, relu_in=False, fused=True, stream=None):
         N, H, W, C = x.shape
         if not fused:
-            return self.pw(self.dw(x, relu_in=relu_in, stream=stream), residual=residual, stream=stream, planes=True)
+            return self.pw(self.dw(x, relu_in=relu_in, stream=stream), stream=stream, planes=True)
         out = DeviceTensor.empty((N, H, W, self.pw.cout))
         check(lib().xdet_sepconv_fused_forward(self.dw.handle, self.pw.handle, x.ptr, N, H, W, x.ld, out.ptr, out.ld,
-                                               residual.ptr if residual is not None else None, 1 if relu_in else 0,
-                                               stream.handle if stream else None))
+                                               1 if relu_in else 0, stream.handle if stream else None))
         synchronize(stream)
         return out
 
