@@ -262,3 +262,38 @@ def test_net_misuse_is_reported_not_executed(lh_weights):
     from xdet import weights as W
     got = det.forward(W.synthetic_images(1, 480, seed=1))   # still works afterwards
     assert len(got) == 1 and len(got[0]) == 20
+
+
+@pytest.mark.parametrize('lsep', ['direct', 'spectral'])
+def test_second_weight_set(lsep, oracle):
+    """The 1e-3 claim on an independent synthetic model: other seed (777, its own BN calibration), other gains on the
+    score layers than the committed recipe (SYNTH_GAINS), other images -- so that the claim does not rest on one
+    hand-picked score spread.  Feature maps within 1e-4 of their scale, proposals equal as sets, detections matched
+    (a difference only where a per-class NMS score tie explains it)."""
+    from xdet import weights as W
+    from xdet.model import LightHeadDetector
+    from xdet.runtime import set_precision
+    gains = {'rpn_head/conv2d_1/kernel': 1.0, 'rpn_head/conv2d_2/kernel': 0.5, 'final_head/fc_cls/kernel': 3.0,
+             'final_head/fc_loc/kernel': 1.0}
+    w = W.make_lighthead_weights(777, gains=gains)
+    imgs = W.synthetic_images(2, 480, seed=555)
+    set_precision('f16x3')
+    try:
+        det = LightHeadDetector(w, image_size=480, max_batch=2, rpn_post_nms_top_n=300, large_sep=lsep)
+    finally:
+        set_precision('f32')
+    got = det.forward(imgs)
+    tr = {}
+    ref = oracle.lighthead_forward(imgs, w, rpn_post_nms_top_n=300, trace=tr)
+    assert rel_err(det.buffer('feat', 2).numpy(), tr['feat']) < 1e-4
+    props = det.flat('proposals', (2, 300, 4))
+    for i in range(2):
+        a = props[i][np.lexsort(props[i].T)]
+        b = tr['proposals'][i][np.lexsort(tr['proposals'][i].T)]
+        assert np.abs(a - b).max() < TOL
+    total = matched = ties = 0
+    for i in range(2):
+        t, m, k = assert_match_or_score_tie(got[i], ref[i])
+        total, matched, ties = total + t, matched + m, ties + k
+    print('seed 777 [%s]: oracle detections %d matched %d, lists explained by a score tie %d' % (lsep, total, matched, ties))
+    assert total > 500 and ties <= 1

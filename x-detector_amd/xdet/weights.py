@@ -166,10 +166,14 @@ SYNTH_GAINS = {
 }
 
 
-def make_lighthead_weights(seed=1234, calibrated=True, **kw):
+def make_lighthead_weights(seed=1234, calibrated=True, gains=None, **kw):
+    """seeded synthetic weights; `gains` overrides SYNTH_GAINS (tests use a second seed with other gains so that the
+    parity claim does not rest on one hand-picked score spread)"""
     calib = os.path.join(_DATA_DIR, 'bn_calib_lighthead_seed%d.npz' % seed) if calibrated else None
+    if calibrated and not os.path.exists(calib):
+        raise FileNotFoundError('no BN calibration for seed %d (tests/golden/make_calibration.py)' % seed)
     w = _fill(lighthead_tables(**kw), seed, calib)
-    for k, g in SYNTH_GAINS.items():
+    for k, g in (SYNTH_GAINS if gains is None else gains).items():
         w[k] = (w[k] * np.float32(g)).astype(np.float32)
     return w
 
