@@ -123,6 +123,13 @@ int xdet_depthwise_forward(void* layer, const float* in, int N, int H, int W, in
  * (option "sepconv" = "fused" (default) | "split"). */
 int xdet_sepconv_fused_forward(void* dw_layer, void* pw_layer, const float* in, int N, int H, int W, int ld_in, float* out,
                                int ld_out, int relu_in, void* stream);
+/* tf.layers.conv2d(3x3, VALID, stride 1, use_bias=False) -> BN (-> ReLU) over 32 input channels and <= 64 outputs
+ * (block1_conv2, net/xception_body.py:252-259) with the input tile staged ONCE in LDS: in_hi/in_lo are the split
+ * planes of xdet_split_f32 (ld 32), `layer` a matching xdet_conv_create layer in a split-precision mode; out is
+ * NHWC f32 [N][H-2][W-2][ld_out].  Bit-identical to xdet_conv_forward_planes on the same layer.  Inside a net:
+ * option "conv3x3" = "patch" (default) | "gemm". */
+int xdet_conv3x3_patch_forward(void* layer, const uint16_t* in_hi, const uint16_t* in_lo, int N, int H, int W, float* out,
+                               int ld_out, void* stream);
 /* tf.layers.max_pooling2d(3,2,'same') + tf.add(residual) (net/xception_body.py:281-286) */
 int xdet_maxpool3x3s2_add(const float* in, const float* residual, float* out, int N, int H, int W, int C, int ld,
                           void* stream);

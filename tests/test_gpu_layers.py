@@ -170,6 +170,33 @@ def test_fused_separable_block(case, prec, oracle):
         close(y_fused, ref, 3e-5)
 
 
+@pytest.mark.parametrize('N,H,W', [(2, 239, 239), (1, 3, 3), (3, 6, 33), (1, 35, 32), (2, 64, 61), (1, 7, 95)])
+@pytest.mark.parametrize('prec', ['f16x3', 'f16'])
+@pytest.mark.parametrize('cout', [64, 40])
+def test_conv3x3_staged_tile(N, H, W, prec, cout, oracle):
+    """block1_conv2's kernel (3x3 VALID over 32 channels, input tile staged once in LDS, taps = shifted fragment
+    reads) against the oracle and bit for bit against the implicit-GEMM kernel; ragged tiles in both directions"""
+    from xdet.ops import Conv2D
+    from xdet.runtime import DeviceTensor, set_precision
+    rng = np.random.default_rng(N * 1000 + H * 7 + W)
+    x = rng.standard_normal((N, H, W, 32)).astype(np.float32)
+    k = (rng.standard_normal((3, 3, 32, cout)) / 17).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.standard_normal(cout).astype(np.float32)
+    set_precision(prec)
+    try:
+        op = Conv2D(k, 1, 'VALID', scale=scale, shift=shift, relu=True)
+    finally:
+        set_precision('f32')
+    xd = DeviceTensor.from_numpy(x)
+    y_gemm = op(xd, planes=True).numpy()
+    y_tile = op(xd, planes=True, staged_tile=True).numpy()
+    assert y_tile.shape == (N, H - 2, W - 2, cout)
+    assert np.array_equal(y_tile, y_gemm)
+    if prec == 'f16x3':
+        close(y_tile, np.maximum(oracle.conv2d(x, k, 1, 'VALID') * scale + shift, 0), 3e-5)
+
+
 @pytest.mark.parametrize('H,W', [(237, 237), (119, 119), (60, 60), (7, 10)])
 def test_maxpool_same_padding_asymmetry(H, W, oracle):
     """TF SAME puts the odd padding pixel at the bottom/right: 60->30 pads 0/1, 237->119 pads 1/1."""

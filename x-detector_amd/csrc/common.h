@@ -129,6 +129,12 @@ int launch_sepconv_fused(const float* in, const float* w9c, const unsigned short
                          const unsigned short* wt_lo_blocked, const float* scale, const float* shift, float* out, int N,
                          int H, int W, int ld, int ldo, int cout_pad, int relu_in, int relu_out, hipStream_t s);
 
+// ---- 3x3 / stride 1 / VALID conv over 32 channels with the input tile staged once in LDS (conv3x3_patch.hip) ----
+bool conv3x3_patch_supported(int kh, int kw, int cin, int cout_pad, int stride, int dil, int pad_mode);
+int launch_conv3x3_patch(const unsigned short* in_hi, const unsigned short* in_lo, const unsigned short* wt_hi_blocked,
+                         const unsigned short* wt_lo_blocked, const float* scale, const float* shift, float* out, int N, int H,
+                         int W, int ldo, int relu, hipStream_t s);
+
 // ---- F1 pre-processing (preprocess.hip) ----------------------------------------------
 int launch_preprocess_eval(const unsigned char* img, int H, int W, float* out_chw, int S, hipStream_t s);
 

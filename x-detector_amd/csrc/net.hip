@@ -418,6 +418,7 @@ struct Plan {
   const float *emit_bn_scale = nullptr, *emit_bn_shift = nullptr;
   bool fuse_sepconv = true;      // option "sepconv" = "fused" | "split"
   bool subsample_projections = true;
+  bool patch_conv3x3 = true;     // option "conv3x3" = "patch" | "gemm"
   int add_conv(const std::string& name, int stage, const Buf& in_, ConvLayer* L, const Buf* res, int relu_in, Buf* out) {
     Buf in = in_;
     const int emit = L->precision == PREC_F32 ? 0 : emit_planes_next;
@@ -527,6 +528,18 @@ struct Plan {
       return add_conv(name, stage, sub, L, res, 0, out);
     }
     XDET_TRY(L->init(k, k, in.C, cout, stride, 1, pad_mode, pad_expl, pad_expl, kt->v.data(), scp, shp, relu_out));
+    // 3x3 VALID over 32 channels (block1_conv2): the input tile is staged in LDS once and the nine taps are shifted
+    // fragment reads of it (conv3x3_patch.hip) instead of nine DMA'd K steps; same products, same order
+    if (patch_conv3x3 && L->dma_capable() && in.hi && !in.planes_relu && !relu_in && !res && emit_planes_next == 0 &&
+        in.ld == 32 && conv3x3_patch_supported(k, k, in.C, L->cout_pad, stride, 1, pad_mode) && L->cout_pad == L->ld_out()) {
+      XDET_TRY(new_buf(in.H - 2, in.W - 2, cout, out));
+      const Buf i = in, o = *out;
+      ops.push_back({name + " [LDS-staged tile]", stage, L->flops(in.H, in.W), [=](int N, hipStream_t s) {
+                       return launch_conv3x3_patch(i.hi, i.lo, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale, L->d_shift, o.p, N, i.H,
+                                                   i.W, o.ld, L->relu_out, s);
+                     }});
+      return XDET_OK;
+    }
     return add_conv(name, stage, in, L, res, relu_in, out);
   }
   // (ReLU ->) separable_conv2d -> BN (-> +residual) (-> ReLU)   net/xception_body.py:220-234
@@ -1291,6 +1304,19 @@ int xdet_sepconv_fused_forward(void* dw_layer, void* pw_layer, const float* in, 
   return launch_sepconv_fused(in, D->d_w, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale, L->d_shift, out, N, H, W, ld_in, ld_out,
                               L->cout_pad, relu_in, L->relu_out, S(stream));
 }
+int xdet_conv3x3_patch_forward(void* layer, const uint16_t* in_hi, const uint16_t* in_lo, int N, int H, int W, float* out,
+                               int ld_out, void* stream) {
+  LayerBase* b = static_cast<LayerBase*>(layer);
+  XDET_REQUIRE(b && b->kind == 1, "not a conv layer");
+  ConvLayer* L = static_cast<ConvLayer*>(b);
+  XDET_REQUIRE(L->dma_capable() && L->groups == 1 && L->ld_in() == 32 && L->ld_out() == ld_out && L->cout_pad == ld_out &&
+                   conv3x3_patch_supported(L->kh, L->kw, L->cin, L->cout_pad, L->stride, L->dil, L->pad_mode),
+               "conv3x3_patch: needs a 3x3 / stride 1 / VALID conv over 32 channels with <= 64 outputs, split-precision mode");
+  XDET_REQUIRE(in_hi && (in_lo || L->precision == PREC_F16), "conv3x3_patch: NULL planes");
+  DeviceGuard guard(L->device);
+  return launch_conv3x3_patch(in_hi, L->precision == PREC_F16 ? nullptr : in_lo, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale,
+                              L->d_shift, out, N, H, W, ld_out, L->relu_out, S(stream));
+}
 int xdet_maxpool3x3s2_add(const float* in, const float* residual, float* out, int N, int H, int W, int C, int ld,
                           void* stream) {
   int Ho, Wo, pt, pl;
@@ -1373,6 +1399,11 @@ int xdet_net_set_option(void* net, const char* key, const char* value) {
   if (k == "sepconv") {
     XDET_REQUIRE(v == "fused" || v == "split", "sepconv must be fused | split");
     n->fuse_sepconv = v == "fused";
+    return XDET_OK;
+  }
+  if (k == "conv3x3") {
+    XDET_REQUIRE(v == "patch" || v == "gemm", "conv3x3 must be patch | gemm");
+    n->patch_conv3x3 = v == "patch";
     return XDET_OK;
   }
   set_last_error("unknown option: " + k);

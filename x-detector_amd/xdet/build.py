@@ -16,6 +16,7 @@ SOURCES = [
     ('elementwise.hip', []),
     ('spectral.hip', []),
     ('sepconv_fused.hip', []),
+    ('conv3x3_patch.hip', []),
     ('psroialign.hip', ['-ffp-contract=off']),
     ('proposals.hip', ['-ffp-contract=off']),
     ('detect.hip', ['-ffp-contract=off']),

@@ -100,9 +100,11 @@ class Conv2D(object):
                                      _host(sh) if sh is not None else None, 1 if relu else 0))
         self.handle = h
 
-    def __call__(self, x, residual=None, relu_in=False, stream=None, planes=False):
+    def __call__(self, x, residual=None, relu_in=False, stream=None, planes=False, staged_tile=False):
         """planes=True (split-precision modes only): split x into f16 hi/lo planes first and run the
-        LDS-DMA kernel -- the path every big contraction takes inside a net."""
+        LDS-DMA kernel -- the path every big contraction takes inside a net.  staged_tile=True (with planes; 3x3 VALID
+        stride 1 over 32 channels, <= 64 outputs): the kernel that stages the input tile once in LDS
+        (xdet_conv3x3_patch_forward, block1_conv2 inside a net)."""
         N, H, W, C = x.shape
         assert C == self.cin, (C, self.cin)
         ho, wo = ctypes.c_int(), ctypes.c_int()
@@ -113,8 +115,12 @@ class Conv2D(object):
             hi, lo = DeviceBuffer(n * 2 + 512, zero=True), DeviceBuffer(n * 2 + 512, zero=True)
             st = stream.handle if stream else None
             check(lib().xdet_split_f32(x.ptr, hi.ptr, lo.ptr, N * H * W, x.ld, 1 if relu_in else 0, st))
-            check(lib().xdet_conv_forward_planes(self.handle, hi.ptr, lo.ptr, N, H, W, x.ld, out.ptr, out.ld,
-                                                 residual.ptr if residual is not None else None, st))
+            if staged_tile:
+                assert residual is None
+                check(lib().xdet_conv3x3_patch_forward(self.handle, hi.ptr, lo.ptr, N, H, W, out.ptr, out.ld, st))
+            else:
+                check(lib().xdet_conv_forward_planes(self.handle, hi.ptr, lo.ptr, N, H, W, x.ld, out.ptr, out.ld,
+                                                     residual.ptr if residual is not None else None, st))
             synchronize(stream)
             return out
         check(lib().xdet_conv_forward(self.handle, x.ptr, N, H, W, x.ld, out.ptr, out.ld,
