@@ -33,12 +33,20 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--only', default='')
     ap.add_argument('--planes', action='store_true', help='A operand pre-split into f16 planes (LDS-DMA kernel)')
+    ap.add_argument('--custom', action='append', default=[],
+                    help='extra 1x1 GEMM shape "H,W,cin,cout" (replaces the built-in list); repeatable')
     a = ap.parse_args()
+    shapes = SHAPES
+    if a.custom:
+        shapes = []
+        for c in a.custom:
+            H, W, cin, cout = [int(v) for v in c.split(',')]
+            shapes.append(('gemm M=%d*B K=%d N=%d' % (H * W, cin, cout), H, W, cin, cout, 1, 1, 1, 'SAME'))
     set_precision(a.precision)
     rng = np.random.default_rng(0)
     st = Stream()
     tot_f = tot_t = 0
-    for name, H, W, cin, cout, kh, kw, s, pad in SHAPES:
+    for name, H, W, cin, cout, kh, kw, s, pad in shapes:
         if a.only and a.only not in name:
             continue
         x = DeviceTensor.from_numpy(rng.standard_normal((a.batch, H, W, cin)).astype(np.float32))

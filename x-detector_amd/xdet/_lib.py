@@ -141,6 +141,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError('libxdet_hip.so is missing (%s): run `python __graft_entry__.py` / '
                               'xdet/build.py; there is no CPU fallback' % LIB_PATH)
+        # the host driver of these boxes only supports dmabuf IPC; RCCL's intra-node P2P (xdet_comm_*) fails with
+        # "hipIpcGetMemHandle: invalid argument" otherwise.  Read by the HSA runtime when it starts: set before loading.
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)      # AttributeError if the symbol is not exported
