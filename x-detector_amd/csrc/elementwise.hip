@@ -433,50 +433,78 @@ int launch_split_f32_subsample2(const float* in, unsigned short* hi, unsigned sh
   return XDET_OK;
 }
 
-// grid.x = N*Ho output rows, grid.y covers Wo * ld/4 items; one thread = 4 channels of one output pixel
+// tf.layers.max_pooling2d(3, 2, 'same') (+ residual).  One thread = 4 channels of one output column, walking
+// MP_ROWS output rows downwards: consecutive windows share an input row (2 oy + 1 - pad), whose 3-column maximum is
+// carried in registers, so every output costs 6 loads instead of 9 and the shared rows are not fetched again at all
+// (one thread per output pixel re-read them through L2, and with more rows in flight than the 4 MB L2 of an XCD holds,
+// from HBM: 1.4x the input by FETCH_SIZE).  The 1.5x horizontal overlap stays inside a wave's neighbouring lanes
+// (TA / L1).  max is exact, so the result does not depend on the order.
+constexpr int MP_ROWS = 8;
+
+__device__ __forceinline__ float4 mp_max4(float4 a, float4 b) {
+  // (plain v_max_f32: fmaxf() on a loaded value costs a second, canonicalising v_max_f32)
+  float4 r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r.x) : "v"(a.x), "v"(b.x));
+  asm("v_max_f32 %0, %1, %2" : "=v"(r.y) : "v"(a.y), "v"(b.y));
+  asm("v_max_f32 %0, %1, %2" : "=v"(r.z) : "v"(a.z), "v"(b.z));
+  asm("v_max_f32 %0, %1, %2" : "=v"(r.w) : "v"(a.w), "v"(b.w));
+  return r;
+}
+
+// grid.x = N * ceil(Ho / MP_ROWS) row bands (XCD-aware), grid.y covers Wo * ld/4 items
 __global__ __launch_bounds__(256) void maxpool3x3s2_add_kernel(const float* __restrict__ in,
                                                                const float* __restrict__ res,
                                                                float* __restrict__ out, int H, int W, int ld, int Ho,
-                                                               int Wo, int pad_t, int pad_l, int norows) {
+                                                               int Wo, int pad_t, int pad_l, int nbands, int bands_per_image) {
   const int c4n = ld >> 2;
   const int item = blockIdx.y * 256 + threadIdx.x;
   if (item >= Wo * c4n) return;
   const int ox = item / c4n;
   const int c = (item - ox * c4n) * 4;
-  const int per_xcd = gridDim.x >> 3;          // XCD-aware row bands (see depthwise3x3_kernel)
-  const int orow = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // n*Ho + oy
-  if (orow >= norows) return;
-  const int n = orow / Ho;
-  const int oy = orow - n * Ho;
+  const int per_xcd = gridDim.x >> 3;          // XCD-aware bands (see depthwise3x3_kernel)
+  const int band = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (band >= nbands) return;
+  const int n = band / bands_per_image;
+  const int oy0 = (band - n * bands_per_image) * MP_ROWS;
   const float* base = in + (size_t)n * H * W * ld + c;
-  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-#pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int iy = oy * 2 - pad_t + ky;
-    if ((unsigned)iy >= (unsigned)H) continue;
+  const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  const int ix0 = ox * 2 - pad_l;
+  // 3-column maximum of one input row (-inf outside the image: SAME padding never wins a max)
+  auto hmax = [&](int iy) {
+    float4 m = ninf;
+    if ((unsigned)iy >= (unsigned)H) return m;
+    const float* row = base + (size_t)iy * W * ld;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-      const int ix = ox * 2 - pad_l + kx;
-      if ((unsigned)ix >= (unsigned)W) continue;
-      const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)iy * W + ix) * ld);
-      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      const int ix = ix0 + kx;
+      if ((unsigned)ix < (unsigned)W) m = mp_max4(m, *reinterpret_cast<const float4*>(row + (size_t)ix * ld));
     }
+    return m;
+  };
+  float4 carry = hmax(oy0 * 2 - pad_t);        // first row of the first window
+  const int oy1 = min(Ho, oy0 + MP_ROWS);
+  for (int oy = oy0; oy < oy1; ++oy) {
+    const int iy = oy * 2 - pad_t;
+    const float4 a = hmax(iy + 1), b = hmax(iy + 2);
+    float4 m = mp_max4(mp_max4(carry, a), b);
+    carry = b;                                 // row iy + 2 is the first row of the next window
+    const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * ld + c;
+    if (res) {
+      const float4 r = *reinterpret_cast<const float4*>(res + o);
+      m.x += r.x; m.y += r.y; m.z += r.z; m.w += r.w;
+    }
+    *reinterpret_cast<float4*>(out + o) = m;
   }
-  const size_t o = ((size_t)orow * Wo + ox) * ld + c;
-  if (res) {
-    const float4 r = *reinterpret_cast<const float4*>(res + o);
-    m.x += r.x; m.y += r.y; m.z += r.z; m.w += r.w;
-  }
-  *reinterpret_cast<float4*>(out + o) = m;
 }
 
 int launch_maxpool3x3s2_add(const float* in, const float* res, float* out, int N, int H, int W, int C, int ld,
                             int Ho, int Wo, int pad_t, int pad_l, hipStream_t s) {
   XDET_REQUIRE(ld % 4 == 0 && ld >= C, "maxpool: channel stride must be a multiple of 4");
   if ((int64_t)N * Ho == 0) return XDET_OK;
-  const dim3 grid((unsigned)(cdiv(N * Ho, 8) * 8), (unsigned)cdiv((int64_t)Wo * (ld / 4), 256));
+  const int bpi = (int)cdiv(Ho, MP_ROWS), nbands = N * bpi;
+  const dim3 grid((unsigned)(cdiv(nbands, 8) * 8), (unsigned)cdiv((int64_t)Wo * (ld / 4), 256));
   hipLaunchKernelGGL(maxpool3x3s2_add_kernel, grid, dim3(256), 0, s, in, res, out, H, W, ld, Ho, Wo, pad_t, pad_l,
-                     N * Ho);
+                     nbands, bpi);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }

@@ -12,7 +12,7 @@
 //
 // A workgroup (4 waves) works on tiles of 4 rows x 30 pixels (a 128-row GEMM tile with 8 idle rows: 30 + 2 halo
 // pixels are exactly four 1 KB DMA pieces) x 128 output channels; channel chunks of 32 are the K steps.  The
-// patch of the next (tile, chunk) is in flight while the current one is filtered and multiplied; ~73 KB of LDS
+// patch of the next (tile, chunk) is in flight while the current one is filtered and multiplied; ~79 KB of LDS
 // -> two workgroups per CU cover each other's barriers.  Arithmetic and accumulation order are exactly those
 // of depthwise3x3_tile_kernel + split + conv_dma_f16_kernel, so the result is bit-identical to the two-kernel
 // form (tests/test_gpu_layers.py).  Cout = 256 runs as two 128-wide passes over the same patch (second pass
@@ -28,7 +28,13 @@ typedef unsigned short u16;
 
 constexpr int SF_R = 4, SF_X = 30, SF_P = 32;       // tile rows, tile width, patch pitch (pixels)
 constexpr int SF_ROWS = SF_R + 2;                   // patch rows
-constexpr int SF_PATCH_F = SF_ROWS * SF_P * 32;     // floats per patch buffer (24 KB)
+// The patch in LDS: 8-pixel pieces of 1 KB (one DMA instruction each), each followed by a 128 B pad.  The pad flips
+// the bank half (128 B of a pixel = half of the 64 banks) of every second piece, so that the four lane groups of the
+// stencil's ds_read_b128 (lanes of strips s and s+2 share a group and read pixels 8 apart) are conflict-free; with
+// dense rows they were 2-way conflicts and the stencil reads -- 60 % of the kernel's LDS cycles -- took twice as long.
+constexpr int SF_PIECE_F = 8 * 32 + 32;             // floats per piece incl. pad (1152 B)
+constexpr int SF_ROW_F = (SF_P / 8) * SF_PIECE_F;   // floats per patch row (4608 B)
+constexpr int SF_PATCH_F = SF_ROWS * SF_ROW_F;      // floats per patch buffer (27 KB)
 constexpr int SF_KMAX = 256;                        // input channels (dw taps live in LDS)
 constexpr int SF_BN = 128;                          // output channels per pass
 constexpr int SF_NJ = SF_ROWS * (SF_P / 8) / 4;     // DMA pieces per wave per chunk (6)
@@ -69,7 +75,15 @@ __device__ __forceinline__ sf_f16x8 sf_ds_read_b128(unsigned addr) {
   return r;
 }
 
-template <bool SPLIT3>
+// ReLU of a value that came out of an asm LDS read.  fmaxf() would first canonicalise it (a second v_max_f32 per
+// element: the compiler cannot know it is not a signalling NaN) -- 72 extra VALU instructions per 32-channel chunk.
+__device__ __forceinline__ float sf_relu(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+template <bool SPLIT3, bool RELU_IN>
 __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p) {
   __shared__ __attribute__((aligned(16))) float s_patch[2][SF_PATCH_F];
   __shared__ __attribute__((aligned(16))) u16 s_a[2 * 128 * 32];        // A tile: hi rows, then lo rows (16 KB)
@@ -129,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
       const int soff = tile_base + ((rr - 1) * p.W + seg * 8 - 1) * p.ld * 4;
       const unsigned voff = ok ? (unsigned)(soff + lane_off) : 0xffffffffu;          // out of bounds -> zeros
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsrc, (__attribute__((address_space(3))) void*)(&s_patch[buf][(rr * SF_P + seg * 8) * 32]), 16, voff, 0, 0, 0);
+          rsrc, (__attribute__((address_space(3))) void*)(&s_patch[buf][rr * SF_ROW_F + seg * SF_PIECE_F]), 16, voff, 0, 0, 0);
     }
   };
 
@@ -196,8 +210,10 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
       __builtin_amdgcn_sched_barrier(0);
       // -- depthwise 3x3, one patch row (6 pixels x 4 channels) and its three taps at a time; per output the FMA
       //    order is ky, kx ascending = depthwise3x3_tile_kernel's --
-      const float lo_clip = p.relu_in ? 0.f : -INFINITY;
-      const unsigned t_addr = sf_lds_addr(&s_patch[buf][0]) + (unsigned)(((wave * SF_P + pxb) * 32 + c4 * 4) * 4);
+      // pixels pxb .. pxb+3 sit in one piece; pxb+4, pxb+5 are in the next one (behind the pad) for the odd strips
+      const unsigned t_addr = sf_lds_addr(&s_patch[buf][0]) +
+                              (unsigned)((wave * SF_ROW_F + pxb * 32 + (pxb >> 3) * 32 + c4 * 4) * 4);
+      const unsigned t_hi = t_addr + 512u + ((pxb & 7) == 4 ? 128u : 0u);
       const unsigned w_addr = sf_lds_addr(s_w) + (unsigned)((chunk * 32 + c4 * 4) * 4);
       sf_f32x4 a[4];
 #pragma unroll
@@ -205,9 +221,9 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         sf_f32x4 col[6], ww[3];
-        const unsigned ra = t_addr + ky * (SF_P * 32 * 4);
+        const unsigned ra = t_addr + ky * (SF_ROW_F * 4), rb = t_hi + ky * (SF_ROW_F * 4);
         col[0] = sf_ds_read_f4<0>(ra);   col[1] = sf_ds_read_f4<128>(ra); col[2] = sf_ds_read_f4<256>(ra);
-        col[3] = sf_ds_read_f4<384>(ra); col[4] = sf_ds_read_f4<512>(ra); col[5] = sf_ds_read_f4<640>(ra);
+        col[3] = sf_ds_read_f4<384>(ra); col[4] = sf_ds_read_f4<0>(rb);   col[5] = sf_ds_read_f4<128>(rb);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) ww[kx] = sf_ds_read_f4<0>(w_addr + (unsigned)((ky * 3 + kx) * p.ld * 4));
         asm volatile("s_waitcnt lgkmcnt(0)"
@@ -215,8 +231,10 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
                        "+v"(ww[1]), "+v"(ww[2])::"memory");
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-          col[k].x = fmaxf(col[k].x, lo_clip); col[k].y = fmaxf(col[k].y, lo_clip);
-          col[k].z = fmaxf(col[k].z, lo_clip); col[k].w = fmaxf(col[k].w, lo_clip);
+          if (RELU_IN) {
+            col[k].x = sf_relu(col[k].x); col[k].y = sf_relu(col[k].y);
+            col[k].z = sf_relu(col[k].z); col[k].w = sf_relu(col[k].w);
+          }
         }
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
@@ -333,8 +351,13 @@ int launch_sepconv_fused(const float* in, const float* w9c, const unsigned short
     p.tiles_per_block = 0;
     // two workgroups per CU (LDS); a multiple of 8 so that every XCD gets the same number
     const dim3 g((unsigned)std::min<int64_t>(512, cdiv(nt, 8) * 8));
-    if (wt_lo_blocked) hipLaunchKernelGGL((sepconv_fused_kernel<true>), g, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((sepconv_fused_kernel<false>), g, dim3(256), 0, s, p);
+    if (wt_lo_blocked) {
+      if (relu_in) hipLaunchKernelGGL((sepconv_fused_kernel<true, true>), g, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((sepconv_fused_kernel<true, false>), g, dim3(256), 0, s, p);
+    } else {
+      if (relu_in) hipLaunchKernelGGL((sepconv_fused_kernel<false, true>), g, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((sepconv_fused_kernel<false, false>), g, dim3(256), 0, s, p);
+    }
     XDET_LAUNCH_CHECK();
   }
   return XDET_OK;

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libxdet_hip.so')
+# XDET_LIB: another build of the same library (A/B measurements of kernel variants on one box)
+LIB_PATH = os.environ.get('XDET_LIB') or os.path.join(_HERE, 'libxdet_hip.so')
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
