@@ -267,6 +267,199 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
   conv_epilogue<WM, WN, TM, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wm, wn, m0, n0);
 }
 
+// ---------------------------------------------------------------------------------------
+// Small-M variant (single images and small batches: a 900-row layer is 8 x 12 workgroups of 128 x 64).  With that few
+// workgroups nothing hides a K step's latency but the step pipeline itself, and the two-stage loop above spends ~1.1 us
+// per 32-deep step (DMA issue -> landed -> barrier -> fragments -> 12 MFMAs) for 0.19 us of matrix work.  Here the
+// operand ring has FOUR stages and three K steps are in flight: the barrier of step kt waits with vmcnt(2 steps' worth)
+// for stage kt only, so a step costs its own issue + fragment reads + MFMAs.  The fragment reads are inline asm: the
+// compiler would put a full vmcnt(0) in front of every LDS read while LDS-DMA writes are outstanding.  Every step
+// issues the same six DMA instructions (steps past the end fetch the zero page into a stage nobody reads) so that the
+// vmcnt arithmetic is static.  Same K order, same product order: bit-identical to conv_dma_f16_kernel.
+// ---------------------------------------------------------------------------------------
+template <int OFF>
+__device__ __forceinline__ f16x8 cd_ds_read_b128(unsigned addr) {
+  f16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+
+template <int NSPLIT>
+__global__ __launch_bounds__(256) void conv_dma_deep_kernel(ConvParams p_in) {
+  constexpr int BM = 128, BN = 64, NW = 4, NSTAGE = 4;
+  constexpr int TN = 2;                            // wave tile 32 x 64
+  constexpr int A_IT = BM / (16 * NW), B_IT = BN / (16 * NW);
+  constexpr int ROWB = 32;
+  constexpr int STAGE = (2 * BM + 2 * BN) * ROWB;  // halves per stage (24 KB)
+  constexpr int PIECES = (A_IT + B_IT) * (NSPLIT > 1 ? 2 : 1);
+  extern __shared__ __attribute__((aligned(16))) u16 smem16[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nby = p_in.Cout_pad / BN;
+  const int slot = blockIdx.x >> 3;
+  int bx, n0;
+  ConvParams p = p_in;
+  if (p_in.group_rows) {                           // grouped GEMM: see conv_dma_f16_kernel
+    const int mt = p_in.group_rows / BM;
+    const int tpg = mt * nby;
+    const int g = (slot / tpg) * 8 + (blockIdx.x & 7);
+    const int w = slot - (slot / tpg) * tpg;
+    if ((int64_t)g * p_in.group_rows >= p_in.M) return;
+    bx = g * mt + w / nby;
+    n0 = (w % nby) * BN;
+    p.wt_hi = p_in.wt_hi + (size_t)g * p_in.group_wt_stride;
+    p.wt_lo = p_in.wt_lo ? p_in.wt_lo + (size_t)g * p_in.group_wt_stride : nullptr;
+    p.scale = p_in.scale + (size_t)g * p_in.Cout_pad;
+    p.shift = p_in.shift + (size_t)g * p_in.Cout_pad;
+  } else {
+    bx = (slot / nby) * 8 + (blockIdx.x & 7);
+    if (bx * BM >= p_in.M) return;
+    n0 = (slot % nby) * BN;
+  }
+  const int m0 = bx * BM;
+
+  const int lr = lane >> 2, pos = lane & 3;
+  int iy0[A_IT], ix0[A_IT], pbase[A_IT], achunk[A_IT];
+#pragma unroll
+  for (int q = 0; q < A_IT; ++q) {
+    const int rt = (wave * A_IT + q) * 16 + lr;
+    achunk[q] = (pos ^ ((rt >> 2) & 3)) * 8;
+    const int m = m0 + rt;
+    if (m < p.M) {
+      const int hw = p.Ho * p.Wo;
+      const int n = m / hw;
+      const int rem = m - n * hw;
+      const int oy = rem / p.Wo;
+      const int ox = rem - oy * p.Wo;
+      iy0[q] = oy * p.stride - p.pad_t;
+      ix0[q] = ox * p.stride - p.pad_l;
+      pbase[q] = n * p.H * p.W;
+    } else {
+      iy0[q] = -(1 << 20);
+      ix0[q] = 0;
+      pbase[q] = 0;
+    }
+  }
+  size_t boff[B_IT];
+#pragma unroll
+  for (int q = 0; q < B_IT; ++q) {
+    const int rt = (wave * B_IT + q) * 16 + lr;
+    boff[q] = (size_t)(n0 + rt) * 32 + (pos ^ ((rt >> 2) & 3)) * 8;
+  }
+  const int nk = p.Kp / 32;
+  const int ntaps = p.KH * p.KW;
+  const unsigned c32n = (unsigned)(p.ldi >> 5);
+
+  auto issue = [&](int kt, int buf) {              // always PIECES instructions
+    u16* Ah = smem16 + buf * STAGE;
+    u16* Al = Ah + BM * ROWB;
+    u16* Bh = Al + BM * ROWB;
+    u16* Bl = Bh + BN * ROWB;
+    const bool live = kt < nk;
+    const int cc = kt / ntaps;
+    const int tap = kt - cc * ntaps;
+    const int ky = tap / p.KW;
+    const int dy = ky * p.dil, dx = (tap - ky * p.KW) * p.dil;
+    const size_t k0 = (size_t)(tap * (p.Cin_p >> 5) + cc) * p.Cout_pad * 32;
+#pragma unroll
+    for (int q = 0; q < A_IT; ++q) {
+      const int iy = iy0[q] + dy, ix = ix0[q] + dx;
+      const bool ok = live && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const unsigned pix = (unsigned)(pbase[q] + iy * p.W + ix);
+      const size_t off = ((size_t)((pix >> 4) * c32n + cc) << 9) + ((pix & 15) << 5) + achunk[q];
+      XDET_GLDS16(ok ? p.in_hi + off : p.zeros, Ah + (wave * A_IT + q) * 16 * ROWB);
+      if (NSPLIT > 1) XDET_GLDS16(ok ? p.in_lo + off : p.zeros, Al + (wave * A_IT + q) * 16 * ROWB);
+    }
+#pragma unroll
+    for (int q = 0; q < B_IT; ++q) {
+      XDET_GLDS16(live ? p.wt_hi + boff[q] + k0 : p.zeros, Bh + (wave * B_IT + q) * 16 * ROWB);
+      if (NSPLIT > 1) XDET_GLDS16(live ? p.wt_lo + boff[q] + k0 : p.zeros, Bl + (wave * B_IT + q) * 16 * ROWB);
+    }
+  };
+
+  f32x16 acc[1][TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+  const int frow = lane & 31, fh = lane >> 5;
+  // byte offsets of this lane's fragments inside a stage: [ks] for A (row wave*32 + frow), [ks][j] for B
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(smem16);
+  unsigned a_off[2], b_off[2][TN];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int c = ks * 2 + fh;
+    const int ra = wave * 32 + frow;
+    a_off[ks] = (unsigned)(ra * ROWB + ((c ^ ((ra >> 2) & 3)) << 3)) * 2u;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int rb = j * 32 + frow;
+      b_off[ks][j] = (unsigned)(2 * BM * ROWB + rb * ROWB + ((c ^ ((rb >> 2) & 3)) << 3)) * 2u;
+    }
+  }
+
+  issue(0, 0);
+  issue(1, 1);
+  issue(2, 2);
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt has landed (the two younger steps may still be in flight) and every wave is done with stage kt-1
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * PIECES) : "memory");
+    issue(kt + 3, (kt + 3) & 3);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned sb = lds0 + (unsigned)((kt & 3) * STAGE * 2);
+    f16x8 ah[2], al[2], bh[2][TN], bl[2][TN];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      ah[ks] = cd_ds_read_b128<0>(sb + a_off[ks]);
+      if (NSPLIT > 1) al[ks] = cd_ds_read_b128<BM * ROWB * 2>(sb + a_off[ks]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[ks][j] = cd_ds_read_b128<0>(sb + b_off[ks][j]);
+        if (NSPLIT > 1) bl[ks][j] = cd_ds_read_b128<BN * ROWB * 2>(sb + b_off[ks][j]);
+      }
+    }
+    if (NSPLIT > 1)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(ah[0]), "+v"(ah[1]), "+v"(al[0]), "+v"(al[1]), "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]),
+                     "+v"(bh[1][1]), "+v"(bl[0][0]), "+v"(bl[0][1]), "+v"(bl[1][0]), "+v"(bl[1][1])::"memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(ah[0]), "+v"(ah[1]), "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]), "+v"(bh[1][1])::"memory");
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (NSPLIT > 1) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh[ks][j], acc[0][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl[ks][j], acc[0][j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[ks][j], acc[0][j], 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy tail steps write LDS too
+  conv_epilogue<32, 64, 1, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wave, 0, m0, n0);
+}
+
+template <int NSPLIT>
+static int launch_deep(const ConvParams& p, hipStream_t s) {
+  constexpr size_t lds = (size_t)4 * (2 * 128 + 2 * 64) * 32 * sizeof(u16);
+  auto kern = conv_dma_deep_kernel<NSPLIT>;
+  static DeviceOnce once;
+  XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
+  dim3 grid((unsigned)(cdiv(cdiv(p.M, 128), 8) * 8 * (p.Cout_pad / 64)));
+  if (p.group_rows) {
+    const int64_t groups = p.M / p.group_rows, tpg = (int64_t)(p.group_rows / 128) * (p.Cout_pad / 64);
+    grid = dim3((unsigned)(cdiv(groups, 8) * 8 * tpg));
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE = 2>
 static int launch_d(const ConvParams& p, hipStream_t s) {
   constexpr size_t lds = (size_t)NSTAGE * (2 * BM + 2 * BN) * 32 * sizeof(u16);
@@ -310,7 +503,11 @@ int launch_conv_mfma_dma(const ConvParams& p, int n_tile, int nsplit, hipStream_
     // small batches: 128 x 128 tiles leave most of the 256 CUs idle (a 900-row layer is 8 x 4..6 workgroups); halve
     // the N tile to double the workgroup count -- per-element K order is unchanged, so results stay bit-identical
     const int64_t b128 = cdiv(p.M, 128) * (p.Cout_pad / 128);
-    if (nsplit == 3 && b128 < 128 && (!p.group_rows || p.group_rows % 128 == 0)) return launch_d<128, 64, 4, 1, 3>(p, s);
+    if (nsplit == 3 && b128 < 128 && (!p.group_rows || p.group_rows % 128 == 0)) {
+      // few workgroups: the four-stage ring (XDET_CONV_SMALL=2stage: the two-stage kernel, for A/B runs)
+      static const bool two_stage = getenv("XDET_CONV_SMALL") && !strcmp(getenv("XDET_CONV_SMALL"), "2stage");
+      return two_stage ? launch_d<128, 64, 4, 1, 3>(p, s) : launch_deep<3>(p, s);
+    }
     return nsplit == 1 ? launch_d<128, 128, 2, 2, 1>(p, s) : launch_d<128, 128, 2, 2, 3>(p, s);
   }
   if (n_tile == 64) return nsplit == 1 ? launch_d<128, 64, 4, 1, 1>(p, s) : launch_d<128, 64, 4, 1, 3>(p, s);
