@@ -109,7 +109,7 @@ int launch_stem_conv3x3s2(const float* in_nchw, const float* w27x32, const float
 int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, int64_t n_pix, int ld, int relu,
                      hipStream_t s);
 int launch_split_f32_subsample2(const float* in, unsigned short* hi, unsigned short* lo, int N, int H, int W, int ld,
-                                hipStream_t s);
+                                hipStream_t s, const float* scale = nullptr, const float* shift = nullptr);
 int launch_depthwise3x3_split(const float* in, const float* w9c, unsigned short* hi, unsigned short* lo, int N,
                               int H, int W, int C, int ld, int dil, int relu_in, hipStream_t s);
 

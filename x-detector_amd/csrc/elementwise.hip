@@ -398,7 +398,8 @@ int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, in
 __global__ __launch_bounds__(256) void split_f32_subsample2_kernel(const float* __restrict__ in,
                                                                    unsigned short* __restrict__ hi,
                                                                    unsigned short* __restrict__ lo, int N, int H, int W,
-                                                                   int Ho, int Wo, int ld) {
+                                                                   int Ho, int Wo, int ld, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift) {
   const int c32n = ld >> 5;
   const int64_t n_pix = (int64_t)N * Ho * Wo;
   const int64_t n8 = ((n_pix + 15) >> 4) * c32n * 64;
@@ -412,7 +413,17 @@ __global__ __launch_bounds__(256) void split_f32_subsample2_kernel(const float* 
     const int rem = (int)(pix - (int64_t)n * Ho * Wo);
     const int oy = rem / Wo, ox = rem - oy * Wo;
     const float* src = in + (((size_t)n * H + 2 * oy) * W + 2 * ox) * ld + cc * 32 + (i & 3) * 8;
-    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    if (scale) {   // relu(x * scale + shift): a pre-activation BN in front of the projection (net/resnet_v2.py:142-156)
+      const float* sc = scale + cc * 32 + (i & 3) * 8;
+      const float* sh = shift + cc * 32 + (i & 3) * 8;
+      const float4 s0 = *reinterpret_cast<const float4*>(sc), s1 = *reinterpret_cast<const float4*>(sc + 4);
+      const float4 h0 = *reinterpret_cast<const float4*>(sh), h1 = *reinterpret_cast<const float4*>(sh + 4);
+      a.x = fmaxf(fmaf(a.x, s0.x, h0.x), 0.f); a.y = fmaxf(fmaf(a.y, s0.y, h0.y), 0.f);
+      a.z = fmaxf(fmaf(a.z, s0.z, h0.z), 0.f); a.w = fmaxf(fmaf(a.w, s0.w, h0.w), 0.f);
+      b.x = fmaxf(fmaf(b.x, s1.x, h1.x), 0.f); b.y = fmaxf(fmaf(b.y, s1.y, h1.y), 0.f);
+      b.z = fmaxf(fmaf(b.z, s1.z, h1.z), 0.f); b.w = fmaxf(fmaf(b.w, s1.w, h1.w), 0.f);
+    }
     f16x8e h, l;
     split8(a, b, &h, &l);
     *reinterpret_cast<f16x8e*>(hi + i * 8) = h;
@@ -421,14 +432,15 @@ __global__ __launch_bounds__(256) void split_f32_subsample2_kernel(const float* 
 }
 
 int launch_split_f32_subsample2(const float* in, unsigned short* hi, unsigned short* lo, int N, int H, int W, int ld,
-                                hipStream_t s) {
+                                hipStream_t s, const float* scale, const float* shift) {
   XDET_REQUIRE(ld > 0 && ld % 32 == 0, "split: channel stride must be a multiple of 32");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int64_t n_pix = (int64_t)N * Ho * Wo;
   if (n_pix == 0) return XDET_OK;
   const int64_t n = cdiv(n_pix, 16) * 16 * ld;
   const int blocks = (int)std::min<int64_t>(cdiv(n / 8, 256), 256 * 32);
-  hipLaunchKernelGGL(split_f32_subsample2_kernel, dim3(blocks), dim3(256), 0, s, in, hi, lo, N, H, W, Ho, Wo, ld);
+  hipLaunchKernelGGL(split_f32_subsample2_kernel, dim3(blocks), dim3(256), 0, s, in, hi, lo, N, H, W, Ho, Wo, ld, scale,
+                     shift);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }

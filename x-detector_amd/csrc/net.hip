@@ -501,8 +501,11 @@ struct Plan {
   DepthwiseLayer* keep(DepthwiseLayer* L) { layers.emplace_back(L); return L; }
 
   // tf.layers.conv2d(use_bias=False) + BN (+ReLU)
+  // pre_sc / pre_sh (1x1 stride-2 projections only): the input is a raw tensor and the conv reads
+  // relu(in * pre_sc + pre_sh) -- the pre-activation BN of a ResNet v2 block, applied in the subsample pass
   int conv_bn(const std::string& name, const std::string& bn, float eps, int stage, const Buf& in, int k, int cout,
-              int stride, int pad_mode, int relu_out, const Buf* res, int relu_in, Buf* out, int pad_expl = 0) {
+              int stride, int pad_mode, int relu_out, const Buf* res, int relu_in, Buf* out, int pad_expl = 0,
+              const float* pre_sc = nullptr, const float* pre_sh = nullptr) {
     const HostTensor* kt;
     XDET_TRY(need(name + "/kernel", &kt, {k, k, in.C, cout}));
     std::vector<float> sc, sh;
@@ -512,9 +515,13 @@ struct Plan {
       scp = sc.data(); shp = sh.data();
     }
     ConvLayer* L = keep(new ConvLayer());
-    if (k == 1 && stride == 2 && pad_mode == 1 && g_default_precision != PREC_F32 && in.C >= 32 && !relu_in &&
-        !in.no_f32 && subsample_projections) {
-      // 1x1 / stride 2 / SAME (the residual projections): output (oy, ox) = input (2 oy, 2 ox) x W.  Subsample + split
+    XDET_REQUIRE(!pre_sc || (k == 1 && stride == 2 && g_default_precision != PREC_F32 && in.C >= 32 && !in.no_f32 &&
+                             in.ld % 32 == 0),
+                 "plan: a pre-activation can only be folded into a 1x1 stride-2 projection on the split path");
+    if (k == 1 && stride == 2 && (pad_mode == 1 || (pad_mode == 2 && pad_expl == 0)) &&
+        g_default_precision != PREC_F32 && in.C >= 32 && in.ld % 32 == 0 && !relu_in && !in.no_f32 &&
+        (subsample_projections || pre_sc)) {
+      // 1x1 / stride 2 / SAME or unpadded (the residual projections): output (oy, ox) = input (2 oy, 2 ox) x W.  Subsample + split
       // in one small pass (a quarter of the input), then a plain stride-1 GEMM on the LDS-DMA kernel -- the strided
       // gather through registers ran at 60-120 TFLOP/s.  Same products in the same order: bit-identical.
       XDET_TRY(L->init(1, 1, in.C, cout, 1, 1, 1, 0, 0, kt->v.data(), scp, shp, relu_out));
@@ -523,7 +530,7 @@ struct Plan {
       XDET_TRY(new_planes(&sub));
       const Buf i = in, o = sub;
       ops.push_back({name + "/subsample_split", stage, 0.0, [=](int N, hipStream_t s) {
-                       return launch_split_f32_subsample2(i.p, o.hi, o.lo, N, i.H, i.W, i.ld, s);
+                       return launch_split_f32_subsample2(i.p, o.hi, o.lo, N, i.H, i.W, i.ld, s, pre_sc, pre_sh);
                      }});
       return add_conv(name, stage, sub, L, res, 0, out);
     }
@@ -1122,6 +1129,7 @@ int ResNetTrunk::build() {
   const int filters[4] = {64, 128, 256, 512}, blocks[4] = {3, 4, 6, 3}, strides[4] = {1, 2, 2, 2};
   Buf fused_pre;                 // planes-only pre-activation of the NEXT block, written by this block's last conv
   bool have_fused = false;
+  const float *fused_sc = nullptr, *fused_sh = nullptr;   // its BN (a strided projection applies it to its own subsample)
   for (int st = 0; st < 4; ++st)
     for (int b = 0; b < blocks[st]; ++b) {
       const int f = filters[st], s = b == 0 ? strides[st] : 1;
@@ -1133,20 +1141,27 @@ int ResNetTrunk::build() {
         XDET_TRY(add_bn_relu(bname(), x, &pre));
       }
       have_fused = false;
-      if (b == 0) XDET_TRY(conv_bn(cname(), "", 0.f, 0, pre, 1, 4 * f, s, s > 1 ? 2 : 1, 0, nullptr, 0, &shortcut, 0));
+      if (b == 0) {
+        if (pre.no_f32 && s > 1) {
+          // the pre-activation exists as full-resolution planes only (conv1 reads those); the stride-2 projection
+          // takes the raw block input and applies the BN + ReLU to the quarter of the pixels it reads
+          XDET_TRY(conv_bn(cname(), "", 0.f, 0, x, 1, 4 * f, s, 2, 0, nullptr, 0, &shortcut, 0, fused_sc, fused_sh));
+        } else {
+          XDET_TRY(conv_bn(cname(), "", 0.f, 0, pre, 1, 4 * f, s, s > 1 ? 2 : 1, 0, nullptr, 0, &shortcut, 0));
+        }
+      }
       const std::string c1 = cname(), b1 = bname(), c2 = cname(), b2 = bname(), c3 = cname();
       // conv1x1 -> (BN+ReLU fused into its epilogue) -> conv3x3/s -> (BN+ReLU fused) -> conv1x1 + shortcut
       if (s == 1) emit_planes_next = 3;           // a stride-1 3x3 takes its input as planes (only)
       XDET_TRY(conv_bn(c1, b1, 1e-5f, 0, pre, 1, f, 1, 1, 1, nullptr, 0, &y1));
       emit_planes_next = 3;                       // the closing 1x1 always does
       XDET_TRY(conv_bn(c2, b2, 1e-5f, 0, y1, 3, f, s, s > 1 ? 2 : 1, 1, nullptr, 0, &y2, 1));
-      // The next block opens with BN+ReLU of this block's output.  Unless that block starts with strided
-      // convs (which gather f32), fold it in: the closing conv writes its f32 output (the identity
-      // shortcut) AND relu(bn_next(output)) as planes, and the separate element-wise pass disappears.
+      // The next block opens with BN+ReLU of this block's output.  Fold it in: the closing conv writes its f32
+      // output (the identity shortcut) AND relu(bn_next(output)) as planes, and the separate element-wise pass
+      // disappears.  (A stage opener's strided projection cannot read those full-resolution planes: see above.)
       const bool last = st == 3 && b == blocks[st] - 1;
-      const bool next_strided = b == blocks[st] - 1 && !last;      // every later stage opens with stride 2
       float *nsc = nullptr, *nsh = nullptr;
-      if (!last && !next_strided && g_default_precision != PREC_F32) {
+      if (!last && g_default_precision != PREC_F32) {
         const std::string nbn = bi == 0 ? "batch_normalization" : "batch_normalization_" + std::to_string(bi);
         std::vector<float> sc, sh;
         XDET_TRY(fold_bn(nbn, 4 * f, 1e-5f, nullptr, &sc, &sh));
@@ -1169,6 +1184,8 @@ int ResNetTrunk::build() {
         fused_pre.planes_relu = false;
         y3.hi = y3.lo = nullptr;                    // the f32 tensor itself has no planes
         have_fused = true;
+        fused_sc = nsc;
+        fused_sh = nsh;
       }
       x = y3;
     }
