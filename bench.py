@@ -323,11 +323,11 @@ def main():
         fl = {'backbone': flops_img}
         net.set_images(W.synthetic_images(B, 480, seed=100 + rank))
 
-        use_graph = False
+        use_graph = not args.eager
         nets, sb, ways = [net], B, 1
 
         def step(graph=None, only_first=False):
-            net.forward_device(B)
+            net.forward_device(B, use_graph=use_graph if graph is None else graph)
 
     def sync_all():
         for nt in nets:

@@ -243,6 +243,9 @@ int xdet_resnet_create(void** net, int image_size, int max_batch);
 int xdet_resnet_set_weight(void* net, const char* name, const float* data_host, int ndim, const int64_t* dims);
 int xdet_resnet_build(void* net);
 int xdet_resnet_forward(void* net, const float* images_nchw, int N, float* out_nhwc, void* stream);
+/* the same forward as a replayed hipGraph (captured on the first call with a given (N, images, out) tuple; needs an
+ * explicit stream; falls back to the eager form while per-op profiling is enabled) */
+int xdet_resnet_forward_graph(void* net, const float* images_nchw, int N, float* out_nhwc, void* stream);
 int xdet_resnet_out_shape(void* net, int* Ho, int* Wo, int* C);
 int xdet_resnet_flops_per_image(void* net, double* flops);
 int xdet_resnet_destroy(void* net);

@@ -35,3 +35,25 @@ def test_resnet50_small_image_and_batch_tail(oracle):
     y = net.forward(imgs)                                      # N=3 < max_batch
     ref = oracle.resnet50_trunk(np.transpose(imgs, (0, 2, 3, 1)), w)
     assert np.abs(y - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_resnet50_graph_replay_is_the_eager_forward():
+    """xdet_resnet_forward_graph: same bits as the eager launch sequence, also after new images were copied into the
+    same device buffer (a replay reads the buffer, not a snapshot) and for a second batch size (its own graph)."""
+    from xdet import weights as W
+    from xdet.resnet import ResNet50Trunk
+    from xdet.runtime import set_precision, to_host
+    w = W.make_resnet50_weights(4321)
+    set_precision('f16x3')
+    try:
+        net = ResNet50Trunk(w, image_size=160, max_batch=4)
+    finally:
+        set_precision('f32')
+    for seed, n in [(3, 4), (4, 4), (5, 2), (6, 4)]:
+        imgs = W.synthetic_images(n, 160, seed=seed)
+        eager = net.forward(imgs)
+        net.set_images(imgs)
+        net.forward_device(n, use_graph=True)
+        net.stream.synchronize()
+        replay = to_host(net._out.ptr, (n,) + net.out_shape, np.float32)
+        assert np.array_equal(eager, replay), (seed, n)

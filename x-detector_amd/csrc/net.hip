@@ -1055,6 +1055,12 @@ struct ResNetTrunk : Plan {
   bool built = false;
   Buf in4, outb;
   double flops = 0;
+  typedef std::array<uintptr_t, 3> Key;            // (N, images, out): every pointer a captured graph bakes in
+  std::map<Key, hipGraphExec_t> graphs;
+  std::vector<Key> graph_order;
+  ~ResNetTrunk() {
+    for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+  }
 
   // Pre-activation bottlenecks (net/resnet_v2.py:142-184).  The BN+ReLU that follows the two inner
   // convs is folded into their epilogues; the one that opens a block cannot be (the raw block input
@@ -1637,6 +1643,43 @@ int xdet_resnet_forward(void* net, const float* images, int N, float* out_nhwc, 
   XDET_TRY(r->run_stage(0, N, s));
   if (out_nhwc)
     XDET_HIP(hipMemcpyAsync(out_nhwc, r->outb.p, (size_t)N * r->outb.per_image() * 4, hipMemcpyDeviceToDevice, s));
+  return XDET_OK;
+}
+int xdet_resnet_forward_graph(void* net, const float* images, int N, float* out_nhwc, void* stream) {
+  ResNetTrunk* r = static_cast<ResNetTrunk*>(net);
+  XDET_REQUIRE(r && r->built && images, "resnet_forward: bad arguments");
+  XDET_REQUIRE(N > 0 && N <= r->max_batch, "batch must be in 1..max_batch");
+  if (r->profiling) return xdet_resnet_forward(net, images, N, out_nhwc, stream);   // event pairs cannot be replayed
+  hipStream_t s = S(stream);
+  XDET_REQUIRE(s != nullptr, "graph replay needs an explicit (non-default) stream");
+  DeviceGuard guard(r->device);
+  const ResNetTrunk::Key key = {{(uintptr_t)N, (uintptr_t)images, (uintptr_t)out_nhwc}};
+  auto it = r->graphs.find(key);
+  if (it == r->graphs.end()) {
+    if (r->graphs.size() >= 8) {
+      const ResNetTrunk::Key old = r->graph_order.front();
+      r->graph_order.erase(r->graph_order.begin());
+      (void)hipGraphExecDestroy(r->graphs[old]);
+      r->graphs.erase(old);
+    }
+    hipGraph_t g = nullptr;
+    XDET_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = xdet_resnet_forward(net, images, N, out_nhwc, stream);
+    const hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc != XDET_OK || e != hipSuccess) {
+      if (g) (void)hipGraphDestroy(g);
+      if (rc != XDET_OK) return rc;
+      XDET_HIP(e);
+    }
+    hipGraphExec_t ge = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    XDET_HIP(ei);
+    r->graphs[key] = ge;
+    r->graph_order.push_back(key);
+    it = r->graphs.find(key);
+  }
+  XDET_HIP(hipGraphLaunch(it->second, s));
   return XDET_OK;
 }
 int xdet_resnet_out_shape(void* net, int* Ho, int* Wo, int* C) {

@@ -118,6 +118,7 @@ SIGNATURES = {
     'xdet_resnet_set_weight': (c_int, [c_void_p, ctypes.c_char_p, PF, c_int, ctypes.POINTER(c_int64)]),
     'xdet_resnet_build': (c_int, [c_void_p]),
     'xdet_resnet_forward': (c_int, [c_void_p, PF, c_int, PF, c_void_p]),
+    'xdet_resnet_forward_graph': (c_int, [c_void_p, PF, c_int, PF, c_void_p]),
     'xdet_resnet_out_shape': (c_int, [c_void_p] + [ctypes.POINTER(c_int)] * 3),
     'xdet_resnet_flops_per_image': (c_int, [c_void_p, ctypes.POINTER(c_double)]),
     'xdet_resnet_destroy': (c_int, [c_void_p]),

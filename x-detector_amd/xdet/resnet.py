@@ -32,8 +32,9 @@ class ResNet50Trunk(object):
         check(lib().xdet_memcpy_h2d(self._images.ptr, _host(a), a.nbytes, self.stream.handle))
         return a.shape[0]
 
-    def forward_device(self, n):
-        check(lib().xdet_resnet_forward(self.handle, self._images.ptr, n, self._out.ptr, self.stream.handle))
+    def forward_device(self, n, use_graph=False):
+        fn = lib().xdet_resnet_forward_graph if use_graph else lib().xdet_resnet_forward
+        check(fn(self.handle, self._images.ptr, n, self._out.ptr, self.stream.handle))
 
     def forward(self, images_nchw):
         """[N,3,S,S] -> NHWC [N,h,w,2048] (C = 2048 is already a multiple of 32: no padding)."""
