@@ -427,7 +427,9 @@ struct Plan {
     emit_bn_scale = emit_bn_shift = nullptr;
     // split path: big stride-1 contractions take their A operand as f16 planes through the LDS DMA;
     // if the producer did not emit planes, one cheap element-wise pass makes them (ReLU folded in)
-    if (L->dma_capable() && L->stride == 1) {
+    // (a strided conv takes planes too if its producer wrote them: the DMA gathers any pixel per row; it is not worth
+    //  a separate split pass over a tensor of which it reads a quarter)
+    if (L->dma_capable() && (L->stride == 1 || (in.hi && !(in.planes_relu && !relu_in)))) {
       if (in.hi && in.planes_relu && !relu_in) in.hi = in.lo = nullptr;   // relu(x) planes are no use here
       XDET_REQUIRE(!in.no_f32 || (in.hi && !relu_in), "plan: this tensor exists as planes only");
       if (in.hi && relu_in && in.planes_relu) {
@@ -1158,7 +1160,7 @@ int ResNetTrunk::build() {
       }
       const std::string c1 = cname(), b1 = bname(), c2 = cname(), b2 = bname(), c3 = cname();
       // conv1x1 -> (BN+ReLU fused into its epilogue) -> conv3x3/s -> (BN+ReLU fused) -> conv1x1 + shortcut
-      if (s == 1) emit_planes_next = 3;           // a stride-1 3x3 takes its input as planes (only)
+      emit_planes_next = 3;                       // the 3x3 (stride 1 or 2) takes its input as planes (only)
       XDET_TRY(conv_bn(c1, b1, 1e-5f, 0, pre, 1, f, 1, 1, 1, nullptr, 0, &y1));
       emit_planes_next = 3;                       // the closing 1x1 always does
       XDET_TRY(conv_bn(c2, b2, 1e-5f, 0, y1, 3, f, s, s > 1 ? 2 : 1, 1, nullptr, 0, &y2, 1));
