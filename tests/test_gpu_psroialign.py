@@ -63,6 +63,50 @@ def test_random_bit_exact(method, shape, oracle):
     assert np.array_equal(i, io)
 
 
+@pytest.mark.parametrize('method', ['max', 'mean'])
+@pytest.mark.parametrize('shape', [(3, 30, 30, 300, 7, 7), (9, 50, 50, 77, 7, 7), (2, 13, 17, 40, 3, 5), (1, 120, 120, 33, 7, 7)])
+@pytest.mark.parametrize('corners', [0, 1])
+def test_nhwc_bank10_form_bit_exact(method, shape, corners, oracle):
+    """The form the net runs: NHWC map with a padded channel stride, 10 channels per bin (one lane per bin,
+    psroialign_bin_kernel), ROIs as centres or as corners, images spread over the XCD-aware block order -- values and
+    argmax indices bit for bit against the oracle (which takes NCHW + centres).  120 x 120 maps give bins with more than
+    8 sample columns."""
+    import ctypes
+    from xdet._lib import lib, check
+    from xdet.runtime import DeviceBuffer, to_device, to_host
+    n, h, w, r, gh, gw = shape
+    c = 10 * gh * gw
+    ldc = -(-c // 32) * 32
+    rng = np.random.default_rng(n * 100 + h)
+    feat = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    rois = random_rois(rng, n, max(r, 8))[:, :r]
+    po, io = oracle.ps_roi_align(feat, rois, gw, gh, method)
+    nhwc = np.zeros((n, h, w, ldc), np.float32)
+    nhwc[..., :c] = np.transpose(feat, (0, 2, 3, 1))
+    rin = rois
+    if corners:     # (ymin, xmin, ymax, xmax) whose _point2center is the centre form to the last bit: halves of small integers
+        k = rng.integers(0, 64, (n, r, 4)).astype(np.float32) / 64
+        ymin, xmin = np.minimum(k[..., 0], k[..., 2]), np.minimum(k[..., 1], k[..., 3])
+        ymax, xmax = np.maximum(k[..., 0], k[..., 2]), np.maximum(k[..., 1], k[..., 3])
+        rin = np.stack([ymin, xmin, ymax, xmax], -1).astype(np.float32)
+        hh, ww = ymax - ymin, xmax - xmin
+        cen = np.stack([ymin + hh / np.float32(2), xmin + ww / np.float32(2), hh, ww], -1).astype(np.float32)
+        po, io = oracle.ps_roi_align(feat, cen, gw, gh, method)
+    d_in, d_roi = to_device(nhwc), to_device(np.ascontiguousarray(rin))
+    d_pool, d_idx = DeviceBuffer(n * r * c * 4), DeviceBuffer(n * r * c * 4)
+    check(lib().xdet_psroialign_fwd(d_in.ptr, d_roi.ptr, d_pool.ptr, d_idx.ptr, n, c, h, w, r, gw, gh,
+                                    1 if method == 'max' else 0, 1, ldc, c, corners, None))
+    p = to_host(d_pool.ptr, (n, r, gh * gw, 10), np.float32)
+    i = to_host(d_idx.ptr, (n, r, gh * gw, 10), np.int32)
+    assert np.array_equal(p, po)
+    assert np.array_equal(i, io)
+    # without the index output (as inside the net)
+    d_pool2 = DeviceBuffer(n * r * c * 4)
+    check(lib().xdet_psroialign_fwd(d_in.ptr, d_roi.ptr, d_pool2.ptr, None, n, c, h, w, r, gw, gh,
+                                    1 if method == 'max' else 0, 1, ldc, c, corners, None))
+    assert np.array_equal(to_host(d_pool2.ptr, (n, r, gh * gw, 10), np.float32), po)
+
+
 def test_empty_and_errors():
     import xdet
     feat = np.zeros((1, 8, 4, 4), np.float32)
