@@ -267,3 +267,30 @@ def test_fused_separable_block_beyond_2gib():
         assert np.array_equal(y[3 * k:3 * k + 3], y[:3]), k      # images 72..74 and 75th sit across / behind the cut
     y3 = op(DeviceTensor.from_numpy(one), relu_in=True, fused=False).numpy()
     assert np.array_equal(y[:3], y3)
+
+
+def test_specialised_conv_entry_points_reject_what_they_cannot_run():
+    """xdet_conv3x3_patch_forward / xdet_sepconv_fused_forward are shape-specialised kernels behind the C-ABI: a layer
+    outside their shape class is an InvalidArgumentError (never a silent fall-back to another kernel)."""
+    from xdet._lib import InvalidArgumentError
+    from xdet.ops import Conv2D, SeparableConvBN
+    from xdet.runtime import DeviceTensor, set_precision
+    rng = np.random.default_rng(0)
+    x32 = DeviceTensor.from_numpy(rng.standard_normal((1, 9, 9, 32)).astype(np.float32))
+    x64 = DeviceTensor.from_numpy(rng.standard_normal((1, 9, 9, 64)).astype(np.float32))
+    k = lambda *s: (rng.standard_normal(s) / 8).astype(np.float32)
+    set_precision('f16x3')
+    try:
+        same = Conv2D(k(3, 3, 32, 64), 1, 'SAME')            # padded: the staged-tile kernel is VALID only
+        wide_in = Conv2D(k(3, 3, 64, 64), 1, 'VALID')        # 64 input channels
+        wide_out = Conv2D(k(3, 3, 32, 96), 1, 'VALID')       # > 64 outputs
+        sep_wide = SeparableConvBN(k(3, 3, 64, 1), k(1, 1, 64, 384), None, None)   # 384 outputs: two-kernel form only
+    finally:
+        set_precision('f32')
+    exact = Conv2D(k(3, 3, 32, 64), 1, 'VALID')              # created in f32 mode: no split-precision weights
+    for op, x in [(same, x32), (wide_in, x64), (wide_out, x32), (exact, x32)]:
+        with pytest.raises(InvalidArgumentError):
+            op(x, planes=True, staged_tile=True)
+    with pytest.raises(InvalidArgumentError):
+        sep_wide(x64, fused=True)
+    assert sep_wide(x64, fused=False).numpy().shape == (1, 9, 9, 384)
