@@ -76,6 +76,8 @@ def parse():
                          'large-separable convs): per-kernel rocprofv3 durations without cross-stream sharing')
     ap.add_argument('--conv3x3', default='patch', choices=['patch', 'gemm'],
                     help='block1_conv2: LDS-staged input tile (default) or the implicit-GEMM kernel (A/B measurements)')
+    ap.add_argument('--pool', default='split', choices=['split', 'whole', 'split_all'],
+                    help='entry-flow pools: horizontal half in the producing block (default, 237x237 block) or one kernel')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=200, help='images of the bounded CPU-baseline sample (~10-20 s)')
     ap.add_argument('--cpu-batch', type=int, default=8, help='images per call of the C++ CPU baseline')
@@ -263,7 +265,8 @@ def main():
             raise SystemExit('--batch must be a multiple of --ways')
         sb = B // ways                               # images per sub-batch / net instance
         nets = [LightHeadDetector(weights, image_size=480, max_batch=sb, rpn_post_nms_top_n=args.proposals,
-                                  rpn_stream='main' if args.serial_rpn else 'side', conv3x3=args.conv3x3)
+                                  rpn_stream='main' if args.serial_rpn else 'side', conv3x3=args.conv3x3,
+                                  pool=args.pool)
                 for _ in range(ways)]
         net = nets[0]
         kind = 0

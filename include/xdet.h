@@ -130,6 +130,16 @@ int xdet_sepconv_fused_forward(void* dw_layer, void* pw_layer, const float* in, 
  * option "conv3x3" = "patch" (default) | "gemm". */
 int xdet_conv3x3_patch_forward(void* layer, const uint16_t* in_hi, const uint16_t* in_lo, int N, int H, int W, float* out,
                                int ld_out, void* stream);
+/* The entry-flow tail "separable block -> max_pooling2d(3, 2, 'same') -> tf.add(residual)" (net/xception_body.py:268-286)
+ * with the pool split between the two kernels: xdet_sepconv_fused_hpool_forward is xdet_sepconv_fused_forward whose
+ * epilogue writes the 3-column / stride-2 maximum of every output row (out_hpooled: NHWC f32 [N][H][(W+1)/2][ld_out]),
+ * xdet_maxpool_v3s2_add the 3-row / stride-2 maximum of that (+ residual) -> [N][(H+1)/2][(W+1)/2][ld].  Together
+ * bit-identical to xdet_sepconv_fused_forward -> xdet_maxpool3x3s2_add; the full-resolution tensor crosses HBM at half
+ * size.  Inside a net: option "pool" = "split" (default: the 237 x 237 block) | "whole" | "split_all". */
+int xdet_sepconv_fused_hpool_forward(void* dw_layer, void* pw_layer, const float* in, int N, int H, int W, int ld_in,
+                                     float* out_hpooled, int ld_out, int relu_in, void* stream);
+int xdet_maxpool_v3s2_add(const float* in_hpooled, const float* residual, float* out, int N, int H, int Wo, int C, int ld,
+                          void* stream);
 /* tf.layers.max_pooling2d(3,2,'same') + tf.add(residual) (net/xception_body.py:281-286) */
 int xdet_maxpool3x3s2_add(const float* in, const float* residual, float* out, int N, int H, int W, int C, int ld,
                           void* stream);

@@ -197,6 +197,41 @@ def test_conv3x3_staged_tile(N, H, W, prec, cout, oracle):
         close(y_tile, np.maximum(oracle.conv2d(x, k, 1, 'VALID') * scale + shift, 0), 3e-5)
 
 
+@pytest.mark.parametrize('case', [(2, 237, 237, 128, 128, True), (1, 119, 119, 256, 256, True), (3, 60, 60, 64, 128, False),
+                                  (2, 29, 57, 96, 128, True), (1, 4, 3, 32, 128, True), (2, 56, 28, 64, 256, False),
+                                  (1, 9, 61, 160, 128, True)])
+@pytest.mark.parametrize('prec', ['f16x3', 'f16'])
+def test_separable_block_with_split_pool(case, prec, oracle):
+    """block -> max_pooling2d(3, 2, 'same') -> + residual with the horizontal half of the pool in the block's epilogue
+    (tiles 28 columns apart, windows from the accumulators by v_permlane32_swap) and a vertical pass: bit for bit the
+    one-kernel block followed by the whole pool, odd and even sizes (pad 1/1 and 0/1), ragged last tiles."""
+    from xdet.ops import SeparableConvBN, max_pool_3x3_s2_same_add, separable_block_then_pool_add
+    from xdet.runtime import DeviceTensor, set_precision
+    N, H, W, cin, cout, relu_in = case
+    rng = np.random.default_rng(H * 13 + W + cin)
+    x = rng.standard_normal((N, H, W, cin)).astype(np.float32)
+    dk = rng.standard_normal((3, 3, cin, 1)).astype(np.float32) / 3
+    pk = (rng.standard_normal((1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((N, -(-H // 2), -(-W // 2), cout)).astype(np.float32)
+    set_precision(prec)
+    try:
+        op = SeparableConvBN(dk, pk, scale, shift, relu=False)
+    finally:
+        set_precision('f32')
+    xd, rd = DeviceTensor.from_numpy(x), DeviceTensor.from_numpy(res)
+    whole = max_pool_3x3_s2_same_add(op(xd, relu_in=relu_in, fused=True), rd).numpy()
+    split = separable_block_then_pool_add(op, xd, rd, relu_in=relu_in).numpy()
+    assert split.shape == whole.shape == res.shape
+    assert np.array_equal(split, whole)
+    no_res = separable_block_then_pool_add(op, xd, None, relu_in=relu_in).numpy()
+    assert np.array_equal(no_res, max_pool_3x3_s2_same_add(op(xd, relu_in=relu_in, fused=True)).numpy())
+    if prec == 'f16x3':
+        y = oracle.separable_conv2d(np.maximum(x, 0) if relu_in else x, dk, pk) * scale + shift
+        close(split, oracle.max_pool_3x3_s2_same(y) + res, 3e-5)
+
+
 @pytest.mark.parametrize('H,W', [(237, 237), (119, 119), (60, 60), (7, 10)])
 def test_maxpool_same_padding_asymmetry(H, W, oracle):
     """TF SAME puts the odd padding pixel at the bottom/right: 60->30 pads 0/1, 237->119 pads 1/1."""

@@ -103,6 +103,9 @@ int launch_depthwise3x3(const float* in, const float* w9c, float* out, int N, in
                         int dil, int relu_in, hipStream_t s);
 int launch_maxpool3x3s2_add(const float* in, const float* res, float* out, int N, int H, int W, int C, int ld,
                             int Ho, int Wo, int pad_t, int pad_l, hipStream_t s);
+// vertical half only, over rows the producer already pooled horizontally (sepconv_fused.hip HPOOL)
+int launch_maxpool_v3s2_add(const float* in_hpooled, const float* res, float* out, int N, int H, int Wo, int C, int ld,
+                            int Ho, int pad_t, hipStream_t s);
 int launch_relu_copy(const float* in, float* out, int64_t n, hipStream_t s);
 int launch_stem_conv3x3s2(const float* in_nchw, const float* w27x32, const float* scale, const float* shift,
                           unsigned short* hi, unsigned short* lo, int N, int S, hipStream_t s);
@@ -127,7 +130,8 @@ int launch_dft_inv(const float* Y, int F, int ldn, int C_ld, int N, int m_pad, c
 bool sepconv_fused_supported(int cin_ld, int cout_pad, int dil);
 int launch_sepconv_fused(const float* in, const float* w9c, const unsigned short* wt_hi_blocked,
                          const unsigned short* wt_lo_blocked, const float* scale, const float* shift, float* out, int N,
-                         int H, int W, int ld, int ldo, int cout_pad, int relu_in, int relu_out, hipStream_t s);
+                         int H, int W, int ld, int ldo, int cout_pad, int relu_in, int relu_out, hipStream_t s,
+                         int pool_pad_l = -1);
 
 // ---- 3x3 / stride 1 / VALID conv over 32 channels with the input tile staged once in LDS (conv3x3_patch.hip) ----
 bool conv3x3_patch_supported(int kh, int kw, int cin, int cout_pad, int stride, int dil, int pad_mode);

@@ -521,6 +521,53 @@ int launch_maxpool3x3s2_add(const float* in, const float* res, float* out, int N
   return XDET_OK;
 }
 
+// The vertical half of max_pooling2d(3, 2, 'same') (+ residual) over a tensor whose rows were already pooled
+// horizontally by the producing kernel (sepconv_fused.hip, HPOOL): in [N][H][Wo][ld] -> out [N][Ho][Wo][ld].
+// Same walk as maxpool3x3s2_add_kernel: one thread = 4 channels of a column, the shared row carried in a register.
+__global__ __launch_bounds__(256) void maxpool_v3s2_add_kernel(const float* __restrict__ in, const float* __restrict__ res,
+                                                               float* __restrict__ out, int H, int Wo, int ld, int Ho,
+                                                               int pad_t, int nbands, int bands_per_image) {
+  const int c4n = ld >> 2;
+  const int item = blockIdx.y * 256 + threadIdx.x;
+  if (item >= Wo * c4n) return;
+  const int per_xcd = gridDim.x >> 3;
+  const int band = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (band >= nbands) return;
+  const int n = band / bands_per_image;
+  const int oy0 = (band - n * bands_per_image) * MP_ROWS;
+  const float* base = in + (size_t)n * H * Wo * ld + (size_t)item * 4;      // item = ox * c4n + c4
+  const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  auto rowv = [&](int iy) {
+    return (unsigned)iy < (unsigned)H ? *reinterpret_cast<const float4*>(base + (size_t)iy * Wo * ld) : ninf;
+  };
+  float4 carry = rowv(oy0 * 2 - pad_t);
+  const int oy1 = min(Ho, oy0 + MP_ROWS);
+  for (int oy = oy0; oy < oy1; ++oy) {
+    const int iy = oy * 2 - pad_t;
+    const float4 a = rowv(iy + 1), b = rowv(iy + 2);
+    float4 m = mp_max4(mp_max4(carry, a), b);
+    carry = b;
+    const size_t o = ((size_t)n * Ho + oy) * Wo * ld + (size_t)item * 4;
+    if (res) {
+      const float4 r = *reinterpret_cast<const float4*>(res + o);
+      m.x += r.x; m.y += r.y; m.z += r.z; m.w += r.w;
+    }
+    *reinterpret_cast<float4*>(out + o) = m;
+  }
+}
+
+int launch_maxpool_v3s2_add(const float* in_hpooled, const float* res, float* out, int N, int H, int Wo, int C, int ld,
+                            int Ho, int pad_t, hipStream_t s) {
+  XDET_REQUIRE(ld % 4 == 0 && ld >= C, "maxpool: channel stride must be a multiple of 4");
+  if ((int64_t)N * Ho == 0) return XDET_OK;
+  const int bpi = (int)cdiv(Ho, MP_ROWS), nbands = N * bpi;
+  const dim3 grid((unsigned)(cdiv(nbands, 8) * 8), (unsigned)cdiv((int64_t)Wo * (ld / 4), 256));
+  hipLaunchKernelGGL(maxpool_v3s2_add_kernel, grid, dim3(256), 0, s, in_hpooled, res, out, H, Wo, ld, Ho, pad_t, nbands,
+                     bpi);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
 __global__ void relu_copy_kernel(const float4* __restrict__ in, float4* __restrict__ out, int64_t n4) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 v = in[i];

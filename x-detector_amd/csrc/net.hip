@@ -419,6 +419,8 @@ struct Plan {
   bool fuse_sepconv = true;      // option "sepconv" = "fused" | "split"
   bool subsample_projections = true;
   bool patch_conv3x3 = true;     // option "conv3x3" = "patch" | "gemm"
+  bool fuse_hpool = true;        // option "pool" = "split" | "whole": horizontal half of an entry-flow pool in the producer
+  int pool_fuse_min_pixels = 150 * 150;   // ... where the block is HBM-bound (237 x 237; the 119 x 119 one is not)
   int add_conv(const std::string& name, int stage, const Buf& in_, ConvLayer* L, const Buf* res, int relu_in, Buf* out) {
     Buf in = in_;
     const int emit = L->precision == PREC_F32 ? 0 : emit_planes_next;
@@ -552,8 +554,12 @@ struct Plan {
     return add_conv(name, stage, in, L, res, relu_in, out);
   }
   // (ReLU ->) separable_conv2d -> BN (-> +residual) (-> ReLU)   net/xception_body.py:220-234
+  // pool_res != NULL: the block is followed by max_pooling2d(3, 2, 'same') + tf.add(pool_res) (entry flow,
+  // net/xception_body.py:281-286); *out is then the pooled sum.  Where the fused kernel runs and the map is large enough
+  // to be HBM-bound (pool_fuse_min_hw), its epilogue does the horizontal half of the pool and a light pass the vertical
+  // half + the add: the full-resolution block output is written and read at half size.
   int sep_bn(const std::string& name, float eps, int stage, const Buf& in, int cout, int pre_relu, int dilation,
-             int relu_out, const Buf* res, Buf* out) {
+             int relu_out, const Buf* res, Buf* out, const Buf* pool_res = nullptr) {
     const HostTensor *dk, *pk;
     XDET_TRY(need(name + "/depthwise_kernel", &dk, {3, 3, in.C, 1}));
     XDET_TRY(need(name + "/pointwise_kernel", &pk, {1, 1, in.C, cout}));
@@ -568,17 +574,42 @@ struct Plan {
     // two-kernel form below, which the wide 30x30 layers keep (their GEMM needs the big MFMA tiles).
     if (fuse_sepconv && L->dma_capable() && !res && emit_planes_next == 0 && !in.no_f32 &&
         sepconv_fused_supported(in.ld, L->cout_pad, dilation) && L->cout_pad == L->ld_out()) {
-      XDET_TRY(new_buf(in.H, in.W, cout, out));
-      const Buf i = in, o = *out;
+      if (pool_res && fuse_hpool && in.H * in.W >= pool_fuse_min_pixels) {
+        int Ho, Wo, pt, pl;
+        same_pad(in.H, 3, 2, 1, &pt, &Ho);
+        same_pad(in.W, 3, 2, 1, &pl, &Wo);
+        Buf hp;
+        XDET_TRY(new_buf(in.H, Wo, cout, &hp));
+        XDET_TRY(new_buf(Ho, Wo, cout, out));
+        XDET_REQUIRE(pool_res->H == Ho && pool_res->W == Wo && pool_res->ld == out->ld && !pool_res->no_f32,
+                     "plan: pool residual shape mismatch");
+        const Buf i = in, h = hp, o = *out;
+        const float* rp = pool_res->p;
+        ops.push_back({name + "/fused_dw+pw+hpool", stage, L->flops(in.H, in.W), [=](int N, hipStream_t s) {
+                         return launch_sepconv_fused(i.p, D->d_w, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale, L->d_shift, h.p, N,
+                                                     i.H, i.W, i.ld, h.ld, L->cout_pad, pre_relu, L->relu_out, s, pl);
+                       }});
+        ops.push_back({name + "/vpool_add", stage, 0.0, [=](int N, hipStream_t s) {
+                         return launch_maxpool_v3s2_add(h.p, rp, o.p, N, h.H, h.W, h.C, h.ld, Ho, pt, s);
+                       }});
+        return XDET_OK;
+      }
+      Buf full;
+      Buf* dst = pool_res ? &full : out;
+      XDET_TRY(new_buf(in.H, in.W, cout, dst));
+      const Buf i = in, o = *dst;
       ops.push_back({name + "/fused_dw+pw", stage, L->flops(in.H, in.W), [=](int N, hipStream_t s) {
                        return launch_sepconv_fused(i.p, D->d_w, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale, L->d_shift, o.p, N,
                                                    i.H, i.W, i.ld, o.ld, L->cout_pad, pre_relu, L->relu_out, s);
                      }});
-      return XDET_OK;
+      return pool_res ? add_pool(name + "/pool_add", stage, full, pool_res, out) : XDET_OK;
     }
     Buf t;
     XDET_TRY(add_dw(name + "/depthwise", stage, in, D, pre_relu, &t, /*planes_only=*/L->dma_capable()));
-    return add_conv(name + "/pointwise", stage, t, L, res, 0, out);
+    if (!pool_res) return add_conv(name + "/pointwise", stage, t, L, res, 0, out);
+    Buf full;
+    XDET_TRY(add_conv(name + "/pointwise", stage, t, L, res, 0, &full));
+    return add_pool(name + "/pool_add", stage, full, pool_res, out);
   }
   int run_stage(int stage, int N, hipStream_t s) {
     for (size_t i = 0; i < ops.size(); ++i) {
@@ -690,10 +721,9 @@ struct LightHeadNet : Plan {
                          {"conv2d_3", "batch_normalization_3", "block4_sepconv1", "block4_sepconv2", 728, 1}};
     for (const Blk& b : blks) {
       XDET_TRY(conv_bn(b.res, b.bn, eps, ST_BODY, x, 1, b.c, 2, 1, 0, nullptr, 0, &r));
-      Buf a, c2, p;
+      Buf a, p;
       XDET_TRY(sep_bn(b.s1, eps, ST_BODY, x, b.c, b.first_relu, 1, 0, nullptr, &a));
-      XDET_TRY(sep_bn(b.s2, eps, ST_BODY, a, b.c, 1, 1, 0, nullptr, &c2));
-      XDET_TRY(add_pool(std::string(b.s2) + "/pool_add", ST_BODY, c2, &r, &p));
+      XDET_TRY(sep_bn(b.s2, eps, ST_BODY, a, b.c, 1, 1, 0, nullptr, &p, &r));
       x = p;
     }
     for (int blk = 5; blk <= 12; ++blk) {
@@ -1342,6 +1372,30 @@ int xdet_conv3x3_patch_forward(void* layer, const uint16_t* in_hi, const uint16_
   return launch_conv3x3_patch(in_hi, L->precision == PREC_F16 ? nullptr : in_lo, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale,
                               L->d_shift, out, N, H, W, ld_out, L->relu_out, S(stream));
 }
+int xdet_sepconv_fused_hpool_forward(void* dw_layer, void* pw_layer, const float* in, int N, int H, int W, int ld_in,
+                                     float* out_hpooled, int ld_out, int relu_in, void* stream) {
+  LayerBase* a = static_cast<LayerBase*>(dw_layer);
+  LayerBase* b = static_cast<LayerBase*>(pw_layer);
+  XDET_REQUIRE(a && a->kind == 2 && b && b->kind == 1, "sepconv_fused: need a depthwise and a conv layer");
+  DepthwiseLayer* D = static_cast<DepthwiseLayer*>(a);
+  ConvLayer* L = static_cast<ConvLayer*>(b);
+  XDET_REQUIRE(L->dma_capable() && L->kh == 1 && L->kw == 1 && L->stride == 1 && L->groups == 1,
+               "sepconv_fused: the pointwise layer must be a 1x1 stride-1 conv created in a split-precision mode");
+  XDET_REQUIRE(D->ld == ld_in && L->ld_in() == ld_in && L->ld_out() == ld_out && L->cout_pad == ld_out &&
+                   sepconv_fused_supported(ld_in, L->cout_pad, D->dil),
+               "sepconv_fused: needs <= 256 input channels (multiple of 32), 128 or 256 outputs, dilation 1");
+  int Wo, pl;
+  same_pad(W, 3, 2, 1, &pl, &Wo);
+  DeviceGuard guard(L->device);
+  return launch_sepconv_fused(in, D->d_w, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale, L->d_shift, out_hpooled, N, H, W, ld_in,
+                              ld_out, L->cout_pad, relu_in, L->relu_out, S(stream), pl);
+}
+int xdet_maxpool_v3s2_add(const float* in_hpooled, const float* residual, float* out, int N, int H, int Wo, int C, int ld,
+                          void* stream) {
+  int Ho, pt;
+  same_pad(H, 3, 2, 1, &pt, &Ho);
+  return launch_maxpool_v3s2_add(in_hpooled, residual, out, N, H, Wo, C, ld, Ho, pt, S(stream));
+}
 int xdet_maxpool3x3s2_add(const float* in, const float* residual, float* out, int N, int H, int W, int C, int ld,
                           void* stream) {
   int Ho, Wo, pt, pl;
@@ -1424,6 +1478,12 @@ int xdet_net_set_option(void* net, const char* key, const char* value) {
   if (k == "sepconv") {
     XDET_REQUIRE(v == "fused" || v == "split", "sepconv must be fused | split");
     n->fuse_sepconv = v == "fused";
+    return XDET_OK;
+  }
+  if (k == "pool") {
+    XDET_REQUIRE(v == "split" || v == "whole" || v == "split_all", "pool must be split | whole | split_all");
+    n->fuse_hpool = v != "whole";
+    if (v == "split_all") n->pool_fuse_min_pixels = 0;
     return XDET_OK;
   }
   if (k == "conv3x3") {

@@ -25,6 +25,7 @@ typedef float sf_f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 sf_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 sf_f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
+typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
 
 constexpr int SF_R = 4, SF_X = 30, SF_P = 32;       // tile rows, tile width, patch pitch (pixels)
 constexpr int SF_ROWS = SF_R + 2;                   // patch rows
@@ -49,6 +50,9 @@ struct SepFusedParams {
   float* out;            // NHWC f32, channel stride ldo
   int N, H, W, ld, ldo, Cout_pad, relu_in, relu_out;
   int TY, TX, NT, ntiles, tiles_per_block;
+  // HPOOL: the epilogue writes the 3-column / stride-2 maximum of each output row (the horizontal half of the
+  // max_pooling2d(3, 2, 'same') that follows the block, net/xception_body.py:281-286): out is [N][H][Wo][ldo]
+  int Wo, pool_pad_l;
 };
 
 // LDS accesses issued while the patch prefetch (an LDS-writing DMA) is in flight.  The compiler cannot tell
@@ -83,7 +87,18 @@ __device__ __forceinline__ float sf_relu(float x) {
   return r;
 }
 
-template <bool SPLIT3, bool RELU_IN>
+// HPOOL tiles are 28 output columns apart and start pool_pad_l columns left of a multiple of 28: the 30 columns a tile
+// computes then hold every window of its 14 pooled columns (window k = local columns 2k .. 2k+2).
+constexpr int SF_XP = 28;
+
+// v_permlane32_swap_b32 a, b: the upper 32 lanes of a and the lower 32 lanes of b change places, i.e. afterwards
+// a = {a.lower, b.lower} and b = {a.upper, b.upper}.  (Inline asm: with the clang builtin, hipcc 7.2 dropped the second
+// result of all but the first swap of an unrolled sequence and used the first result in its place.)
+__device__ __forceinline__ void sf_permlane32_swap(float& a, float& b) {
+  asm("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+template <bool SPLIT3, bool RELU_IN, bool HPOOL>
 __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p) {
   __shared__ __attribute__((aligned(16))) float s_patch[2][SF_PATCH_F];
   __shared__ __attribute__((aligned(16))) u16 s_a[2 * 128 * 32];        // A tile: hi rows, then lo rows (16 KB)
@@ -124,7 +139,8 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.ld * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-      p.out, 0, (int)(unsigned)std::min<size_t>((size_t)p.N * p.H * p.W * p.ldo * 4, 0xffffffffull), 0x00020000);
+      p.out, 0, (int)(unsigned)std::min<size_t>((size_t)p.N * p.H * (HPOOL ? p.Wo : p.W) * p.ldo * 4, 0xffffffffull),
+      0x00020000);
   // Offsets are rebuilt from wave-uniform (scalar) parts + one per-lane register each time: keeping six per-lane
   // descriptors resident cost 12 VGPRs the stencil needs.  `live == false` issues the same six instructions
   // with every lane out of bounds (zero fill): an unconditional instruction count keeps the compiler's vmcnt
@@ -132,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
   const int px8 = lane >> 3;
   const int lane_off = (px8 * p.ld + (lane & 7) * 4) * 4;                            // bytes
   auto issue = [&](const Coord& c, int chunk, int buf, bool live) {
-    const int y0 = c.ty * SF_R, x0 = c.tx * SF_X;
+    const int y0 = c.ty * SF_R, x0 = HPOOL ? c.tx * SF_XP - p.pool_pad_l : c.tx * SF_X;
     const int tile_base = ((((c.n * p.H + y0) * p.W + x0) * p.ld) + chunk * 32) * 4;   // bytes, < 2^31 (host check)
 #pragma unroll
     for (int jj = 0; jj < SF_NJ; ++jj) {
@@ -170,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
   issue(cur, 0, 0, true);
   for (int t = t_begin; t < t_end; t += G) {
     const Coord nxt = decode(min(t + G, p.ntiles - 1));
-    const int y0 = cur.ty * SF_R, x0 = cur.tx * SF_X, n0 = cur.nt * SF_BN;
+    const int y0 = cur.ty * SF_R, x0 = HPOOL ? cur.tx * SF_XP - p.pool_pad_l : cur.tx * SF_X, n0 = cur.nt * SF_BN;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -302,6 +318,59 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
     // holds one output channel (column frow) of 16 pixels of one tile row; lanes 0..31 of a store cover 128
     // contiguous bytes.  Raw buffer stores: the row offset rides in the scalar offset, pixels outside the tile /
     // image get an out-of-range lane offset (dropped by the bounds check) -- no branches, no 64-bit pointers. ----
+    if (HPOOL) {
+      // Horizontal half of the pool, from the accumulators.  A lane holds columns c + 4 fh (c = 0..3, 8..11 in registers
+      // 0..7, 16..19, 24..27 in 8..15) of one channel; v_permlane32_swap of register r with r + 8 leaves lanes 0..31
+      // with columns 0..15 and lanes 32..63 with 16..31, window k = columns 2k..2k+2: the lower half takes k = 0..7
+      // (its last window borrows column 16), the upper half k = 8..13.  Columns outside the image are -inf (SAME
+      // padding never wins a maximum); max is exact, so the order of the nine comparisons does not matter.
+      const int klim = min(SF_XP / 2, p.Wo - cur.tx * (SF_XP / 2)) - 8 * fh;   // this lane's windows are 8 fh + kk
+      const bool edge = x0 < 0 || x0 + 32 > p.W;                               // wave-uniform
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int y = y0 + wm * 2 + i;
+        if (y >= p.H) continue;                                                // wave-uniform
+        const unsigned row_off = (unsigned)((((size_t)cur.n * p.H + y) * p.Wo + cur.tx * (SF_XP / 2)) * p.ldo * 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int co = n0 + wn * 64 + j * 32 + frow;
+          const unsigned lane_off = co < p.ldo ? (unsigned)((8 * fh * p.ldo + co) * 4) : 0xffffffffu;
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            v[r] = fmaf(acc[i][j][r], esc[j], esh[j]);
+            if (p.relu_out) v[r] = fmaxf(v[r], 0.f);
+          }
+          if (edge) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int col = x0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+              if ((unsigned)col >= (unsigned)p.W) v[r] = -INFINITY;
+            }
+          }
+          float X[8], Y[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            X[r] = v[r];
+            Y[r] = v[r + 8];
+            sf_permlane32_swap(X[r], Y[r]);
+          }
+          // column q of this half (q = 0..15): X or Y [(q & 3) + 4 (q >> 3)] by (q & 4)
+          auto colv = [&](int q) { return (q & 4) ? Y[(q & 3) + 4 * (q >> 3)] : X[(q & 3) + 4 * (q >> 3)]; };
+          float c16a = X[0], col16 = X[0];
+          sf_permlane32_swap(c16a, col16);                                    // lower half: the upper half's column 16
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            const float c2 = kk < 7 ? colv(2 * kk + 2) : col16;
+            const float m = fmaxf(fmaxf(colv(2 * kk), colv(2 * kk + 1)), c2);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), orsrc, kk < klim ? lane_off : 0xffffffffu,
+                                                  row_off + kk * p.ldo * 4, 0);
+          }
+        }
+      }
+      cur = nxt;
+      continue;
+    }
     const int lim = min(SF_X, p.W - x0) - 4 * fh;            // this lane's pixels are c + 4*fh, c = 0..3, 8..11, 16.., 24..
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -330,9 +399,11 @@ bool sepconv_fused_supported(int cin_ld, int cout_pad, int dil) {
 }
 
 // One launch per image range whose input stays below 2 GiB (32-bit buffer offsets of the LDS DMA).
+// pool_pad_l >= 0: the horizontally pooled form (out = [N][H][(W+1)/2][ldo], see SepFusedParams)
 int launch_sepconv_fused(const float* in, const float* w9c, const unsigned short* wt_hi_blocked,
                          const unsigned short* wt_lo_blocked, const float* scale, const float* shift, float* out, int N,
-                         int H, int W, int ld, int ldo, int cout_pad, int relu_in, int relu_out, hipStream_t s) {
+                         int H, int W, int ld, int ldo, int cout_pad, int relu_in, int relu_out, hipStream_t s,
+                         int pool_pad_l) {
   XDET_REQUIRE(sepconv_fused_supported(ld, cout_pad, 1), "sepconv_fused: unsupported channel counts");
   XDET_REQUIRE(in && w9c && wt_hi_blocked && scale && shift && out, "sepconv_fused: NULL argument");
   const size_t per_image = (size_t)H * W * std::max(ld, ldo) * 4;   // input offsets are signed 32-bit, output unsigned
@@ -343,20 +414,23 @@ int launch_sepconv_fused(const float* in, const float* w9c, const unsigned short
     SepFusedParams p;
     p.in = in + (size_t)nb * H * W * ld;
     p.w9c = w9c; p.wt_hi = wt_hi_blocked; p.wt_lo = wt_lo_blocked; p.scale = scale; p.shift = shift;
-    p.out = out + (size_t)nb * H * W * ldo;
+    p.out = out + (size_t)nb * H * (pool_pad_l >= 0 ? (W + 1) / 2 : W) * ldo;
     p.N = n; p.H = H; p.W = W; p.ld = ld; p.ldo = ldo; p.Cout_pad = cout_pad; p.relu_in = relu_in; p.relu_out = relu_out;
-    p.TY = (int)cdiv(H, SF_R); p.TX = (int)cdiv(W, SF_X); p.NT = cout_pad / SF_BN;
+    const bool hpool = pool_pad_l >= 0;
+    p.Wo = (W + 1) / 2; p.pool_pad_l = hpool ? pool_pad_l : 0;
+    p.TY = (int)cdiv(H, SF_R); p.TX = hpool ? (int)cdiv(p.Wo, SF_XP / 2) : (int)cdiv(W, SF_X); p.NT = cout_pad / SF_BN;
     const int64_t nt = (int64_t)n * p.TY * p.TX * p.NT;
     p.ntiles = (int)nt;
     p.tiles_per_block = 0;
     // two workgroups per CU (LDS); a multiple of 8 so that every XCD gets the same number
     const dim3 g((unsigned)std::min<int64_t>(512, cdiv(nt, 8) * 8));
-    if (wt_lo_blocked) {
-      if (relu_in) hipLaunchKernelGGL((sepconv_fused_kernel<true, true>), g, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((sepconv_fused_kernel<true, false>), g, dim3(256), 0, s, p);
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, g, dim3(256), 0, s, p); };
+    if (hpool) {
+      if (wt_lo_blocked) { if (relu_in) go(sepconv_fused_kernel<true, true, true>); else go(sepconv_fused_kernel<true, false, true>); }
+      else { if (relu_in) go(sepconv_fused_kernel<false, true, true>); else go(sepconv_fused_kernel<false, false, true>); }
     } else {
-      if (relu_in) hipLaunchKernelGGL((sepconv_fused_kernel<false, true>), g, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((sepconv_fused_kernel<false, false>), g, dim3(256), 0, s, p);
+      if (wt_lo_blocked) { if (relu_in) go(sepconv_fused_kernel<true, true, false>); else go(sepconv_fused_kernel<true, false, false>); }
+      else { if (relu_in) go(sepconv_fused_kernel<false, true, false>); else go(sepconv_fused_kernel<false, false, false>); }
     }
     XDET_LAUNCH_CHECK();
   }

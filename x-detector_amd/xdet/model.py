@@ -21,7 +21,7 @@ class LightHeadDetector(object):
     def __init__(self, weights, image_size=480, max_batch=1, num_classes=21, rpn_pre_nms_top_n=5000,
                  rpn_post_nms_top_n=1000, rpn_nms_thres=0.7, rpn_min_size=None, select_threshold=0.01,
                  nms_threshold=0.3, nms_topk=200, device=None, large_sep='auto', sepconv='fused', rpn_stream='side',
-                 conv3x3='patch'):
+                 conv3x3='patch', pool='split'):
         if device is not None:
             check(lib().xdet_set_device(int(device)))
         self.cfg = LightHeadConfig(image_size=image_size, max_batch=max_batch, num_classes=num_classes,
@@ -40,6 +40,7 @@ class LightHeadDetector(object):
         check(lib().xdet_net_set_option(self.handle, b'sepconv', sepconv.encode()))
         check(lib().xdet_net_set_option(self.handle, b'rpn_stream', rpn_stream.encode()))
         check(lib().xdet_net_set_option(self.handle, b'conv3x3', conv3x3.encode()))
+        check(lib().xdet_net_set_option(self.handle, b'pool', pool.encode()))
         check(lib().xdet_net_build(self.handle))
         self.max_batch = max_batch
         self.image_size = image_size

@@ -179,6 +179,22 @@ class SeparableConvBN(object):
         return out
 
 
+def separable_block_then_pool_add(op, x, residual, relu_in=False, stream=None):
+    """SeparableConvBN `op` -> max_pooling2d(3, 2, 'same') -> + residual with the pool split between the block's epilogue
+    (horizontal half) and a light vertical pass (xdet_sepconv_fused_hpool_forward + xdet_maxpool_v3s2_add)."""
+    N, H, W, C = x.shape
+    Ho, Wo = -(-H // 2), -(-W // 2)
+    hp = DeviceTensor.empty((N, H, Wo, op.pw.cout))
+    out = DeviceTensor.empty((N, Ho, Wo, op.pw.cout))
+    st = stream.handle if stream else None
+    check(lib().xdet_sepconv_fused_hpool_forward(op.dw.handle, op.pw.handle, x.ptr, N, H, W, x.ld, hp.ptr, hp.ld,
+                                                 1 if relu_in else 0, st))
+    check(lib().xdet_maxpool_v3s2_add(hp.ptr, residual.ptr if residual is not None else None, out.ptr, N, H, Wo,
+                                      op.pw.cout, hp.ld, st))
+    synchronize(stream)
+    return out
+
+
 def max_pool_3x3_s2_same_add(x, residual=None, stream=None):
     N, H, W, C = x.shape
     out = DeviceTensor.empty((N, -(-H // 2), -(-W // 2), C))
