@@ -18,6 +18,8 @@
 // form (tests/test_gpu_layers.py).  Cout = 256 runs as two 128-wide passes over the same patch (second pass
 // from L2); wider layers (728) stay on the two-kernel path.
 #include "common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace xdet {
 
@@ -37,7 +39,6 @@ constexpr int SF_PIECE_F = 8 * 32 + 32;             // floats per piece incl. pa
 constexpr int SF_ROW_F = (SF_P / 8) * SF_PIECE_F;   // floats per patch row (4608 B)
 constexpr int SF_PATCH_F = SF_ROWS * SF_ROW_F;      // floats per patch buffer (27 KB)
 constexpr int SF_KMAX = 256;                        // input channels (dw taps live in LDS)
-constexpr int SF_BN = 128;                          // output channels per pass
 constexpr int SF_NJ = SF_ROWS * (SF_P / 8) / 4;     // DMA pieces per wave per chunk (6)
 
 struct SepFusedParams {
@@ -62,8 +63,9 @@ typedef __attribute__((address_space(3))) void* sf_lds_ptr;
 __device__ __forceinline__ unsigned sf_lds_addr(const void* p) {
   return (unsigned)(size_t)(sf_lds_ptr)(p);
 }
+template <int OFF>
 __device__ __forceinline__ void sf_ds_write_b64(unsigned addr, uint2 v) {
-  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+  asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
 typedef float sf_f32x4 __attribute__((ext_vector_type(4)));
 template <int OFF>
@@ -91,6 +93,20 @@ __device__ __forceinline__ float sf_relu(float x) {
 // computes then hold every window of its 14 pooled columns (window k = local columns 2k .. 2k+2).
 constexpr int SF_XP = 28;
 
+// hi (and lo) halves of four channels of A-tile row `r` of a strip (r = 0..3: 64 B apart; lo plane 8 KB behind hi)
+template <bool SPLIT3>
+__device__ __forceinline__ void sf_write_row(unsigned wa0, int r, sf_f16x4 hv, sf_f32x4 a) {
+  sf_f16x4 lv = {(_Float16)(a.x - (float)hv[0]), (_Float16)(a.y - (float)hv[1]), (_Float16)(a.z - (float)hv[2]),
+                 (_Float16)(a.w - (float)hv[3])};
+  const uint2 h = *reinterpret_cast<uint2*>(&hv), l = *reinterpret_cast<uint2*>(&lv);
+  switch (r) {   // r is a compile-time constant after unrolling: one case survives
+    case 0: sf_ds_write_b64<0>(wa0, h); if (SPLIT3) sf_ds_write_b64<8192>(wa0, l); break;
+    case 1: sf_ds_write_b64<64>(wa0, h); if (SPLIT3) sf_ds_write_b64<8192 + 64>(wa0, l); break;
+    case 2: sf_ds_write_b64<128>(wa0, h); if (SPLIT3) sf_ds_write_b64<8192 + 128>(wa0, l); break;
+    default: sf_ds_write_b64<192>(wa0, h); if (SPLIT3) sf_ds_write_b64<8192 + 192>(wa0, l); break;
+  }
+}
+
 // v_permlane32_swap_b32 a, b: the upper 32 lanes of a and the lower 32 lanes of b change places, i.e. afterwards
 // a = {a.lower, b.lower} and b = {a.upper, b.upper}.  (Inline asm: with the clang builtin, hipcc 7.2 dropped the second
 // result of all but the first swap of an unrolled sequence and used the first result in its place.)
@@ -98,8 +114,16 @@ __device__ __forceinline__ void sf_permlane32_swap(float& a, float& b) {
   asm("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
-template <bool SPLIT3, bool RELU_IN, bool HPOOL>
+// WAVES_N = 2: the four waves as 2 x 2 over a 128 x 128 tile (64 x 64 each), a 256-channel layer as two passes.
+// WAVES_N = 4: 1 x 4 over a 128 x 256 tile (a wave: all four tile rows x 64 channels) -- ONE pass: the patch DMA, the
+// stencil and the A-tile round trip of a chunk are paid once for all 256 output channels (they, not the MFMAs, are what
+// a chunk costs).  128 accumulator registers leave no room for the two-pass form's habits: the stencil runs in two
+// halves of 2 pixels (28 fewer live registers, the taps read twice), the pointwise weights are loaded AFTER it (and the
+// prefetch after them, to land under the chunk's 96 MFMAs), fragments one 16-deep half at a time.
+template <bool SPLIT3, bool RELU_IN, bool HPOOL, int WAVES_N>
 __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p) {
+  constexpr int TM = WAVES_N;                     // 32-row accumulator blocks (= tile rows) per wave
+  constexpr int BN = 64 * WAVES_N;                // output channels per pass
   __shared__ __attribute__((aligned(16))) float s_patch[2][SF_PATCH_F];
   __shared__ __attribute__((aligned(16))) u16 s_a[2 * 128 * 32];        // A tile: hi rows, then lo rows (16 KB)
   __shared__ __attribute__((aligned(16))) float s_w[9 * SF_KMAX];
@@ -166,41 +190,45 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
   // ---- roles ----
   const int c4 = lane & 7, strip = lane >> 3;     // depthwise: wave = tile row, 4 pixels x 4 channels per lane
   const int frow = lane & 31, fh = lane >> 5;     // MFMA fragments
-  const int wm = wave >> 1, wn = wave & 1;        // 2 x 2 waves over the 128 x 128 tile (64 x 64 each)
-  unsigned a_rd[2][2];                            // LDS byte address of this lane's A fragment [ks][i] (hi; lo = +8192)
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int rt = wm * 64 + i * 32 + frow;
-      a_rd[ks][i] = sf_lds_addr(s_a) + (unsigned)(rt * 32 + (((ks * 2 + fh) ^ ((rt >> 2) & 3)) << 3)) * 2u;
-    }
-  // depthwise: this lane's 4 output pixels of tile row `wave` start at pxb.  Strips 0..6 own pixels 4*strip..+3;
-  // the tile is 30 wide, so strip 7 recomputes 26..29 (26, 27 duplicate strip 6's values) instead of reaching
-  // past the patch; rows 30, 31 of the A tile are never written and feed only masked output rows.
-  const int pxb = min(strip * 4, SF_X - 4);
-  const unsigned a_base = sf_lds_addr(s_a);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  unsigned a_rd[2];                               // LDS byte address of this lane's A fragment [ks] in its first row block
+#pragma unroll                                    // (hi; lo = +8192; row block i = +2048 i, same chunk permutation)
+  for (int ks = 0; ks < 2; ++ks) {
+    const int rt = wm * TM * 32 + frow;
+    a_rd[ks] = sf_lds_addr(s_a) + (unsigned)(rt * 32 + (((ks * 2 + fh) ^ ((rt >> 2) & 3)) << 3)) * 2u;
+  }
+  // depthwise: this lane's 4 output pixels of tile row `wave` are pxb .. pxb+3.  The tile is 30 wide: the last strip's
+  // pixels 30, 31 are computed from whatever follows the patch row in LDS and land in A-tile rows that feed only masked
+  // output rows (an MFMA row depends on its own A row only).  A strip's four A rows share one chunk permutation
+  // ((row >> 2) & 3 with pxb a multiple of 4): one address register, the rows at immediate offsets.
+  const int pxb = strip * 4;
+  const unsigned wa0 = sf_lds_addr(s_a) + (unsigned)((wave * 32 + pxb) * 32 + (((c4 >> 1) ^ (strip & 3)) << 3) + (c4 & 1) * 4) * 2u;
 
-  sf_f32x16 acc[2][2];
+  sf_f32x16 acc[TM][2];
   int buf = 0;
   issue(cur, 0, 0, true);
   for (int t = t_begin; t < t_end; t += G) {
     const Coord nxt = decode(min(t + G, p.ntiles - 1));
-    const int y0 = cur.ty * SF_R, x0 = HPOOL ? cur.tx * SF_XP - p.pool_pad_l : cur.tx * SF_X, n0 = cur.nt * SF_BN;
+    const int y0 = cur.ty * SF_R, x0 = HPOOL ? cur.tx * SF_XP - p.pool_pad_l : cur.tx * SF_X, n0 = cur.nt * BN;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     // folded-BN scale/shift of this lane's two output channels: requested here, so that they are older than every
     // prefetch of the tile and using them in the epilogue never waits for a DMA (vmcnt retires in order)
+    // (one-pass form: no four registers to spare across the chunks; loaded in front of the epilogue, behind a prefetch
+    //  that has had the last chunk's 96 MFMAs to land)
     float esc[2], esh[2];
+    auto load_bn = [&]() {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      esc[j] = p.scale[n0 + wn * 64 + j * 32 + frow];
-      esh[j] = p.shift[n0 + wn * 64 + j * 32 + frow];
-    }
+      for (int j = 0; j < 2; ++j) {
+        esc[j] = p.scale[n0 + wn * 64 + j * 32 + frow];
+        esh[j] = p.shift[n0 + wn * 64 + j * 32 + frow];
+      }
+    };
+    if (TM == 2) load_bn();
 
     for (int chunk = 0; chunk < KC; ++chunk, buf ^= 1) {
       // patch(chunk) has landed (vmcnt(0): the DMA's LDS writes retire through vmcnt) and every wave is done with
@@ -210,18 +238,24 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
       // -- this chunk's pointwise weights: L2 -> registers, issued BEFORE the DMA so that waiting for them
       //    (vmcnt retires in order) does not wait for the prefetch --
       sf_f16x8 bh[2][2], bl[2][2];
+      auto load_b = [&]() {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const size_t o = ((size_t)chunk * p.Cout_pad + (n0 + wn * 64 + j * 32 + frow)) * 32 + (ks * 2 + fh) * 8;
-          bh[ks][j] = *reinterpret_cast<const sf_f16x8*>(p.wt_hi + o);
-          if (SPLIT3) bl[ks][j] = *reinterpret_cast<const sf_f16x8*>(p.wt_lo + o);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-      {
+          for (int j = 0; j < 2; ++j) {
+            const size_t o = ((size_t)chunk * p.Cout_pad + (n0 + wn * 64 + j * 32 + frow)) * 32 + (ks * 2 + fh) * 8;
+            bh[ks][j] = *reinterpret_cast<const sf_f16x8*>(p.wt_hi + o);
+            if (SPLIT3) bl[ks][j] = *reinterpret_cast<const sf_f16x8*>(p.wt_lo + o);
+          }
+      };
+      auto prefetch = [&]() {
         const bool more = chunk + 1 < KC;
         issue(more ? cur : nxt, more ? chunk + 1 : 0, buf ^ 1, more || t + G < t_end);
+      };
+      if (TM == 2) {
+        load_b();
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch();
       }
       __builtin_amdgcn_sched_barrier(0);
       // -- depthwise 3x3, one patch row (6 pixels x 4 channels) and its three taps at a time; per output the FMA
@@ -231,93 +265,123 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
                               (unsigned)((wave * SF_ROW_F + pxb * 32 + (pxb >> 3) * 32 + c4 * 4) * 4);
       const unsigned t_hi = t_addr + 512u + ((pxb & 7) == 4 ? 128u : 0u);
       const unsigned w_addr = sf_lds_addr(s_w) + (unsigned)((chunk * 32 + c4 * 4) * 4);
-      sf_f32x4 a[4];
+      // NP pixels at a time: 4 (two-pass form) or 2 + 2 (one-pass form: fewer live registers)
+      constexpr int NP = TM == 2 ? 4 : 2;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) a[k] = (sf_f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int half = 0; half < 4 / NP; ++half) {
+        sf_f32x4 a[NP];
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        sf_f32x4 col[6], ww[3];
-        const unsigned ra = t_addr + ky * (SF_ROW_F * 4), rb = t_hi + ky * (SF_ROW_F * 4);
-        col[0] = sf_ds_read_f4<0>(ra);   col[1] = sf_ds_read_f4<128>(ra); col[2] = sf_ds_read_f4<256>(ra);
-        col[3] = sf_ds_read_f4<384>(ra); col[4] = sf_ds_read_f4<0>(rb);   col[5] = sf_ds_read_f4<128>(rb);
+        for (int k = 0; k < NP; ++k) a[k] = (sf_f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) ww[kx] = sf_ds_read_f4<0>(w_addr + (unsigned)((ky * 3 + kx) * p.ld * 4));
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(col[0]), "+v"(col[1]), "+v"(col[2]), "+v"(col[3]), "+v"(col[4]), "+v"(col[5]), "+v"(ww[0]),
-                       "+v"(ww[1]), "+v"(ww[2])::"memory");
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          if (RELU_IN) {
-            col[k].x = sf_relu(col[k].x); col[k].y = sf_relu(col[k].y);
-            col[k].z = sf_relu(col[k].z); col[k].w = sf_relu(col[k].w);
+        for (int ky = 0; ky < 3; ++ky) {
+          sf_f32x4 col[NP + 2], ww[3];
+          const unsigned ra = t_addr + ky * (SF_ROW_F * 4), rb = t_hi + ky * (SF_ROW_F * 4);
+          if (NP == 4) {
+            col[0] = sf_ds_read_f4<0>(ra);   col[1] = sf_ds_read_f4<128>(ra); col[2] = sf_ds_read_f4<256>(ra);
+            col[3] = sf_ds_read_f4<384>(ra); col[NP] = sf_ds_read_f4<0>(rb);  col[NP + 1] = sf_ds_read_f4<128>(rb);
+          } else if (half == 0) {
+            col[0] = sf_ds_read_f4<0>(ra);   col[1] = sf_ds_read_f4<128>(ra); col[2] = sf_ds_read_f4<256>(ra);
+            col[3] = sf_ds_read_f4<384>(ra);
+          } else {
+            col[0] = sf_ds_read_f4<256>(ra); col[1] = sf_ds_read_f4<384>(ra); col[2] = sf_ds_read_f4<0>(rb);
+            col[3] = sf_ds_read_f4<128>(rb);
           }
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) ww[kx] = sf_ds_read_f4<0>(w_addr + (unsigned)((ky * 3 + kx) * p.ld * 4));
+          if (NP == 4)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(col[0]), "+v"(col[1]), "+v"(col[2]), "+v"(col[3]), "+v"(col[NP]), "+v"(col[NP + 1]),
+                           "+v"(ww[0]), "+v"(ww[1]), "+v"(ww[2])::"memory");
+          else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(col[0]), "+v"(col[1]), "+v"(col[2]), "+v"(col[3]), "+v"(ww[0]), "+v"(ww[1]), "+v"(ww[2])::"memory");
+#pragma unroll
+          for (int k = 0; k < NP + 2; ++k) {
+            if (RELU_IN) {
+              col[k].x = sf_relu(col[k].x); col[k].y = sf_relu(col[k].y);
+              col[k].z = sf_relu(col[k].z); col[k].w = sf_relu(col[k].w);
+            }
+          }
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+              a[k].x = fmaf(col[k + kx].x, ww[kx].x, a[k].x); a[k].y = fmaf(col[k + kx].y, ww[kx].y, a[k].y);
+              a[k].z = fmaf(col[k + kx].z, ww[kx].z, a[k].z); a[k].w = fmaf(col[k + kx].w, ww[kx].w, a[k].w);
+            }
         }
+        // -- split into f16 hi/lo, A tile rows wave*32 + pxb + k (chunk-permuted like the conv kernel's DMA layout) --
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            a[k].x = fmaf(col[k + kx].x, ww[kx].x, a[k].x); a[k].y = fmaf(col[k + kx].y, ww[kx].y, a[k].y);
-            a[k].z = fmaf(col[k + kx].z, ww[kx].z, a[k].z); a[k].w = fmaf(col[k + kx].w, ww[kx].w, a[k].w);
-          }
-      }
-      // -- split into f16 hi/lo, A tile rows wave*32 + pxb + k (chunk-permuted like the conv kernel's DMA layout) --
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int row = wave * 32 + pxb + k;
-        const unsigned wa = a_base + (unsigned)(row * 32 + (((c4 >> 1) ^ ((row >> 2) & 3)) << 3) + (c4 & 1) * 4) * 2u;
-        const _Float16 h0 = (_Float16)a[k].x, h1 = (_Float16)a[k].y, h2 = (_Float16)a[k].z, h3 = (_Float16)a[k].w;
-        sf_f16x4 hv = {h0, h1, h2, h3};
-        sf_ds_write_b64(wa, *reinterpret_cast<uint2*>(&hv));
-        if (SPLIT3) {
-          sf_f16x4 lv = {(_Float16)(a[k].x - (float)h0), (_Float16)(a[k].y - (float)h1), (_Float16)(a[k].z - (float)h2),
-                         (_Float16)(a[k].w - (float)h3)};
-          sf_ds_write_b64(wa + 128 * 64, *reinterpret_cast<uint2*>(&lv));
+        for (int k = 0; k < NP; ++k) {
+          const _Float16 h0 = (_Float16)a[k].x, h1 = (_Float16)a[k].y, h2 = (_Float16)a[k].z, h3 = (_Float16)a[k].w;
+          sf_f16x4 hv = {h0, h1, h2, h3};
+          sf_write_row<SPLIT3>(wa0, half * NP + k, hv, a[k]);
         }
       }
       // A tile visible to the workgroup: LDS writes only (lgkmcnt) -- the prefetch DMA stays in flight
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (TM != 2) {
+        load_b();
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch();
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // -- pointwise: two 16-deep halves, products in the conv kernel's order (lo*hi, hi*lo, hi*hi) --
-      sf_f16x8 ah[2][2], al[2][2];
+      auto read_half = [&](int ks, sf_f16x8* ah, sf_f16x8* al) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          ah[ks][i] = sf_ds_read_b128<0>(a_rd[ks][i]);
-          if (SPLIT3) al[ks][i] = sf_ds_read_b128<128 * 64>(a_rd[ks][i]);
+        for (int i = 0; i < TM; ++i) {
+          ah[i] = sf_ds_read_b128<0>(a_rd[ks] + i * 2048);
+          if (SPLIT3) al[i] = sf_ds_read_b128<128 * 64>(a_rd[ks] + i * 2048);
         }
-      // one wait for all eight reads; the operands pass through it so that no MFMA can be scheduled above it
-      if (SPLIT3)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(ah[0][0]), "+v"(ah[0][1]), "+v"(ah[1][0]), "+v"(ah[1][1]), "+v"(al[0][0]), "+v"(al[0][1]),
-                       "+v"(al[1][0]), "+v"(al[1][1])::"memory");
-      else
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0][0]), "+v"(ah[0][1]), "+v"(ah[1][0]), "+v"(ah[1][1])::"memory");
+      };
+      // one wait for the reads; the operands pass through it so that no MFMA can be scheduled above it
+      auto wait_half = [&](sf_f16x8* ah, sf_f16x8* al) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+        for (int i = 0; i < TM; i += 2) {
+          if (SPLIT3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i]), "+v"(ah[i + 1]), "+v"(al[i]), "+v"(al[i + 1])::"memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i]), "+v"(ah[i + 1])::"memory");
+        }
+      };
+      auto mma_half = [&](int ks, const sf_f16x8* ah, const sf_f16x8* al) {
         if (SPLIT3) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[ks][j], acc[i][j], 0, 0, 0);
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[ks][j], acc[i][j], 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[ks][j], acc[i][j], 0, 0, 0);
+      };
+      if (TM == 2) {
+        sf_f16x8 ah[2][TM], al[2][TM];
+        read_half(0, ah[0], al[0]);
+        read_half(1, ah[1], al[1]);
+        wait_half(ah[0], al[0]);
+        wait_half(ah[1], al[1]);
+        mma_half(0, ah[0], al[0]);
+        mma_half(1, ah[1], al[1]);
+      } else {
+        sf_f16x8 ah[TM], al[TM];
+        read_half(0, ah, al);
+        wait_half(ah, al);
+        mma_half(0, ah, al);
+        __builtin_amdgcn_sched_barrier(0);
+        read_half(1, ah, al);
+        wait_half(ah, al);
+        mma_half(1, ah, al);
       }
     }
 
-    // ---- epilogue: straight from the accumulators (no LDS: the next tile's patch is already in flight).  A lane
-    // holds one output channel (column frow) of 16 pixels of one tile row; lanes 0..31 of a store cover 128
-    // contiguous bytes.  Raw buffer stores: the row offset rides in the scalar offset, pixels outside the tile /
-    // image get an out-of-range lane offset (dropped by the bounds check) -- no branches, no 64-bit pointers. ----
+    if (TM != 2) load_bn();
     if (HPOOL) {
       // Horizontal half of the pool, from the accumulators.  A lane holds columns c + 4 fh (c = 0..3, 8..11 in registers
       // 0..7, 16..19, 24..27 in 8..15) of one channel; v_permlane32_swap of register r with r + 8 leaves lanes 0..31
@@ -327,8 +391,8 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
       const int klim = min(SF_XP / 2, p.Wo - cur.tx * (SF_XP / 2)) - 8 * fh;   // this lane's windows are 8 fh + kk
       const bool edge = x0 < 0 || x0 + 32 > p.W;                               // wave-uniform
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int y = y0 + wm * 2 + i;
+      for (int i = 0; i < TM; ++i) {
+        const int y = y0 + wm * TM + i;
         if (y >= p.H) continue;                                                // wave-uniform
         const unsigned row_off = (unsigned)((((size_t)cur.n * p.H + y) * p.Wo + cur.tx * (SF_XP / 2)) * p.ldo * 4);
 #pragma unroll
@@ -373,8 +437,8 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
     }
     const int lim = min(SF_X, p.W - x0) - 4 * fh;            // this lane's pixels are c + 4*fh, c = 0..3, 8..11, 16.., 24..
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int y = y0 + wm * 2 + i;                         // tile row of this 32-row accumulator block
+    for (int i = 0; i < TM; ++i) {
+      const int y = y0 + wm * TM + i;                        // tile row of this 32-row accumulator block
       if (y >= p.H) continue;                                // wave-uniform
       const unsigned row_off = (unsigned)((((size_t)cur.n * p.H + y) * p.W + x0) * p.ldo * 4);   // < 2^32 (host check)
 #pragma unroll
@@ -395,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
 }
 
 bool sepconv_fused_supported(int cin_ld, int cout_pad, int dil) {
-  return dil == 1 && cin_ld % 32 == 0 && cin_ld <= SF_KMAX && cout_pad % SF_BN == 0 && cout_pad <= 256;
+  return dil == 1 && cin_ld % 32 == 0 && cin_ld <= SF_KMAX && cout_pad % 128 == 0 && cout_pad <= 256;
 }
 
 // One launch per image range whose input stays below 2 GiB (32-bit buffer offsets of the LDS DMA).
@@ -417,21 +481,32 @@ int launch_sepconv_fused(const float* in, const float* w9c, const unsigned short
     p.out = out + (size_t)nb * H * (pool_pad_l >= 0 ? (W + 1) / 2 : W) * ldo;
     p.N = n; p.H = H; p.W = W; p.ld = ld; p.ldo = ldo; p.Cout_pad = cout_pad; p.relu_in = relu_in; p.relu_out = relu_out;
     const bool hpool = pool_pad_l >= 0;
+    // 256 output channels: one pass of the 1 x 4 wave layout (XDET_SEPCONV_TWO_PASS=1: two 128-wide passes, for A/B runs)
+    static const bool two_pass = getenv("XDET_SEPCONV_TWO_PASS") != nullptr;
+    const bool wide = cout_pad == 256 && !two_pass;
     p.Wo = (W + 1) / 2; p.pool_pad_l = hpool ? pool_pad_l : 0;
-    p.TY = (int)cdiv(H, SF_R); p.TX = hpool ? (int)cdiv(p.Wo, SF_XP / 2) : (int)cdiv(W, SF_X); p.NT = cout_pad / SF_BN;
+    p.TY = (int)cdiv(H, SF_R); p.TX = hpool ? (int)cdiv(p.Wo, SF_XP / 2) : (int)cdiv(W, SF_X); p.NT = wide ? 1 : cout_pad / 128;
     const int64_t nt = (int64_t)n * p.TY * p.TX * p.NT;
     p.ntiles = (int)nt;
     p.tiles_per_block = 0;
     // two workgroups per CU (LDS); a multiple of 8 so that every XCD gets the same number
     const dim3 g((unsigned)std::min<int64_t>(512, cdiv(nt, 8) * 8));
     auto go = [&](auto kern) { hipLaunchKernelGGL(kern, g, dim3(256), 0, s, p); };
-    if (hpool) {
-      if (wt_lo_blocked) { if (relu_in) go(sepconv_fused_kernel<true, true, true>); else go(sepconv_fused_kernel<true, false, true>); }
-      else { if (relu_in) go(sepconv_fused_kernel<false, true, true>); else go(sepconv_fused_kernel<false, false, true>); }
-    } else {
-      if (wt_lo_blocked) { if (relu_in) go(sepconv_fused_kernel<true, true, false>); else go(sepconv_fused_kernel<true, false, false>); }
-      else { if (relu_in) go(sepconv_fused_kernel<false, true, false>); else go(sepconv_fused_kernel<false, false, false>); }
-    }
+    auto pick = [&](auto split3, auto relu, auto pool) {
+      constexpr bool S3 = decltype(split3)::value, RL = decltype(relu)::value, PL = decltype(pool)::value;
+      if (wide) go(sepconv_fused_kernel<S3, RL, PL, 4>);
+      else go(sepconv_fused_kernel<S3, RL, PL, 2>);
+    };
+    auto pick2 = [&](auto split3, auto relu) {
+      if (hpool) pick(split3, relu, std::true_type{});
+      else pick(split3, relu, std::false_type{});
+    };
+    auto pick1 = [&](auto split3) {
+      if (relu_in) pick2(split3, std::true_type{});
+      else pick2(split3, std::false_type{});
+    };
+    if (wt_lo_blocked) pick1(std::true_type{});
+    else pick1(std::false_type{});
     XDET_LAUNCH_CHECK();
   }
   return XDET_OK;
