@@ -138,6 +138,9 @@ SEP_CASES = [
     (2, 31, 61, 96, 128, False, True),        # W = 2 tiles + 1, H % 4 = 3
     (1, 4, 1, 64, 128, True, False),          # one pixel column
     (5, 9, 29, 160, 256, True, False),        # several images per workgroup walk
+    (2, 60, 60, 256, 728, True, False),       # block4_sepconv1: 728 -> 768 outputs as three 256-wide passes
+    (1, 13, 31, 64, 96, False, True),         # fewer outputs than the 128-wide pass (masked channels)
+    (1, 7, 33, 32, 1000, True, False),        # 1000 -> 1024: four passes
 ]
 
 

@@ -573,7 +573,7 @@ struct Plan {
     // ONE fused kernel, the depthwise result never leaves the CU (sepconv_fused.hip); bit-identical to the
     // two-kernel form below, which the wide 30x30 layers keep (their GEMM needs the big MFMA tiles).
     if (fuse_sepconv && L->dma_capable() && !res && emit_planes_next == 0 && !in.no_f32 &&
-        sepconv_fused_supported(in.ld, L->cout_pad, dilation) && L->cout_pad == L->ld_out()) {
+        sepconv_fused_supported(in.ld, L->cout_pad, dilation) && L->ld_out() <= L->cout_pad) {
       if (pool_res && fuse_hpool && in.H * in.W >= pool_fuse_min_pixels) {
         int Ho, Wo, pt, pl;
         same_pad(in.H, 3, 2, 1, &pt, &Ho);
@@ -1352,9 +1352,9 @@ int xdet_sepconv_fused_forward(void* dw_layer, void* pw_layer, const float* in, 
   ConvLayer* L = static_cast<ConvLayer*>(b);
   XDET_REQUIRE(L->dma_capable() && L->kh == 1 && L->kw == 1 && L->stride == 1 && L->groups == 1,
                "sepconv_fused: the pointwise layer must be a 1x1 stride-1 conv created in a split-precision mode");
-  XDET_REQUIRE(D->ld == ld_in && L->ld_in() == ld_in && L->ld_out() == ld_out && L->cout_pad == ld_out &&
+  XDET_REQUIRE(D->ld == ld_in && L->ld_in() == ld_in && L->ld_out() == ld_out && ld_out <= L->cout_pad &&
                    sepconv_fused_supported(ld_in, L->cout_pad, D->dil),
-               "sepconv_fused: needs <= 256 input channels (multiple of 32), 128 or 256 outputs, dilation 1");
+               "sepconv_fused: needs <= 256 input channels (multiple of 32), <= 128 or 129..1024 outputs, dilation 1");
   DeviceGuard guard(L->device);
   return launch_sepconv_fused(in, D->d_w, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale, L->d_shift, out, N, H, W, ld_in, ld_out,
                               L->cout_pad, relu_in, L->relu_out, S(stream));
@@ -1381,9 +1381,9 @@ int xdet_sepconv_fused_hpool_forward(void* dw_layer, void* pw_layer, const float
   ConvLayer* L = static_cast<ConvLayer*>(b);
   XDET_REQUIRE(L->dma_capable() && L->kh == 1 && L->kw == 1 && L->stride == 1 && L->groups == 1,
                "sepconv_fused: the pointwise layer must be a 1x1 stride-1 conv created in a split-precision mode");
-  XDET_REQUIRE(D->ld == ld_in && L->ld_in() == ld_in && L->ld_out() == ld_out && L->cout_pad == ld_out &&
+  XDET_REQUIRE(D->ld == ld_in && L->ld_in() == ld_in && L->ld_out() == ld_out && ld_out <= L->cout_pad &&
                    sepconv_fused_supported(ld_in, L->cout_pad, D->dil),
-               "sepconv_fused: needs <= 256 input channels (multiple of 32), 128 or 256 outputs, dilation 1");
+               "sepconv_fused: needs <= 256 input channels (multiple of 32), <= 128 or 129..1024 outputs, dilation 1");
   int Wo, pl;
   same_pad(W, 3, 2, 1, &pl, &Wo);
   DeviceGuard guard(L->device);

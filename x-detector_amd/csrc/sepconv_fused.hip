@@ -459,7 +459,8 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
 }
 
 bool sepconv_fused_supported(int cin_ld, int cout_pad, int dil) {
-  return dil == 1 && cin_ld % 32 == 0 && cin_ld <= SF_KMAX && cout_pad % 128 == 0 && cout_pad <= 256;
+  // 128 outputs: one 128-wide pass; multiples of 256 (block4_sepconv1: 728 -> 768): 256-wide passes over the same patch
+  return dil == 1 && cin_ld % 32 == 0 && cin_ld <= SF_KMAX && (cout_pad == 128 || (cout_pad % 256 == 0 && cout_pad <= 1024));
 }
 
 // One launch per image range whose input stays below 2 GiB (32-bit buffer offsets of the LDS DMA).
@@ -483,9 +484,9 @@ int launch_sepconv_fused(const float* in, const float* w9c, const unsigned short
     const bool hpool = pool_pad_l >= 0;
     // 256 output channels: one pass of the 1 x 4 wave layout (XDET_SEPCONV_TWO_PASS=1: two 128-wide passes, for A/B runs)
     static const bool two_pass = getenv("XDET_SEPCONV_TWO_PASS") != nullptr;
-    const bool wide = cout_pad == 256 && !two_pass;
+    const bool wide = cout_pad % 256 == 0 && !two_pass;
     p.Wo = (W + 1) / 2; p.pool_pad_l = hpool ? pool_pad_l : 0;
-    p.TY = (int)cdiv(H, SF_R); p.TX = hpool ? (int)cdiv(p.Wo, SF_XP / 2) : (int)cdiv(W, SF_X); p.NT = wide ? 1 : cout_pad / 128;
+    p.TY = (int)cdiv(H, SF_R); p.TX = hpool ? (int)cdiv(p.Wo, SF_XP / 2) : (int)cdiv(W, SF_X); p.NT = wide ? cout_pad / 256 : cout_pad / 128;
     const int64_t nt = (int64_t)n * p.TY * p.TX * p.NT;
     p.ntiles = (int)nt;
     p.tiles_per_block = 0;
