@@ -420,7 +420,7 @@ struct Plan {
   bool subsample_projections = true;
   bool patch_conv3x3 = true;     // option "conv3x3" = "patch" | "gemm"
   bool fuse_hpool = true;        // option "pool" = "split" | "whole": horizontal half of an entry-flow pool in the producer
-  int pool_fuse_min_pixels = 150 * 150;   // ... where the block is HBM-bound (237 x 237; the 119 x 119 one is not)
+  int pool_fuse_min_pixels = 100 * 100;   // ... for the 237 x 237 block (+0.8 %) and the 119 x 119 one (time-neutral, -0.9 GB)
   int add_conv(const std::string& name, int stage, const Buf& in_, ConvLayer* L, const Buf* res, int relu_in, Buf* out) {
     Buf in = in_;
     const int emit = L->precision == PREC_F32 ? 0 : emit_planes_next;
