@@ -105,3 +105,43 @@ def test_ext_decode_and_bboxes_eval(oracle):
             assert (gs > 0).sum() == (rs > 0).sum(), c
             assert np.abs(gs - rs).max() <= 1e-6
             assert np.abs(gb - rb).max() <= 1e-6
+
+
+def test_non_finite_head_outputs_are_loud(oracle, lh_weights):
+    """A NaN / inf head logit compares false against every threshold: the image would silently lose its detections.
+    bboxes_eval marks the (image, class) slot NaN instead and the host raises.  An activation beyond the f16 range of the
+    split-precision convs (|x| > 65504) becomes inf -> NaN -> 0 at the next ReLU; the check_range option
+    validates every activation tensor and reports through the same channel."""
+    from xdet import ops
+    from xdet._lib import XdetError
+    from xdet.model import LightHeadDetector
+    from xdet import weights as W
+    rng = np.random.default_rng(4)
+    R = 64
+    boxes = oracle.bboxes_clip([0, 0, 1, 1], _boxes_scores(rng, 1, R, 0.5)[1][0])
+    logits = (rng.standard_normal((R, 21)) * 3).astype(np.float32)
+    clean = ops.bboxes_eval(logits, boxes, (480, 480))
+    assert all(np.isfinite(clean[c][0]).all() for c in range(1, 21))
+    for bad in (np.nan, np.inf, -np.inf):
+        lg = logits.copy()
+        lg[17, 5] = bad
+        got = ops.bboxes_eval(lg, boxes, (480, 480))
+        assert all(np.isnan(got[c][0][0]) for c in range(1, 21)), bad
+    # end to end: an image far outside the whitened range drives the activations beyond the f16 range
+    from xdet.runtime import set_precision
+    set_precision('f16x3')
+    try:
+        det = LightHeadDetector(lh_weights, image_size=256, max_batch=2, rpn_post_nms_top_n=50, check_range=True)
+        quiet = LightHeadDetector(lh_weights, image_size=256, max_batch=2, rpn_post_nms_top_n=50)
+    finally:
+        set_precision('f32')
+    imgs = W.synthetic_images(2, 256, seed=3)
+    det.forward(imgs)                                   # fine
+    imgs[1] *= 1e30
+    with pytest.raises(XdetError, match=r'image\(s\) \[1\]'):
+        det.forward(imgs)
+    # without the validation pass the overflow is laundered by the next ReLU (max(NaN, 0) = 0): image 1's detections are
+    # then garbage without a NaN in them -- which is what the option is for; image 0 is untouched either way
+    out = quiet.forward(imgs)
+    ref = quiet.forward(W.synthetic_images(2, 256, seed=3))
+    assert all(np.array_equal(out[0][c][0], ref[0][c][0]) for c in range(1, 21))

@@ -106,6 +106,10 @@ int launch_maxpool3x3s2_add(const float* in, const float* res, float* out, int N
 // vertical half only, over rows the producer already pooled horizontally (sepconv_fused.hip HPOOL)
 int launch_maxpool_v3s2_add(const float* in_hpooled, const float* res, float* out, int N, int H, int Wo, int C, int ld,
                             int Ho, int pad_t, hipStream_t s);
+// diagnostic: bad_per_image[n] = 1 if any element of image n is NaN or beyond +-limit
+int launch_range_check(const float* x, int N, size_t per_image, float limit, int* bad_per_image, hipStream_t s);
+int launch_range_check_planes(const unsigned short* hi, int N, int64_t pix_per_image, int ld, int* bad_per_image,
+                              hipStream_t s);
 int launch_relu_copy(const float* in, float* out, int64_t n, hipStream_t s);
 int launch_stem_conv3x3s2(const float* in_nchw, const float* w27x32, const float* scale, const float* shift,
                           unsigned short* hi, unsigned short* lo, int N, int S, hipStream_t s);
@@ -161,6 +165,7 @@ struct ProposalWorkspace {
   float* sscores;             // [N][pre_n]
   unsigned long long* cand;   // [N][n_anchor] keys that can still reach the top pre_n
   int* hist;                  // [N][16384] histogram of the keys' top 16 bits
+  int* bad;                   // [N] set when an objectness score / box of the image is not finite (read by bboxes_eval)
   int* tbin;                  // [N] threshold bin
   int* kept;                  // [N][post_n]
 };
@@ -176,6 +181,7 @@ int launch_get_proposals(const float* objectness, const float* boxes, int N, int
 int launch_ext_decode_rois(const float* rois, const float* reg, int ld_reg, int64_t n, float* out, hipStream_t s);
 int launch_bboxes_eval(const float* cls, int ld_cls, const float* boxes, int N, int R, int num_classes,
                        const int* image_shapes, const float* bbox_img, int net_h, int net_w, float select_thr,
-                       float nms_thr, int nms_topk, float* det_scores, float* det_boxes, hipStream_t s);
+                       float nms_thr, int nms_topk, float* det_scores, float* det_boxes, hipStream_t s,
+                       const int* bad_per_image = nullptr);
 
 }  // namespace xdet

@@ -11,6 +11,7 @@
 // bitmask NMS and the ordered scan all stay in LDS; output is the reference's zero-padded
 // per-class (scores[topk], boxes[topk,4]).
 #include "common.h"
+#include <cfloat>
 
 namespace xdet {
 
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(256) void bboxes_eval_kernel(const float* __restric
                                                           const float* __restrict__ bbox_img, int net_h, int net_w,
                                                           float select_thr, float nms_thr, int nms_topk,
                                                           float* __restrict__ det_scores,
-                                                          float* __restrict__ det_boxes) {
+                                                          float* __restrict__ det_boxes,
+                                                          const int* __restrict__ bad_per_image) {
   __shared__ u64 keys[EV_MAXR];
   __shared__ float4 bx[EV_MAXR];
   __shared__ float4 sbox[EV_MAXS];
@@ -77,11 +79,12 @@ __global__ __launch_bounds__(256) void bboxes_eval_kernel(const float* __restric
   __shared__ int s_nvalid;
   __shared__ int s_keptidx[EV_MAXS];
   __shared__ int s_nkeep;
+  __shared__ int s_bad;
 
   const int c = blockIdx.x + 1;
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
-  if (tid == 0) { s_nvalid = 0; s_nkeep = 0; }
+  if (tid == 0) { s_nvalid = 0; s_nkeep = 0; s_bad = 0; }
   __syncthreads();
 
   const float4 ref = *reinterpret_cast<const float4*>(bbox_img + n * 4);
@@ -90,11 +93,16 @@ __global__ __launch_bounds__(256) void bboxes_eval_kernel(const float* __restric
   const float min_size = fmaxf(0.0001f, 0.03f * sqrtf(area / (float)(net_h * net_w)));
   const float sx = ref.z - ref.x, sy = ref.w - ref.y;   // bboxes_resize scale (h, w)
 
-  int local_valid = 0;
+  int local_valid = 0, local_bad = bad_per_image ? bad_per_image[n] : 0;   // (proposal stage: non-finite RPN outputs)
   for (int r = tid; r < R; r += 256) {
     const float* lg = cls + ((int64_t)n * R + r) * ld_cls;
     float m = lg[0];
-    for (int k = 1; k < num_classes; ++k) m = fmaxf(m, lg[k]);
+    float lsum = lg[0];
+    for (int k = 1; k < num_classes; ++k) { m = fmaxf(m, lg[k]); lsum += lg[k]; }
+    // A non-finite logit (an activation that left the f16 range of the split-precision convs upstream, or a broken
+    // checkpoint) would otherwise vanish here: its score compares false against the threshold and the image simply
+    // has no detections.  It is made loud instead: the (image, class) slot is marked NaN below, the host raises.
+    local_bad |= !(fabsf(lsum) <= FLT_MAX);
     float sum = 0.f, ec = 0.f;
     for (int k = 0; k < num_classes; ++k) {
       const float e = expf(lg[k] - m);
@@ -122,6 +130,7 @@ __global__ __launch_bounds__(256) void bboxes_eval_kernel(const float* __restric
     local_valid += valid;
   }
   if (local_valid) atomicAdd(&s_nvalid, local_valid);
+  if (local_bad) atomicOr(&s_bad, 1);
   __syncthreads();
 
   const int max_sorted = min(2 * nms_topk, EV_MAXS);
@@ -194,6 +203,7 @@ __global__ __launch_bounds__(256) void bboxes_eval_kernel(const float* __restric
       s = sscore[src];
       b = sbox[src];
     }
+    if (k == 0 && s_bad) s = NAN;
     os[k] = s;
     *reinterpret_cast<float4*>(ob + k * 4) = b;
   }
@@ -201,14 +211,15 @@ __global__ __launch_bounds__(256) void bboxes_eval_kernel(const float* __restric
 
 int launch_bboxes_eval(const float* cls, int ld_cls, const float* boxes, int N, int R, int num_classes,
                        const int* image_shapes, const float* bbox_img, int net_h, int net_w, float select_thr,
-                       float nms_thr, int nms_topk, float* det_scores, float* det_boxes, hipStream_t s) {
+                       float nms_thr, int nms_topk, float* det_scores, float* det_boxes, hipStream_t s,
+                       const int* bad_per_image) {
   XDET_REQUIRE(R > 0 && R <= EV_MAXR, "bboxes_eval: 1 <= rois per image <= 1024");
   XDET_REQUIRE(nms_topk > 0 && 2 * nms_topk <= EV_MAXS, "bboxes_eval: nms_topk must be in 1..256");
   XDET_REQUIRE(num_classes >= 2 && num_classes <= ld_cls, "bboxes_eval: bad num_classes");
   if (N == 0) return XDET_OK;
   hipLaunchKernelGGL(bboxes_eval_kernel, dim3(num_classes - 1, N), dim3(256), 0, s, cls, ld_cls, boxes, R,
                      num_classes, image_shapes, bbox_img, net_h, net_w, select_thr, nms_thr, nms_topk, det_scores,
-                     det_boxes);
+                     det_boxes, bad_per_image);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }

@@ -568,6 +568,62 @@ int launch_maxpool_v3s2_add(const float* in_hpooled, const float* res, float* ou
   return XDET_OK;
 }
 
+// Diagnostic pass of the "check_range" net option: |x| <= limit (65504, the largest f16) for every element of an f32
+// activation tensor, else bad[image] = 1.  The split-precision convs turn a larger activation into hi = inf, and the
+// NaN that follows does not survive the next ReLU (max(NaN, 0) = 0): without this pass an overflow ends as a silently
+// empty detection list.  BN-normalised checkpoints stay orders of magnitude inside the range; the pass is for
+// validating a new checkpoint once (it reads every activation again: ~+30 % time).
+__global__ __launch_bounds__(256) void range_check_kernel(const float4* __restrict__ x, int64_t n4, int64_t per_image4,
+                                                          float limit, int* __restrict__ bad) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = x[i];
+    const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    const bool nan = v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w;
+    if (nan || !(m <= limit)) bad[i / per_image4] = 1;
+  }
+}
+
+// ... and the same for a tensor that only exists as split planes [pix/16][ld/32][16][32] (stem, depthwise, conv
+// epilogues that feed the LDS-DMA kernel): hi = inf / NaN is how an element beyond the f16 range looks there.
+__global__ __launch_bounds__(256) void range_check_planes_kernel(const uint4* __restrict__ hi, int64_t n8, int c32n,
+                                                                 int64_t pix_per_image, int64_t n_pix,
+                                                                 int* __restrict__ bad) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 v = hi[i];
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    bool b = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b |= (w[k] & 0x7c00u) == 0x7c00u || (w[k] & 0x7c000000u) == 0x7c000000u;
+    if (b) {
+      const int64_t pix = (i >> 6) / c32n * 16 + ((i >> 2) & 15);      // 64 chunks of 8 halves per 1 KB block
+      if (pix < n_pix) bad[pix / pix_per_image] = 1;
+    }
+  }
+}
+
+int launch_range_check_planes(const unsigned short* hi, int N, int64_t pix_per_image, int ld, int* bad_per_image,
+                              hipStream_t s) {
+  const int64_t n_pix = (int64_t)N * pix_per_image;
+  const int64_t n8 = cdiv(n_pix, 16) * 16 * ld / 8;
+  if (n8 == 0) return XDET_OK;
+  const int blocks = (int)std::min<int64_t>(cdiv(n8, 256), 256 * 16);
+  hipLaunchKernelGGL(range_check_planes_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(hi), n8, ld >> 5,
+                     pix_per_image, n_pix, bad_per_image);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
+int launch_range_check(const float* x, int N, size_t per_image, float limit, int* bad_per_image, hipStream_t s) {
+  XDET_REQUIRE(per_image % 4 == 0, "range_check: tensor size must be a multiple of 4");
+  const int64_t n4 = (int64_t)N * (int64_t)(per_image / 4);
+  if (n4 == 0) return XDET_OK;
+  const int blocks = (int)std::min<int64_t>(cdiv(n4, 256), 256 * 16);
+  hipLaunchKernelGGL(range_check_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x), n4,
+                     (int64_t)(per_image / 4), limit, bad_per_image);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
 __global__ void relu_copy_kernel(const float4* __restrict__ in, float4* __restrict__ out, int64_t n4) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 v = in[i];

@@ -328,6 +328,10 @@ struct Plan {
   bool profiling = false;
   std::vector<ProfRec> prof;
   std::vector<void*> allocs;
+  std::vector<std::pair<const float*, size_t>> f32_bufs;   // every activation tensor of new_buf(): (pointer, floats per image)
+  struct PlanesRec { const unsigned short* hi; int64_t pix_per_image; int ld; };
+  std::vector<PlanesRec> planes_bufs;                      // ... and of new_planes()
+  int net_precision = PREC_F32;                            // precision mode the plan was built in
   std::vector<std::unique_ptr<LayerBase>> layers;
   std::vector<Op> ops;
   WeightMap w;
@@ -345,7 +349,9 @@ struct Plan {
     b->H = H; b->W = W; b->C = C;
     b->ld = C <= 4 ? 4 : round_up(C, 32);
     // +128 floats of slack: the conv loader may read a full 32-channel slice of the last pixel
-    return alloc_bytes(((size_t)max_batch * b->per_image() + 128) * sizeof(float), reinterpret_cast<void**>(&b->p));
+    XDET_TRY(alloc_bytes(((size_t)max_batch * b->per_image() + 128) * sizeof(float), reinterpret_cast<void**>(&b->p)));
+    f32_bufs.emplace_back(b->p, b->per_image());
+    return XDET_OK;
   }
   const HostTensor* find(const std::string& name) const {
     auto it = w.find(name);
@@ -392,6 +398,7 @@ struct Plan {
     const size_t bytes = ((size_t)cdiv((int64_t)max_batch * b->H * b->W, 16) * 16 * b->ld + 256) * sizeof(unsigned short);
     XDET_TRY(alloc_bytes(bytes, reinterpret_cast<void**>(&b->hi)));
     XDET_TRY(alloc_bytes(bytes, reinterpret_cast<void**>(&b->lo)));
+    planes_bufs.push_back({b->hi, (int64_t)b->H * b->W, b->ld});
     return get_zeros();
   }
   // element-wise f32 -> (hi, lo) f16 planes (optionally through a ReLU) for a tensor whose producer
@@ -668,6 +675,7 @@ struct LightHeadNet : Plan {
   int large_sep_mode = 0;               // 0 = auto, 1 = direct (15,1)/(1,15) convs, 2 = spectral (DFT-domain GEMMs)
   bool large_sep_spectral = false;      // decided at build
   bool rpn_side_stream = true;          // option "rpn_stream" = "side" | "main"
+  bool check_range = false;             // option "check_range" = "off" | "on": validate every activation against the f16 range
   bool stem_direct = false;             // block1_conv1 as the dedicated NCHW -> planes kernel
   const float* cur_images = nullptr;
   hipStream_t aux = nullptr;            // side stream of the RPN/proposal branch
@@ -956,6 +964,7 @@ struct LightHeadNet : Plan {
     XDET_REQUIRE(cfg.max_batch > 0 && cfg.image_size >= 64, "bad max_batch / image_size");
     XDET_REQUIRE(cfg.num_anchors == 22, "anchor table is the reference's 22-anchor set (1 extra + 7 scales x 3 ratios)");
     max_batch = cfg.max_batch;
+    net_precision = g_default_precision;
     XDET_TRY(build_body());
     XDET_TRY(build_rpn());
     XDET_TRY(large_sep_spectral ? build_large_sep_spectral() : build_large_sep());
@@ -1044,7 +1053,7 @@ struct LightHeadNet : Plan {
     XDET_TRY(check(N));
     return launch_bboxes_eval(cls_reg.p, cls_reg.ld, head_boxes, N, cfg.rpn_post_nms_top_n, cfg.num_classes,
                               shapes ? shapes : def_shapes, bbox ? bbox : def_bbox, cfg.image_size, cfg.image_size,
-                              cfg.select_threshold, cfg.nms_threshold, cfg.nms_topk, ds, db, s);
+                              cfg.select_threshold, cfg.nms_threshold, cfg.nms_topk, ds, db, s, prop_ws.bad);
   }
   int forward_eager(const float* images, int N, const int* shapes, const float* bbox, float* ds, float* db,
                     hipStream_t s) {
@@ -1075,6 +1084,10 @@ struct LightHeadNet : Plan {
     }
     XDET_TRY(get_head(N, s));
     XDET_TRY(head_decode(N, s));
+    if (check_range && net_precision != PREC_F32) {
+      for (const auto& b : f32_bufs) XDET_TRY(launch_range_check(b.first, N, b.second, 65504.f, prop_ws.bad, s));
+      for (const auto& b : planes_bufs) XDET_TRY(launch_range_check_planes(b.hi, N, b.pix_per_image, b.ld, prop_ws.bad, s));
+    }
     return bboxes_eval(N, shapes, bbox, ds, db, s);
   }
 };
@@ -1478,6 +1491,11 @@ int xdet_net_set_option(void* net, const char* key, const char* value) {
   if (k == "sepconv") {
     XDET_REQUIRE(v == "fused" || v == "split", "sepconv must be fused | split");
     n->fuse_sepconv = v == "fused";
+    return XDET_OK;
+  }
+  if (k == "check_range") {
+    XDET_REQUIRE(v == "on" || v == "off", "check_range must be on | off");
+    n->check_range = v == "on";
     return XDET_OK;
   }
   if (k == "pool") {

@@ -20,6 +20,7 @@
 //                wavefront; stops at post_n
 //   7. gather  : rois[j] = kept[j mod n_keep]  (tile + identity "shuffle" of :196-213)
 #include "common.h"
+#include <cfloat>
 #include <cstdlib>
 
 namespace xdet {
@@ -38,7 +39,7 @@ size_t proposal_workspace_bytes(int N, int n_anchor, int pre_n, int post_n) {
   add((size_t)N * pre_n * 16);
   add((size_t)N * pre_n * 4);
   add((size_t)N * n_anchor * 8);
-  add((size_t)N * HIST_BINS * 4);
+  add(((size_t)N * HIST_BINS + (size_t)round_up(N, 4)) * 4);   // hist + bad (zeroed together)
   add((size_t)N * 4);
   add((size_t)N * post_n * 4);
   return b;
@@ -54,7 +55,8 @@ void proposal_workspace_carve(void* base, int N, int n_anchor, int pre_n, int po
   ws->sboxes = reinterpret_cast<float*>(take((size_t)N * pre_n * 16));
   ws->sscores = reinterpret_cast<float*>(take((size_t)N * pre_n * 4));
   ws->cand = reinterpret_cast<u64*>(take((size_t)N * n_anchor * 8));
-  ws->hist = reinterpret_cast<int*>(take((size_t)N * HIST_BINS * 4));
+  ws->hist = reinterpret_cast<int*>(take(((size_t)N * HIST_BINS + (size_t)round_up(N, 4)) * 4));
+  ws->bad = ws->hist + (size_t)N * HIST_BINS;
   ws->tbin = reinterpret_cast<int*>(take((size_t)N * 4));
   ws->kept = reinterpret_cast<int*>(take((size_t)N * post_n * 4));
 }
@@ -105,7 +107,7 @@ int launch_rpn_decode(const float* rpn_out, int ld, int cls_off, int box_off, in
 // ---------------------------------------------------------------------------------------
 __global__ void prop_prepare_kernel(const float* __restrict__ score, const float* __restrict__ boxes, int n_anchor,
                                     float min_size, u64* __restrict__ keys, float* __restrict__ cboxes,
-                                    int* __restrict__ hist) {
+                                    int* __restrict__ hist, int* __restrict__ bad) {
   const int n = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_anchor) return;
@@ -121,6 +123,9 @@ __global__ void prop_prepare_kernel(const float* __restrict__ score, const float
   const float ws = xmax - xmin, hs = ymax - ymin;
   const float xc = xmin + ws / 2.f, yc = ymin + hs / 2.f;
   const float sc = score[g];
+  // A non-finite score or box compares false below and would just drop out: the image would quietly lose proposals
+  // (all of them if the backbone overflowed).  Remembered per image; bboxes_eval turns it into a NaN the host raises on.
+  if (!(fabsf(sc) <= FLT_MAX) || !(fabsf(b.x + b.y + b.z + b.w) <= FLT_MAX)) bad[n] = 1;
   // a score <= 0 survives top_k in the reference but is dropped as padding by
   // _upsample_rois (:199-200); such entries sort last, so excluding them here is equivalent.
   const bool valid = ws > min_size && hs > min_size && xc > 0.f && yc > 0.f && xc < 1.f && yc < 1.f && sc > 0.f;
@@ -422,12 +427,12 @@ int launch_get_proposals(const float* objectness, const float* boxes, int N, int
   XDET_REQUIRE(N > 0 && n_anchor > 0 && pre_n > 0 && post_n > 0, "get_proposals: sizes must be positive");
   // one launch instead of three hipMemsetAsync (which the runtime splits into ~12 fill kernels per forward)
   hipLaunchKernelGGL(prop_zero_kernel, dim3(512), dim3(256), 0, s, reinterpret_cast<uint4*>(ws.hist),
-                     (int64_t)N * HIST_BINS * 4 / 16, reinterpret_cast<uint4*>(ws.sboxes), (int64_t)N * pre_n,
+                     ((int64_t)N * HIST_BINS + round_up(N, 4)) * 4 / 16, reinterpret_cast<uint4*>(ws.sboxes), (int64_t)N * pre_n,
                      reinterpret_cast<unsigned*>(ws.sscores), (int64_t)N * pre_n);
   XDET_LAUNCH_CHECK();
   const unsigned gb = (unsigned)cdiv(n_anchor, 256);
   hipLaunchKernelGGL(prop_prepare_kernel, dim3(gb, N), dim3(256), 0, s, objectness, boxes, n_anchor, min_size,
-                     ws.keys, ws.cboxes, ws.hist);
+                     ws.keys, ws.cboxes, ws.hist, ws.bad);
   XDET_LAUNCH_CHECK();
   hipLaunchKernelGGL(prop_select_kernel, dim3(N), dim3(1024), 0, s, ws.hist, pre_n, ws.tbin, ws.counts);
   XDET_LAUNCH_CHECK();

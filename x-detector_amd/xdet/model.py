@@ -21,7 +21,10 @@ class LightHeadDetector(object):
     def __init__(self, weights, image_size=480, max_batch=1, num_classes=21, rpn_pre_nms_top_n=5000,
                  rpn_post_nms_top_n=1000, rpn_nms_thres=0.7, rpn_min_size=None, select_threshold=0.01,
                  nms_threshold=0.3, nms_topk=200, device=None, large_sep='auto', sepconv='fused', rpn_stream='side',
-                 conv3x3='patch', pool='split'):
+                 conv3x3='patch', pool='split', check_range=False):
+        """check_range=True: every activation tensor is validated against the f16 range of the split-precision convs
+        after each forward (|x| <= 65504, no NaN); a violation raises in detections() / forward().  For validating a
+        new checkpoint once: the pass re-reads every activation (~+30 % time)."""
         if device is not None:
             check(lib().xdet_set_device(int(device)))
         self.cfg = LightHeadConfig(image_size=image_size, max_batch=max_batch, num_classes=num_classes,
@@ -41,6 +44,7 @@ class LightHeadDetector(object):
         check(lib().xdet_net_set_option(self.handle, b'rpn_stream', rpn_stream.encode()))
         check(lib().xdet_net_set_option(self.handle, b'conv3x3', conv3x3.encode()))
         check(lib().xdet_net_set_option(self.handle, b'pool', pool.encode()))
+        check(lib().xdet_net_set_option(self.handle, b'check_range', b'on' if check_range else b'off'))
         check(lib().xdet_net_build(self.handle))
         self.max_batch = max_batch
         self.image_size = image_size
@@ -116,6 +120,12 @@ class LightHeadDetector(object):
         self.stream.synchronize()
         s = to_host(self._det_scores.ptr, (n, nc, k), np.float32)
         b = to_host(self._det_boxes.ptr, (n, nc, k, 4), np.float32)
+        if np.isnan(s[:, :, 0]).any():
+            # bboxes_eval marks an (image, class) slot NaN when a head logit was not finite (csrc/detect.hip)
+            raise XdetError(-4, 'non-finite network outputs / out-of-range activations for image(s) %s: an activation '
+                                'left the f16 range of the split-precision convs (|x| > 65504) or the weights are '
+                                'broken; use set_precision("f32")'
+                            % sorted(set(np.argwhere(np.isnan(s[:, :, 0]))[:, 0].tolist())))
         return s, b
 
     def forward(self, images_nchw, use_graph=False):
