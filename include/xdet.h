@@ -203,7 +203,14 @@ int xdet_net_set_weight(void* net, const char* name, const float* data_host, int
  *   The choice is per net, never per call: results do not depend on the batch an image arrives in.
  *   "sepconv" = "fused" | "split": entry-flow separable blocks as one kernel (default) or depthwise + pointwise.
  *   "rpn_stream" = "side" | "main": the RPN / proposal branch forks onto a side stream under the large-separable
- *   convs (default) or stays on the caller's stream (per-kernel profiles without cross-stream sharing). */
+ *   convs (default) or stays on the caller's stream (per-kernel profiles without cross-stream sharing).
+ *   "conv3x3" = "patch" | "gemm": block1_conv2 on the staged-tile kernel (default) or the implicit-GEMM kernel.
+ *   "pool" = "split" | "whole" | "split_all": the horizontal half of the block2 / block3 max-pools in the producing
+ *   block's epilogue (default) or the whole pool as its own kernel.
+ *   "check_range" = "off" | "on": after each forward validate every activation tensor and split plane against the
+ *   f16 range of the split-precision convs (|x| <= 65504, no inf / NaN); a violation marks the image's detection
+ *   scores NaN (slot 0 of every class), as a non-finite RPN score or head logit always does.  A diagnostic for new
+ *   checkpoints: the pass re-reads all activations. */
 int xdet_net_set_option(void* net, const char* key, const char* value);
 int xdet_net_build(void* net);     /* folds BN, transposes/pads weights, allocates the workspace */
 int xdet_net_destroy(void* net);
