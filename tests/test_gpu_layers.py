@@ -332,3 +332,37 @@ def test_specialised_conv_entry_points_reject_what_they_cannot_run():
     with pytest.raises(InvalidArgumentError):
         sep_wide(x64, fused=True)
     assert sep_wide(x64, fused=False).numpy().shape == (1, 9, 9, 384)
+
+
+def test_fused_block_and_split_pool_random_shapes():
+    """60 random (N, H, W, Cin, Cout, ReLU) draws -- single rows / columns, widths around the 28- and 30-column tile
+    steps, every output-width class of the fused kernel (one 128-wide pass, 256-wide passes, masked channels): the
+    one-kernel block equals depthwise -> split -> pointwise bit for bit, and block + split pool equals block + whole pool."""
+    from xdet.ops import SeparableConvBN, max_pool_3x3_s2_same_add, separable_block_then_pool_add
+    from xdet.runtime import DeviceTensor, set_precision
+    rng = np.random.default_rng(2024)
+    widths = [1, 2, 3, 13, 14, 15, 27, 28, 29, 30, 31, 32, 55, 56, 57, 59, 60, 61, 85, 91]
+    for it in range(60):
+        N = int(rng.integers(1, 4))
+        H = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 17, 33]))
+        W = int(rng.choice(widths))
+        cin = int(rng.choice([32, 40, 64, 96, 128, 200, 256]))
+        cout = int(rng.choice([70, 96, 128, 200, 256, 500, 512, 728, 1000]))     # padded to 128 or a multiple of 256
+        relu_in, relu_out = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        x = rng.standard_normal((N, H, W, cin)).astype(np.float32)
+        dk = rng.standard_normal((3, 3, cin, 1)).astype(np.float32) / 3
+        pk = (rng.standard_normal((1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+        scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        shift = rng.standard_normal(cout).astype(np.float32)
+        res = rng.standard_normal((N, -(-H // 2), -(-W // 2), cout)).astype(np.float32)
+        set_precision('f16x3' if it % 3 else 'f16')
+        try:
+            op = SeparableConvBN(dk, pk, scale, shift, relu=relu_out)
+        finally:
+            set_precision('f32')
+        tag = (it, N, H, W, cin, cout, relu_in, relu_out)
+        xd, rd = DeviceTensor.from_numpy(x), DeviceTensor.from_numpy(res)
+        fused = op(xd, relu_in=relu_in, fused=True)
+        assert np.array_equal(fused.numpy(), op(xd, relu_in=relu_in, fused=False).numpy()), tag
+        whole = max_pool_3x3_s2_same_add(fused, rd).numpy()
+        assert np.array_equal(separable_block_then_pool_add(op, xd, rd, relu_in=relu_in).numpy(), whole), tag
