@@ -5,7 +5,7 @@
 
 One "step" = one pass of the whole hot path (backbone + RPN + proposals + PsRoiAlign + light
 head + per-class NMS) over one batch of B synthetic 480x480 images per GPU, inputs already
-resident in HBM.  The batch runs as --ways concurrent sub-batches (default 2 x 64), each a net
+resident in HBM.  The batch runs as --ways concurrent sub-batches (default 2 x 128), each a net
 instance replaying its hipGraph on its own stream, so the partial last round of workgroups of one
 launch is filled by the other stream's kernels.
 
@@ -54,7 +54,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=128, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=256, help='images per GPU per step')
     ap.add_argument('--ways', type=int, default=2,
                     help='the batch runs as this many concurrent sub-batches (net instances on their own HIP '
                          'streams): the partial last round of one launch is filled by the other stream')
@@ -176,10 +176,11 @@ def cpu_baseline(args, weights):
     return out
 
 
-def counters_from_profiles(precision, src_hash):
+def counters_from_profiles(precision, src_hash, sub_batch):
     """HBM bytes per conv launch and counter-based MFMA utilisation from the committed rocprofv3 --pmc
     passes (profiles/<tag>_summary.json, tools/summarize_profile.py; PMC collection cannot run inside the
-    bench itself).  A summary is quoted only if it was taken with THESE kernel sources (source_hash)."""
+    bench itself).  A summary is quoted only if it was taken with THESE kernel sources (source_hash) and with launches
+    of the same size (one sub-batch stream of `sub_batch` images: the command the summary records)."""
     if precision != 'f16x3':      # the committed PMC passes are of the default configuration only
         return None
     want = 'conv_dma_f16'
@@ -187,6 +188,8 @@ def counters_from_profiles(precision, src_hash):
         try:
             d = json.load(open(path))
         except Exception:
+            continue
+        if '--ways 1 --batch %d ' % sub_batch not in (d.get('command') or '') + ' ':
             continue
         if d.get('source_hash') != src_hash:
             continue
@@ -390,8 +393,8 @@ def main():
             ach = conv_flops / (conv_ms * 1e-3) / 1e12
             kname = 'conv_mfma_f32_kernel' if args.precision == 'f32' else 'conv_dma_f16_kernel (+conv_mfma_f16_kernel for the 5 small/strided convs)'
             src = kernel_source_hash()
-            default_cfg = args.workload == 'lighthead' and sb == 64 and args.proposals == 300
-            ctr = counters_from_profiles(args.precision, src) if default_cfg else None
+            default_cfg = args.workload == 'lighthead' and args.proposals == 300
+            ctr = counters_from_profiles(args.precision, src, sb) if default_cfg else None
             roof = {'bound': 'mfma', 'kernel': kname, 'achieved': round(ach, 2),
                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                     'mfma_issued_tflops': round(issued_flops / (conv_ms * 1e-3) / 1e12, 2),

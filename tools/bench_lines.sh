@@ -10,7 +10,8 @@ mkdir -p $OUT
 cd $REPO
 B="python bench.py --no-cpu-baseline"
 $B --ops > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench_ops.txt
-$B --no-parity --ways 1 --batch 64 > $OUT/${TAG}_bench_1way_b64.json 2>/dev/null
+$B --no-parity --ways 1 --batch 128 > $OUT/${TAG}_bench_1way_b128.json 2>/dev/null
+$B --no-parity --batch 128 > $OUT/${TAG}_bench_2x64.json 2>/dev/null
 $B --no-parity --batch 1 --steps 200 --warmup 20 > $OUT/${TAG}_bench_b1.json 2>/dev/null
 $B --no-parity --batch 8 --ways 1 --steps 100 --warmup 20 > $OUT/${TAG}_bench_b8.json 2>/dev/null
 $B --no-parity --workload resnet50 --batch 8 --steps 100 --warmup 20 > $OUT/${TAG}_bench_resnet50_b8.json 2>/dev/null
