@@ -271,11 +271,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
 // Small-M variant (single images and small batches: a 900-row layer is 8 x 12 workgroups of 128 x 64).  With that few
 // workgroups nothing hides a K step's latency but the step pipeline itself, and the two-stage loop above spends ~1.1 us
 // per 32-deep step (DMA issue -> landed -> barrier -> fragments -> 12 MFMAs) for 0.19 us of matrix work.  Here the
-// operand ring has FOUR stages and three K steps are in flight: the barrier of step kt waits with vmcnt(2 steps' worth)
-// for stage kt only, so a step costs its own issue + fragment reads + MFMAs.  The fragment reads are inline asm: the
-// compiler would put a full vmcnt(0) in front of every LDS read while LDS-DMA writes are outstanding.  Every step
-// issues the same six DMA instructions (steps past the end fetch the zero page into a stage nobody reads) so that the
-// vmcnt arithmetic is static.  Same K order, same product order: bit-identical to conv_dma_f16_kernel.
+// operand ring has SIX stages, a barrier covers a PAIR of K steps and two more pairs are in flight: the barrier waits with
+// vmcnt(one pair's worth) for the pair it is about to read only, so a step costs its own issue + fragment reads + MFMAs
+// and half a barrier.  The fragment reads are inline asm: the compiler would put a full vmcnt(0) in front of every LDS
+// read while LDS-DMA writes are outstanding.  Every pair issues the same twelve DMA instructions (steps past the end
+// fetch the zero page: zero operands add nothing) so that the vmcnt arithmetic is static.  Same K order, same product
+// order: bit-identical to conv_dma_f16_kernel.  Batch-1 latency 1.90 -> 1.74 ms (four stages, one step per barrier)
+// -> 1.70 ms.
 // ---------------------------------------------------------------------------------------
 template <int OFF>
 __device__ __forceinline__ f16x8 cd_ds_read_b128(unsigned addr) {
@@ -286,7 +288,9 @@ __device__ __forceinline__ f16x8 cd_ds_read_b128(unsigned addr) {
 
 template <int NSPLIT>
 __global__ __launch_bounds__(256) void conv_dma_deep_kernel(ConvParams p_in) {
-  constexpr int BM = 128, BN = 64, NW = 4, NSTAGE = 4;
+  constexpr int BM = 128, BN = 64, NW = 4;
+  constexpr int PAIR = 2;                          // K steps per barrier
+  constexpr int NSTAGE = 3 * PAIR;                 // ring: the pair being read + two pairs in flight
   constexpr int TN = 2;                            // wave tile 32 x 64
   constexpr int A_IT = BM / (16 * NW), B_IT = BN / (16 * NW);
   constexpr int ROWB = 32;
@@ -401,44 +405,53 @@ __global__ __launch_bounds__(256) void conv_dma_deep_kernel(ConvParams p_in) {
     }
   }
 
-  issue(0, 0);
-  issue(1, 1);
-  issue(2, 2);
-  for (int kt = 0; kt < nk; ++kt) {
-    // stage kt has landed (the two younger steps may still be in flight) and every wave is done with stage kt-1
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * PIECES) : "memory");
-    issue(kt + 3, (kt + 3) & 3);
+#pragma unroll
+  for (int q = 0; q < 2 * PAIR; ++q) issue(q, q);
+  int ring = 0;                                    // ring ring of the pair's first stage
+  for (int kt = 0; kt < nk; kt += PAIR) {
+    // this pair of stages has landed (the two younger pairs may still be in flight) and every wave is done with the
+    // pair before it, whose rings the new DMA overwrites
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PAIR * PIECES) : "memory");
+    {
+      const int ns = ring + 2 * PAIR >= NSTAGE ? ring + 2 * PAIR - NSTAGE : ring + 2 * PAIR;
+#pragma unroll
+      for (int q = 0; q < PAIR; ++q) issue(kt + 2 * PAIR + q, ns + q);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    const unsigned sb = lds0 + (unsigned)((kt & 3) * STAGE * 2);
-    f16x8 ah[2], al[2], bh[2][TN], bl[2][TN];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      ah[ks] = cd_ds_read_b128<0>(sb + a_off[ks]);
-      if (NSPLIT > 1) al[ks] = cd_ds_read_b128<BM * ROWB * 2>(sb + a_off[ks]);
+    for (int q = 0; q < PAIR; ++q) {
+      const unsigned sb = lds0 + (unsigned)((ring + q) * STAGE * 2);
+      f16x8 ah[2], al[2], bh[2][TN], bl[2][TN];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bh[ks][j] = cd_ds_read_b128<0>(sb + b_off[ks][j]);
-        if (NSPLIT > 1) bl[ks][j] = cd_ds_read_b128<BN * ROWB * 2>(sb + b_off[ks][j]);
+      for (int ks = 0; ks < 2; ++ks) {
+        ah[ks] = cd_ds_read_b128<0>(sb + a_off[ks]);
+        if (NSPLIT > 1) al[ks] = cd_ds_read_b128<BM * ROWB * 2>(sb + a_off[ks]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          bh[ks][j] = cd_ds_read_b128<0>(sb + b_off[ks][j]);
+          if (NSPLIT > 1) bl[ks][j] = cd_ds_read_b128<BN * ROWB * 2>(sb + b_off[ks][j]);
+        }
+      }
+      if (NSPLIT > 1)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ah[0]), "+v"(ah[1]), "+v"(al[0]), "+v"(al[1]), "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]),
+                       "+v"(bh[1][1]), "+v"(bl[0][0]), "+v"(bl[0][1]), "+v"(bl[1][0]), "+v"(bl[1][1])::"memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ah[0]), "+v"(ah[1]), "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]), "+v"(bh[1][1])::"memory");
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (NSPLIT > 1) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh[ks][j], acc[0][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl[ks][j], acc[0][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[ks][j], acc[0][j], 0, 0, 0);
       }
     }
-    if (NSPLIT > 1)
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(ah[0]), "+v"(ah[1]), "+v"(al[0]), "+v"(al[1]), "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]),
-                     "+v"(bh[1][1]), "+v"(bl[0][0]), "+v"(bl[0][1]), "+v"(bl[1][0]), "+v"(bl[1][1])::"memory");
-    else
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(ah[0]), "+v"(ah[1]), "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]), "+v"(bh[1][1])::"memory");
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if (NSPLIT > 1) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh[ks][j], acc[0][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl[ks][j], acc[0][j], 0, 0, 0);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[ks][j], acc[0][j], 0, 0, 0);
-    }
+    ring = ring + PAIR >= NSTAGE ? ring + PAIR - NSTAGE : ring + PAIR;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy tail steps write LDS too
   conv_epilogue<32, 64, 1, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wave, 0, m0, n0);
@@ -446,7 +459,7 @@ __global__ __launch_bounds__(256) void conv_dma_deep_kernel(ConvParams p_in) {
 
 template <int NSPLIT>
 static int launch_deep(const ConvParams& p, hipStream_t s) {
-  constexpr size_t lds = (size_t)4 * (2 * 128 + 2 * 64) * 32 * sizeof(u16);
+  constexpr size_t lds = (size_t)6 * (2 * 128 + 2 * 64) * 32 * sizeof(u16);
   auto kern = conv_dma_deep_kernel<NSPLIT>;
   static DeviceOnce once;
   XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
@@ -504,7 +517,7 @@ int launch_conv_mfma_dma(const ConvParams& p, int n_tile, int nsplit, hipStream_
     // the N tile to double the workgroup count -- per-element K order is unchanged, so results stay bit-identical
     const int64_t b128 = cdiv(p.M, 128) * (p.Cout_pad / 128);
     if (nsplit == 3 && b128 < 128 && (!p.group_rows || p.group_rows % 128 == 0)) {
-      // few workgroups: the four-stage ring (XDET_CONV_SMALL=2stage: the two-stage kernel, for A/B runs)
+      // few workgroups: the deep operand ring (XDET_CONV_SMALL=2stage: the two-stage kernel, for A/B runs)
       static const bool two_stage = getenv("XDET_CONV_SMALL") && !strcmp(getenv("XDET_CONV_SMALL"), "2stage");
       return two_stage ? launch_d<128, 64, 4, 1, 3>(p, s) : launch_deep<3>(p, s);
     }
