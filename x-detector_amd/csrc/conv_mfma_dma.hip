@@ -516,7 +516,7 @@ int launch_conv_mfma_dma(const ConvParams& p, int n_tile, int nsplit, hipStream_
     // small batches: 128 x 128 tiles leave most of the 256 CUs idle (a 900-row layer is 8 x 4..6 workgroups); halve
     // the N tile to double the workgroup count -- per-element K order is unchanged, so results stay bit-identical
     const int64_t b128 = cdiv(p.M, 128) * (p.Cout_pad / 128);
-    if (nsplit == 3 && b128 < 128 && (!p.group_rows || p.group_rows % 128 == 0)) {
+    if (nsplit == 3 && b128 <= 128 && (!p.group_rows || p.group_rows % 128 == 0)) {
       // few workgroups: the deep operand ring (XDET_CONV_SMALL=2stage: the two-stage kernel, for A/B runs)
       static const bool two_stage = getenv("XDET_CONV_SMALL") && !strcmp(getenv("XDET_CONV_SMALL"), "2stage");
       return two_stage ? launch_d<128, 64, 4, 1, 3>(p, s) : launch_deep<3>(p, s);
