@@ -59,6 +59,9 @@ def parse():
                     help='the batch runs as this many concurrent sub-batches (net instances on their own HIP '
                          'streams): the partial last round of one launch is filled by the other stream')
     ap.add_argument('--workload', default='lighthead', choices=['lighthead', 'resnet50'])
+    ap.add_argument('--image-size', type=int, default=480,
+                    help='network input size: 480 (the metric) or 800 (BASELINE config 5 shape; implies --no-parity '
+                         '--no-cpu-baseline, whose legs are 480x480)')
     ap.add_argument('--proposals', type=int, default=300, help='rpn_post_nms_top_n (BASELINE config 3: 300)')
     ap.add_argument('--precision', default='f16x3', choices=['f32', 'f16x3', 'f16'],
                     help='conv/dense arithmetic: exact f32 MFMA, split-precision f16 MFMA (~f32 accuracy), plain f16')
@@ -259,6 +262,9 @@ def main():
     comm = xdist.Communicator(rank, world) if use_comm else None
 
     B, K, Wm = args.batch, args.steps, args.warmup
+    S = args.image_size
+    if S != 480:
+        args.no_parity = args.no_cpu_baseline = True
     gathered = None
     if args.workload == 'lighthead':
         from xdet.model import LightHeadDetector
@@ -267,7 +273,7 @@ def main():
         if B % ways:
             raise SystemExit('--batch must be a multiple of --ways')
         sb = B // ways                               # images per sub-batch / net instance
-        nets = [LightHeadDetector(weights, image_size=480, max_batch=sb, rpn_post_nms_top_n=args.proposals,
+        nets = [LightHeadDetector(weights, image_size=S, max_batch=sb, rpn_post_nms_top_n=args.proposals,
                                   rpn_stream='main' if args.serial_rpn else 'side', conv3x3=args.conv3x3,
                                   pool=args.pool)
                 for _ in range(ways)]
@@ -275,7 +281,7 @@ def main():
         kind = 0
         fl = net.flops_per_image()
         flops_img = sum(fl.values())
-        imgs = W.synthetic_images(B, 480, seed=100 + rank)
+        imgs = W.synthetic_images(B, S, seed=100 + rank)
         for i, nt in enumerate(nets):
             nt.set_images(imgs[i * sb:(i + 1) * sb])
         raw = None
@@ -306,7 +312,7 @@ def main():
                 for nt in nets:
                     for j in range(sb):
                         buf, h, w = raw[j % len(raw)]
-                        check(lib().xdet_preprocess_eval(buf.ptr, h, w, nt._images.ptr + j * 3 * 480 * 480 * 4, 480,
+                        check(lib().xdet_preprocess_eval(buf.ptr, h, w, nt._images.ptr + j * 3 * S * S * 4, S,
                                                          nt.stream.handle))
             if comm is None:
                 for nt in nets:
@@ -419,18 +425,18 @@ def main():
                              'duration would include the other stream\'s kernels); frac_whole_step is the '
                              'un-instrumented figure of the timed region itself' % ways))}
         out = {
-            'metric': 'images/sec at 480x480 Light-Head R-CNN, 1/2/4/8 MI355X + backbone MFMA util%',
+            'metric': 'images/sec at %dx%d Light-Head R-CNN, 1/2/4/8 MI355X + backbone MFMA util%%' % (S, S),
             'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': K, 'warmup': Wm,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'f32': 'f32', 'f16x3': 'f16x3 (split-precision f16 MFMA, f32 accumulate, f32 activations)',
                       'f16': 'f16'}[args.precision], 'data': 'synthetic',
             'config': {'workload': ('Full Light-Head R-CNN (Xception backbone + RPN + GPU proposals/NMS + PSROIAlign + '
-                                    'light head + per-class NMS), %d proposals, 480x480' % args.proposals)
+                                    'light head + per-class NMS), %d proposals, %dx%d' % (args.proposals, S, S))
                        if args.workload == 'lighthead' else 'ResNet-50 v2 trunk only (BASELINE config 2), 480x480',
-                       'batch_per_gpu': B, 'global_batch': B * world, 'image_size': 480,
+                       'batch_per_gpu': B, 'global_batch': B * world, 'image_size': S,
                        'concurrent_sub_batches': ways,
                        'input': ('uint8 VOC-shape stream + F1 pre-processing kernel in the step' if args.voc_stream
-                                 else 'whitened f32 [B,3,480,480] resident in HBM'),
+                                 else 'whitened f32 [B,3,%d,%d] resident in HBM' % (S, S)),
                        'parallelism': 'image-sharded dp%d%s' % (world, ', RCCL all-gather of detections per step '
                                                                 '(C-ABI, overlapped with the next forward)'
                                                                 if comm is not None else ''),

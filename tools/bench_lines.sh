@@ -19,6 +19,7 @@ $B --no-parity --workload resnet50 --batch 32 --steps 50 --warmup 10 > $OUT/${TA
 $B --no-parity --voc-stream > $OUT/${TAG}_bench_voc_stream.json 2>/dev/null
 $B --no-parity --comm > $OUT/${TAG}_bench_comm_world1.json 2>/dev/null
 $B --no-parity --precision f32 --batch 32 --ways 1 > $OUT/${TAG}_bench_f32_b32.json 2>/dev/null
+$B --image-size 800 --batch 96 > $OUT/${TAG}_bench_800x800.json 2>/dev/null
 for f in $OUT/${TAG}_bench*.json; do python - "$f" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
