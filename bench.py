@@ -47,6 +47,9 @@ import numpy as np   # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense f16/bf16 MFMA (no sparsity)
 PEAK_HBM_GBS = 8000.0
+# SURVEY.md 8d "Bytes (minimum, each tensor once)": activations sum(in+out) per layer (136.4 + 1.7 + 5.9) M elements x 4 B,
+# PSROIAlign 1.76 + 1.2 MB, detections 80 KB; weights (44.7 M x 4 B) are amortised over the batch
+HBM_MIN_BYTES_PER_IMAGE = (136.4e6 + 1.7e6 + 5.9e6) * 4 + 1.76e6 + 1.2e6 + 80e3
 
 
 def parse():
@@ -206,8 +209,17 @@ def counters_from_profiles(precision, src_hash, sub_batch):
                 busy += e['mfma_busy_cycles']
                 act += e['gui_active_cycles']
         if cnt:
+            per_img = d.get('hbm_bytes_per_image')
+            if per_img is None:
+                # summaries written before the field existed: the stats run's step count is in the recorded command
+                import re
+                m_s, m_w = re.search(r'--steps (\d+)', d.get('command', '')), re.search(r'--warmup (\d+)', d.get('command', ''))
+                if m_s and m_w:
+                    allb = sum(e.get('hbm_bytes_per_launch', 0) * e['calls'] for k, e in d['kernels'].items()
+                               if not k.startswith('__amd_rocclr'))
+                    per_img = int(allb / (int(m_s.group(1)) + int(m_w.group(1))) / sub_batch)
             return {'traffic': int(tot / cnt), 'mfma_busy_frac': round(busy / (act / 8.0 * 1024.0), 4) if act else None,
-                    'file': os.path.relpath(path, ROOT)}
+                    'hbm_bytes_per_image': per_img, 'file': os.path.relpath(path, ROOT)}
     return None
 
 
@@ -246,6 +258,15 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch N ranks with --gpus N)' % (args.gpus, world))
+    numa_cpus = None
+    if 'RANK' in os.environ:
+        # a rank of a multi-process job (xdet.launch or torch.distributed.run): RCCL's warnings go to stderr (stdout
+        # carries the JSON line), and the process is bound to the CPUs of its GPU's NUMA node
+        os.environ.setdefault('NCCL_DEBUG', 'WARN')
+        os.environ.setdefault('NCCL_DEBUG_FILE', '/dev/stderr')
+        if os.environ.get('XDET_BIND_NUMA', '1') != '0':
+            from xdet.launch import bind_to_gpu_numa
+            numa_cpus = bind_to_gpu_numa(local_rank)
 
     from xdet import weights as W
     from xdet import dist as xdist
@@ -381,7 +402,12 @@ def main():
         rows = read_profile(net.handle, kind)
         check(lib().xdet_profile_enable(net.handle, kind, 0))
 
+    dev_records = None
     if comm is not None:
+        # every rank's (rank, hip device, PCI bus id, host, its own images/s) through ncclAllGather: the line then
+        # proves how many DISTINCT GPUs took part, and shows the per-rank rates behind the max-over-ranks value
+        dev_records = comm.device_records({'images_per_sec': round(B * K / dt, 1), 'ms_per_step': round(dt / K * 1e3, 3),
+                                           'numa_cpus': len(numa_cpus) if numa_cpus else None})
         dt = comm.max_over_ranks(dt)
 
     if rank == 0:
@@ -401,8 +427,23 @@ def main():
             src = kernel_source_hash()
             default_cfg = args.workload == 'lighthead' and args.proposals == 300
             ctr = counters_from_profiles(args.precision, src, sb) if default_cfg else None
+            # frac counts SURVEY 8d's algorithmic FLOPs (the direct-form count also for the two large-separable convs,
+            # which run in the DFT domain and execute ~5x fewer).  The kernel-quality views next to it:
+            #   frac_executed    = FLOPs actually executed / products per term (i.e. the algorithmic FLOPs of the form
+            #                      that ran) over the same conv time -- no spectral credit;
+            #   frac_direct_only = the directly computed contractions alone: their FLOPs over their own time.
+            spec_rows = [r for r in rows if r[3] > 0 and r[4] > 0 and abs(r[4] - nprod * r[3]) > 1e-6 * r[3]]
+            prefixes = [r[0].split(' [')[0] for r in spec_rows]       # their DFT passes carry the same name prefix
+            d_rows = [r for r in rows if r[3] > 0 and not any(r[0].startswith(q) for q in prefixes)]
+            d_ms = sum(r[1] for r in d_rows)
+            d_fl = sum(r[3] * r[2] for r in d_rows) * sb
             roof = {'bound': 'mfma', 'kernel': kname, 'achieved': round(ach, 2),
                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                    'frac_executed': round(issued_flops / nprod / (conv_ms * 1e-3) / 1e12 / peak, 4),
+                    'frac_direct_only': round(d_fl / (d_ms * 1e-3) / 1e12 / peak, 4) if d_ms > 0 else None,
+                    'frac_cap': round(1.0 / nprod, 4),
+                    'frac_note': ('%d MFMA products per term cap frac at %.3f; spectral ops credited with their direct-form '
+                                  'FLOPs in frac, not in frac_executed' % (nprod, 1.0 / nprod)),
                     'mfma_issued_tflops': round(issued_flops / (conv_ms * 1e-3) / 1e12, 2),
                     'mfma_util': round(issued_flops / (conv_ms * 1e-3) / 1e12 / peak, 4),
                     'mfma_util_how': 'FLOPs executed on the matrix cores (%d products per term; the spectral GEMMs execute '
@@ -412,6 +453,10 @@ def main():
                     'traffic_unit': ('HBM bytes per conv launch (PMC FETCH_SIZE x2 + WRITE_SIZE), from %s, same kernel '
                                      'sources (%s)' % (ctr['file'], src)) if ctr
                     else 'no PMC pass committed for these kernel sources (%s) / this configuration' % src,
+                    'hbm_bytes_per_image': ctr['hbm_bytes_per_image'] if ctr else None,
+                    'hbm_min_bytes_per_image': int(HBM_MIN_BYTES_PER_IMAGE + 44.7e6 * 4 / sb) if args.workload == 'lighthead' and S == 480 else None,
+                    'hbm_over_min': (round(ctr['hbm_bytes_per_image'] / (HBM_MIN_BYTES_PER_IMAGE + 44.7e6 * 4 / sb), 3)
+                                     if ctr and ctr.get('hbm_bytes_per_image') and args.workload == 'lighthead' and S == 480 else None),
                     'launches_per_step': conv_launches // K,
                     'avg_launch_us': round(conv_ms * 1e3 / max(conv_launches, 1), 2),
                     'kernel_ms_per_step': round(conv_ms / K, 3), 'gflop_per_image': round(flops_img / 1e9, 2),
@@ -451,6 +496,11 @@ def main():
             info = comm.info()
             out['comm'] = {'transport': 'RCCL %d via libxdet_hip.so (xdet_comm_*), no torch' % info['rccl_version'],
                            'world': info['world'],
+                           # gathered through ncclAllGather: one record per rank
+                           'devices': dev_records,
+                           'ranks_seen': sorted(r['rank'] for r in dev_records) if dev_records else None,
+                           'distinct_gpus': len({(r['host'], r['pci_bus_id']) for r in dev_records}) if dev_records else None,
+                           'per_rank_images_per_sec': [r.get('images_per_sec') for r in dev_records] if dev_records else None,
                            'gathered_shape': list(gathered.shape) if gathered is not None else None,
                            'gathered_images_with_detections': int((gathered[..., 0].reshape(gathered.shape[0], -1) > 0)
                                                                   .any(1).sum()) if gathered is not None else None}

@@ -33,6 +33,14 @@ const char* xdet_last_error(void);
 int xdet_version(void);
 int xdet_device_count(int* n);
 int xdet_set_device(int dev);
+/* "0000:c1:00.0"-style PCI bus id of HIP device `dev` (what identifies a physical GPU across ranks: the launcher
+ * binds a rank to the NUMA node of its GPU with it, bench.py gathers it from every rank); buflen >= 16 */
+int xdet_device_pci_bus_id(int dev, char* buf, int buflen);
+/* hipMalloc + hipIpcGetMemHandle + hipFree on the current device: 0 if this process can export device memory to a
+ * peer process (what RCCL's intra-node transport needs), XDET_ERR_HIP otherwise.  Whether it works depends on
+ * HSA_ENABLE_IPC_MODE_LEGACY, which the HSA runtime reads when it starts -- so xdet.launch runs this in a fresh
+ * probe process before it decides what to export to the ranks. */
+int xdet_probe_ipc(void);
 /* Arithmetic of the conv / dense contractions for layers and nets created AFTER the call:
  *   0 = f32 MFMA (v_mfma_f32_32x32x2_f32, exact f32 FMA chains; default)
  *   1 = f16x3: operands split into f16 hi+lo parts, three v_mfma_f32_32x32x16_f16 per product
@@ -283,7 +291,15 @@ int xdet_resnet_destroy(void* net);
  *   the producers then only wait for the PREVIOUS call's pack (the one that read the pair they write
  *   next), which removes the once-per-step join of the producer streams.
  * xdet_comm_wait: stream != NULL -> that stream waits for the last gather; NULL -> the host does.
- * xdet_comm_allreduce_max / xdet_comm_barrier: scalar collectives for bench timing (host-synchronous). */
+ * xdet_comm_allreduce_max / xdet_comm_barrier: scalar collectives for bench timing (host-synchronous).
+ * xdet_comm_allgather_bytes: `bytes` (<= 1 MiB) of host memory from every rank -> world * bytes in rank order,
+ *   moved by ncclAllGather on the communicator's stream (rank / device / PCI-bus-id records, per-rank rates).
+ * Watchdog: every HOST wait on the communicator's stream (comm_wait(NULL), the scalar collectives, allgather_bytes,
+ *   destroy) polls instead of blocking; when RCCL reports an asynchronous error or nothing completes for the
+ *   timeout (XDET_COMM_TIMEOUT_S or xdet_comm_set_timeout, default 300 s) the communicator is aborted
+ *   (ncclCommAbort) and the call returns XDET_ERR_STATE, as does every later call -- a rank whose peer died exits
+ *   with an error instead of hanging in hipStreamSynchronize.
+ * Rank 0 removes a stale id file before it creates the id and removes its own once ncclCommInitRank has returned. */
 int xdet_comm_init(void** comm, int rank, int world, const char* unique_id_path, int timeout_s);
 int xdet_comm_destroy(void* comm);
 int xdet_comm_info(void* comm, int* rank, int* world, int* device, int* rccl_version);
@@ -294,6 +310,8 @@ int xdet_comm_allgather_detections(void* comm, const float* det_scores, const fl
 int xdet_comm_wait(void* comm, void* stream);
 int xdet_comm_allreduce_max(void* comm, double* value_host);
 int xdet_comm_barrier(void* comm);
+int xdet_comm_allgather_bytes(void* comm, const void* send_host, void* recv_host, size_t bytes);
+int xdet_comm_set_timeout(void* comm, double seconds);
 
 #ifdef __cplusplus
 }

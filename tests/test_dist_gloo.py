@@ -150,3 +150,115 @@ def test_no_torch_in_the_product_or_the_bench():
     for f in files:
         src = open(f).read()
         assert not re.search(r'^\s*(import|from)\s+torch\b', src, flags=re.M), f
+
+
+# ---- hardening of the N-rank path (round 3): none of it needs a GPU ------------------------------
+def _gone(pid, timeout=10.0):
+    import time
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        try:
+            os.kill(pid, 0)
+        except OSError:
+            return True
+        time.sleep(0.05)
+    return False
+
+
+def test_launcher_returns_promptly_when_a_rank_is_killed_mid_run(tmp_path):
+    """rank 1 dies by SIGKILL while rank 0 sits in a (simulated) collective that would never finish: the launcher
+    must come back with a failure well inside the timeout and leave no rank behind."""
+    import signal
+    import time
+    from xdet.launch import launch_ranks
+    script = tmp_path / 'rank.py'
+    script.write_text(
+        'import os, signal, sys, time\n'
+        'r = os.environ["RANK"]\n'
+        'open(os.path.join(%r, "pid_" + r), "w").write(str(os.getpid()))\n'
+        'if r == "1":\n'
+        '    time.sleep(0.5)\n'
+        '    os.kill(os.getpid(), signal.SIGKILL)\n'
+        'signal.signal(signal.SIGTERM, signal.SIG_IGN)   # a rank stuck in a collective does not react to SIGTERM\n'
+        'time.sleep(600)\n' % str(tmp_path))
+    t0 = time.time()
+    rc = launch_ranks([sys.executable, str(script)], 2, timeout=120)
+    dt = time.time() - t0
+    assert rc == -signal.SIGKILL
+    assert dt < 30, dt                       # SIGTERM grace (10 s) + SIGKILL, not the 120 s timeout
+    assert _gone(int(open(tmp_path / 'pid_0').read()))     # rank 0 is gone too
+
+
+def test_launcher_kills_its_ranks_when_it_is_interrupted(tmp_path):
+    """an exception inside the poll loop (KeyboardInterrupt) must not leave ranks holding GPUs."""
+    from xdet import launch
+    script = tmp_path / 'rank.py'
+    script.write_text('import os, time\n'
+                      'open(os.path.join(%r, "pid_" + os.environ["RANK"]), "w").write(str(os.getpid()))\n'
+                      'time.sleep(600)\n' % str(tmp_path))
+    real_sleep = launch.time.sleep
+    calls = {'n': 0}
+
+    def sleep(t):
+        calls['n'] += 1
+        if calls['n'] > 20 and not calls.get('raised') and all(os.path.exists(tmp_path / ('pid_%d' % r)) for r in range(2)):
+            calls['raised'] = True           # once: Popen.wait(timeout) inside the cleanup sleeps through time.sleep too
+            raise KeyboardInterrupt
+        real_sleep(t)
+    launch.time.sleep = sleep
+    try:
+        with pytest.raises(KeyboardInterrupt):
+            launch.launch_ranks([sys.executable, str(script)], 2, ipc={})
+    finally:
+        launch.time.sleep = real_sleep
+    for r in range(2):
+        assert _gone(int(open(tmp_path / ('pid_%d' % r)).read()))
+
+
+def test_rank_env_defaults(monkeypatch):
+    from xdet.launch import rank_env
+    monkeypatch.delenv('NCCL_DEBUG', raising=False)
+    monkeypatch.delenv('NCCL_DEBUG_FILE', raising=False)
+    env = rank_env(2, 4, '/tmp/idf', base={'PATH': '/bin'}, ipc={})
+    assert env['RANK'] == '2' and env['LOCAL_RANK'] == '2' and env['WORLD_SIZE'] == '4'
+    assert env['XDET_COMM_ID_FILE'] == '/tmp/idf'
+    assert env['NCCL_DEBUG'] == 'WARN' and env['NCCL_DEBUG_FILE'] == '/dev/stderr'   # RCCL warnings -> stderr, per rank
+    assert env['XDET_BIND_NUMA'] == '1'
+    assert 'HSA_ENABLE_IPC_MODE_LEGACY' not in env                                    # nothing forced
+    env = rank_env(0, 2, '/x', base={'NCCL_DEBUG': 'INFO'}, ipc={'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
+    assert env['NCCL_DEBUG'] == 'INFO' and env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_ipc_mode_is_set_only_when_the_probe_says_the_default_fails(monkeypatch):
+    from xdet import launch
+    monkeypatch.delenv('HSA_ENABLE_IPC_MODE_LEGACY', raising=False)
+    monkeypatch.delenv('XDET_IPC_PROBE', raising=False)
+    seen = []
+
+    def probe_factory(default_ok, dmabuf_ok):
+        def probe(extra):
+            seen.append(dict(extra))
+            return dmabuf_ok if extra.get('HSA_ENABLE_IPC_MODE_LEGACY') == '0' else default_ok
+        return probe
+    assert launch.ipc_env(probe_factory(True, True)) == {}                                   # default works: untouched
+    assert launch.ipc_env(probe_factory(False, True)) == {'HSA_ENABLE_IPC_MODE_LEGACY': '0'}
+    assert launch.ipc_env(probe_factory(False, False)) == {}                                 # nothing works: do not guess
+    assert launch.ipc_env(probe_factory(None, True)) == {}                                   # probe could not run (no GPU)
+    monkeypatch.setenv('HSA_ENABLE_IPC_MODE_LEGACY', '1')
+    n = len(seen)
+    assert launch.ipc_env(probe_factory(False, True)) == {'HSA_ENABLE_IPC_MODE_LEGACY': '1'}  # the caller's word wins
+    assert len(seen) == n                                                                     # ... without probing
+
+
+def test_numa_cpus_of_a_pci_device(tmp_path):
+    from xdet.launch import numa_cpus_of_pci
+    dev = tmp_path / 'bus/pci/devices/0000:c1:00.0'
+    dev.mkdir(parents=True)
+    (dev / 'numa_node').write_text('1\n')
+    node = tmp_path / 'devices/system/node/node1'
+    node.mkdir(parents=True)
+    (node / 'cpulist').write_text('64-67,192-193\n')
+    assert numa_cpus_of_pci('0000:C1:00.0', str(tmp_path)) == {64, 65, 66, 67, 192, 193}
+    (dev / 'numa_node').write_text('-1\n')
+    assert numa_cpus_of_pci('0000:c1:00.0', str(tmp_path)) is None          # single-node box: leave the affinity alone
+    assert numa_cpus_of_pci('0000:ff:00.0', str(tmp_path)) is None

@@ -136,3 +136,59 @@ def test_layers_remember_their_device():
     rois = np.array([[[0.2, 0.2, 0.7, 0.7]]], np.float32)
     p, _ = xdet.ps_roi_align(inp, rois, 2, 2, 'mean')
     assert np.allclose(p[0, 0, :, 0], [5.125, 6.5, 12., 13.375])
+
+
+def test_byte_allgather_and_device_records():
+    """bench.py's comm.devices: every rank's (rank, hip device, PCI bus id, host) moved by ncclAllGather."""
+    import re
+    from xdet import dist as xd
+    comm = xd.Communicator(0, 1)
+    comm.set_timeout(60)
+    got = comm.allgather_bytes(b'0123456789abcdef' * 4)
+    assert got == [b'0123456789abcdef' * 4]
+    recs = comm.device_records({'images_per_sec': 12.5})
+    assert len(recs) == 1 and recs[0]['rank'] == 0 and recs[0]['hip_device'] == 0 and recs[0]['images_per_sec'] == 12.5
+    assert re.match(r'^[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9]$', recs[0]['pci_bus_id']), recs[0]
+    comm.close()
+
+
+def test_ipc_probe_and_numa_binding():
+    """what xdet.launch decides per launch: the IPC probe runs (this image exports HSA_ENABLE_IPC_MODE_LEGACY=0, under
+    which exporting a device allocation must work), and binding to the GPU's NUMA node leaves a non-empty CPU set."""
+    import os
+    from xdet._lib import lib
+    from xdet import launch
+    assert lib().xdet_probe_ipc() == 0
+    before = os.sched_getaffinity(0)
+    try:
+        cpus = launch.bind_to_gpu_numa(0)
+        assert cpus is None or (len(cpus) > 0 and cpus <= before)
+        assert len(os.sched_getaffinity(0)) > 0
+    finally:
+        os.sched_setaffinity(0, before)
+
+
+def test_bench_through_the_rank_launcher(tmp_path):
+    """`python bench.py --gpus 1 --comm` through xdet.launch.launch_ranks (the spawn path `bench.py --gpus N` takes):
+    rank 0 prints exactly one JSON line with the SCALE-ready keys."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import sys; sys.path.insert(0, %r); from xdet.launch import launch_ranks; '
+            'sys.exit(launch_ranks([sys.executable, %r, "--gpus", "1", "--comm", "--steps", "2", "--warmup", "1", '
+            '"--batch", "16", "--no-cpu-baseline", "--no-parity"], 1, timeout=900))'
+            % (os.path.join(root, 'x-detector_amd'), os.path.join(root, 'bench.py')))
+    p = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1000)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['value'] > 0
+    c = d['comm']
+    assert c['world'] == 1 and c['ranks_seen'] == [0] and c['distinct_gpus'] == 1
+    assert c['devices'][0]['pci_bus_id'] and c['per_rank_images_per_sec'][0] > 0
+    assert c['gathered_shape'] == [16, 20, 200, 5] and c['gathered_images_with_detections'] == 16
+    r = d['roofline']
+    assert 0 < r['frac_executed'] <= r['frac'] <= r['frac_cap'] and r['frac_direct_only'] > 0

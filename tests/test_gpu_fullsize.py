@@ -175,3 +175,74 @@ def test_batch_invariance_across_batch_sizes(big, lh_weights, nb):
     det.forward_device(nb, use_graph=True)
     s2, b2 = det.detections(nb)
     assert np.array_equal(s2, s[:nb]) and np.array_equal(b2, b[:nb])
+
+
+def test_the_configuration_the_driver_benches(oracle, lh_weights):
+    """BENCH_rNN's configuration, asserted instead of only timed (BASELINE config 4 at world size 1): 2 concurrent
+    sub-batches x 128 images, f16x3 + spectral, hipGraph replay, input = raw uint8 VOC-shape images through the F1
+    kernel into the nets' input buffers, detections written into one shared pair of buffers per parity, packed and
+    all-gathered by the RCCL communicator with the double-buffered event protocol, no host sync between steps.
+    Checked: the gathered records of >= 3 positions per sub-batch equal single-image nets bit for bit, and two sampled
+    images agree with the oracle (own F1 restatement included) within 1e-3."""
+    from xdet import dist as xd
+    from xdet._lib import lib, check
+    from xdet.model import LightHeadDetector
+    from xdet.runtime import DeviceBuffer, set_precision, to_device
+    SB, WAYS, S = 128, 2, 480
+    Bt = SB * WAYS
+    nc, k = 20, 200
+    shapes = [(375, 500), (500, 375), (333, 500), (500, 333)]
+    rng = np.random.default_rng(77)
+    probes = {0: (0, 61, 127), 1: (0, 5, 127)}              # sub-batch -> positions compared with single-image nets
+    # every image distinct at the probed positions, the rest cycle through a small pool (as bench.py --voc-stream does)
+    pool = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes for _ in range(2)]
+    raw = {}
+    for i in range(WAYS):
+        for j in range(SB):
+            raw[(i, j)] = pool[(i * 3 + j) % len(pool)]
+        for j in probes[i]:
+            h, w = shapes[(i + j) % 4]
+            raw[(i, j)] = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    dev = {id(a): to_device(a) for a in {id(a): a for a in raw.values()}.values()}
+    set_precision('f16x3')
+    try:
+        nets = [LightHeadDetector(lh_weights, image_size=S, max_batch=SB, rpn_post_nms_top_n=300) for _ in range(WAYS)]
+        one = LightHeadDetector(lh_weights, image_size=S, max_batch=1, rpn_post_nms_top_n=300, large_sep='spectral')
+    finally:
+        set_precision('f32')
+    comm = xd.Communicator(0, 1)
+    det = [(DeviceBuffer(Bt * nc * k * 4, zero=True), DeviceBuffer(Bt * nc * k * 16, zero=True)) for _ in range(2)]
+    for step in range(3):                                    # both buffer pairs get used; nothing syncs in between
+        for i, nt in enumerate(nets):
+            for j in range(SB):
+                a = raw[(i, j)]
+                check(lib().xdet_preprocess_eval(dev[id(a)].ptr, a.shape[0], a.shape[1], nt._images.ptr + j * 3 * S * S * 4, S,
+                                                 nt.stream.handle))
+        ds, db = det[step & 1]
+        for i, nt in enumerate(nets):
+            nt.forward_device(SB, use_graph=True, det_scores_ptr=ds.ptr + i * SB * nc * k * 4,
+                              det_boxes_ptr=db.ptr + i * SB * nc * k * 16)
+        comm.allgather_detections(ds.ptr, db.ptr, Bt, nc, k, streams=[nt.stream for nt in nets], double_buffered=True)
+    g = comm.gathered()
+    assert g.shape == (Bt, nc, k, 5)
+    gs, gb = xd.unpack_detections(g)
+    assert np.isfinite(gs).all() and ((gs > 0).reshape(Bt, -1).any(1)).all()     # every image produced detections
+    from xdet.ops import light_head_preprocess_for_test
+    total = matched = extra = 0
+    for i in range(WAYS):
+        for n_, j in enumerate(probes[i]):
+            x = light_head_preprocess_for_test(raw[(i, j)], (S, S), 'NCHW')[None]
+            got = one.forward(x, use_graph=True)
+            pos = i * SB + j
+            for c in range(nc):
+                assert np.array_equal(got[0][c + 1][0], gs[pos, c]), (i, j, c)
+                assert np.array_equal(got[0][c + 1][1], gb[pos, c]), (i, j, c)
+            if n_ == 1:                                      # one image per sub-batch through the oracle (own F1 too)
+                xo = oracle.preprocess_for_eval(raw[(i, j)], S)[None]
+                ref = oracle.lighthead_forward(xo, lh_weights, rpn_post_nms_top_n=300)
+                t, m, e = match_detections({c + 1: (gs[pos, c], gb[pos, c]) for c in range(nc)}, ref[0])
+                total, matched, extra = total + t, matched + m, extra + e
+    print('driver configuration (2 x 128, VOC stream, RCCL world 1): 6 positions bitwise, oracle %d matched %d extra %d'
+          % (total, matched, extra))
+    assert total > 50 and matched == total and extra == 0, (total, matched, extra)
+    comm.close()

@@ -145,3 +145,33 @@ def test_non_finite_head_outputs_are_loud(oracle, lh_weights):
     out = quiet.forward(imgs)
     ref = quiet.forward(W.synthetic_images(2, 256, seed=3))
     assert all(np.array_equal(out[0][c][0], ref[0][c][0]) for c in range(1, 21))
+
+
+def test_overflow_in_the_dft_domain_is_loud(lh_weights):
+    """the spectral large-separable path keeps DFT-domain planes and an un-normalised (15,1) conv
+    output that check_range did not see, and its inverse transform's ReLU turned a NaN bin into 0 -> silent zeros in
+    `feat`.  Now the DFT tensors are part of the validation pass, and the inverse DFT's ReLU propagates NaN so that even
+    WITHOUT check_range the overflow reaches the head logits and the always-on guard.  The (15,1) kernels are scaled so
+    that only the tensors between the two spectral GEMMs leave the f16 range (the backbone output stays O(1))."""
+    from xdet._lib import XdetError
+    from xdet.model import LightHeadDetector
+    from xdet import weights as W
+    from xdet.runtime import set_precision
+    w = dict(lh_weights)
+    for br in ('Branch_0', 'Branch_1'):
+        w['large_sep_feature/%s/conv2d/kernel' % br] = lh_weights['large_sep_feature/%s/conv2d/kernel' % br] * np.float32(2.0 ** 17)
+    imgs = W.synthetic_images(2, 256, seed=3)
+    set_precision('f16x3')
+    try:
+        checked = LightHeadDetector(w, image_size=256, max_batch=2, rpn_post_nms_top_n=50, large_sep='spectral', check_range=True)
+        quiet = LightHeadDetector(w, image_size=256, max_batch=2, rpn_post_nms_top_n=50, large_sep='spectral')
+        fine = LightHeadDetector(lh_weights, image_size=256, max_batch=2, rpn_post_nms_top_n=50, large_sep='spectral',
+                                 check_range=True)
+    finally:
+        set_precision('f32')
+    fine.forward(imgs)                                   # the unscaled net passes the (now wider) validation
+    with pytest.raises(XdetError, match=r'image\(s\) \[0, 1\]'):
+        checked.forward(imgs)
+    with pytest.raises(XdetError, match=r'non-finite'):
+        quiet.forward(imgs)                              # NaN survives the inverse DFT's ReLU and reaches the guard
+    assert not np.isfinite(quiet.buffer('feat', 2).numpy()).all()

@@ -67,8 +67,8 @@ def test_random_bit_exact(method, shape, oracle):
 @pytest.mark.parametrize('shape', [(3, 30, 30, 300, 7, 7), (9, 50, 50, 77, 7, 7), (2, 13, 17, 40, 3, 5), (1, 120, 120, 33, 7, 7)])
 @pytest.mark.parametrize('corners', [0, 1])
 def test_nhwc_bank10_form_bit_exact(method, shape, corners, oracle):
-    """The form the net runs: NHWC map with a padded channel stride, 10 channels per bin (one lane per bin,
-    psroialign_bin_kernel), ROIs as centres or as corners, images spread over the XCD-aware block order -- values and
+    """The form the net runs: NHWC map with a padded channel stride, 10 channels per bin (psroialign_fwd_kernel: one
+    wavefront per ROI, lanes over the output elements), ROIs as centres or as corners, images spread over the XCD-aware block order -- values and
     argmax indices bit for bit against the oracle (which takes NCHW + centres).  120 x 120 maps give bins with more than
     8 sample columns."""
     import ctypes

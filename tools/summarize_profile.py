@@ -95,6 +95,17 @@ def main():
             e['gui_active_cycles'] = ga[k][1] * mf[k][0] / max(ga[k][0], 1)      # same number of launches
             e['mfma_busy_frac'] = round(e['mfma_busy_cycles'] / (e['gui_active_cycles'] / 8.0 * 1024.0), 4)
         summ['kernels'][k] = e
+    # HBM bytes per image of one forward: sum over the net's own kernels (build-time fills / copies excluded) of
+    # bytes per launch (PMC pass) x launches per step (stats run: calls / (steps + warmup)) / images per step
+    import re
+    m_s, m_w, m_b = re.search(r'--steps (\d+)', a.note), re.search(r'--warmup (\d+)', a.note), re.search(r'--batch (\d+)', a.note)
+    if m_s and m_w and m_b and rows:
+        nsteps, nimg = int(m_s.group(1)) + int(m_w.group(1)), int(m_b.group(1))
+        tot = sum(e.get('hbm_bytes_per_launch', 0) * e['calls'] for k, e in summ['kernels'].items()
+                  if not k.startswith('__amd_rocclr'))
+        summ['steps_in_stats_run'] = nsteps
+        summ['images_per_step'] = nimg
+        summ['hbm_bytes_per_image'] = int(tot / nsteps / nimg)
     json.dump(summ, open(os.path.join(out, a.tag + '_summary.json'), 'w'), indent=1, sort_keys=True)
     print(json.dumps(summ, indent=1)[:1500])
 

@@ -49,6 +49,9 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   int (*GetVersion)(int*) = nullptr;
+  // optional (the watchdog degrades to a plain timeout without them)
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
 };
 
 static RcclApi g_rccl;
@@ -84,6 +87,8 @@ static int load_rccl() {
   XDET_SYM(GetErrorString, "ncclGetErrorString")
   XDET_SYM(GetVersion, "ncclGetVersion")
 #undef XDET_SYM
+  *reinterpret_cast<void**>(&a.CommAbort) = dlsym(h, "ncclCommAbort");
+  *reinterpret_cast<void**>(&a.CommGetAsyncError) = dlsym(h, "ncclCommGetAsyncError");
   g_rccl = a;
   return XDET_OK;
 }
@@ -110,8 +115,24 @@ __global__ void pack_detections_kernel(const float* __restrict__ scores, const f
   }
 }
 
+// make the communicator's device current for the call (the caller may have switched devices since init)
+struct CommDeviceGuard {
+  int prev = -1, want = -1;
+  explicit CommDeviceGuard(int dev) : want(dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != want) (void)hipSetDevice(want);
+  }
+  ~CommDeviceGuard() {
+    if (prev >= 0 && prev != want) (void)hipSetDevice(prev);
+  }
+};
+
 struct Comm {
   int rank = 0, world = 1, device = 0;
+  double timeout_s = 300.0;       // watchdog: a host wait on the communicator's stream longer than this is a dead peer
+  bool dead = false;              // set by the watchdog; every later call fails fast
+  char* d_bytes = nullptr;        // device staging of xdet_comm_allgather_bytes
+  size_t d_bytes_cap = 0;
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev_packed[2] = {nullptr, nullptr}, ev_done = nullptr;
@@ -120,7 +141,9 @@ struct Comm {
   int64_t gathers = 0;
 
   ~Comm() {
-    if (comm) (void)g_rccl.CommDestroy(comm);
+    // a communicator the watchdog gave up on is aborted, not destroyed: ncclCommDestroy would wait for the dead peer
+    if (comm) (void)((dead && g_rccl.CommAbort) ? g_rccl.CommAbort(comm) : g_rccl.CommDestroy(comm));
+    if (d_bytes) (void)hipFree(d_bytes);
     for (hipEvent_t e : ev_in) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_packed)
       if (e) (void)hipEventDestroy(e);
@@ -164,6 +187,48 @@ static int read_id_file(const std::string& path, int timeout_s, ncclUniqueId* id
   }
 }
 
+// Host wait for `ev` on the communicator's stream with a watchdog.  hipEventSynchronize / hipStreamSynchronize would
+// block forever when a peer dies inside a collective (its ring neighbour never sends); here the event is polled,
+// RCCL's asynchronous error state is consulted, and after timeout_s the communicator is aborted and the call fails
+// with XDET_ERR_STATE -- the launcher (xdet.launch) then sees a non-zero exit instead of a hung rank.
+static int watchdog_wait(Comm* c, hipEvent_t ev, const char* what) {
+  if (c->dead) {
+    set_last_error(std::string(what) + ": the communicator was aborted by an earlier watchdog timeout");
+    return XDET_ERR_STATE;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  int spins = 0;
+  for (;;) {
+    const hipError_t q = hipEventQuery(ev);
+    if (q == hipSuccess) return XDET_OK;
+    if (q != hipErrorNotReady) return hip_fail(q, "hipEventQuery(comm event)", __FILE__, __LINE__);
+    std::string why;
+    if (g_rccl.CommGetAsyncError && c->comm) {
+      ncclResult_t ar = ncclSuccess;
+      if (g_rccl.CommGetAsyncError(c->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)
+        why = std::string("RCCL reports an asynchronous error (") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(ar) : "?") + ")";
+    }
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (why.empty() && el > c->timeout_s) {
+      char buf[160];
+      snprintf(buf, sizeof(buf), "no progress on the communicator stream for %.0f s (a peer rank died or hangs)", el);
+      why = buf;
+    }
+    if (!why.empty()) {
+      c->dead = true;
+      if (g_rccl.CommAbort && c->comm) {
+        (void)g_rccl.CommAbort(c->comm);
+        c->comm = nullptr;
+      }
+      set_last_error(std::string(what) + ": " + why + "; rank " + std::to_string(c->rank) + " of " + std::to_string(c->world) +
+                     " aborted its communicator");
+      return XDET_ERR_STATE;
+    }
+    if (++spins < 2000) std::this_thread::yield();          // short waits stay cheap
+    else std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+}
+
 }  // namespace xdet
 
 using namespace xdet;
@@ -180,13 +245,22 @@ int xdet_comm_init(void** comm_out, int rank, int world, const char* unique_id_p
   XDET_HIP(hipGetDevice(&c->device));
   ncclUniqueId id;
   memset(&id, 0, sizeof(id));
+  if (const char* t = getenv("XDET_COMM_TIMEOUT_S")) {
+    const double v = atof(t);
+    if (v > 0) c->timeout_s = v;
+  }
   if (rank == 0) {
+    // a file left behind by an earlier launch that resolved to the same name must never be read as this launch's id:
+    // remove it before the new id exists (the launcher additionally hands every launch a fresh directory)
+    if (world > 1) (void)unlink(unique_id_path);
     XDET_RCCL(g_rccl.GetUniqueId(&id));
     if (world > 1) XDET_TRY(write_id_file(unique_id_path, id));
   } else {
     XDET_TRY(read_id_file(unique_id_path, timeout_s > 0 ? timeout_s : 120, &id));
   }
   XDET_RCCL(g_rccl.CommInitRank(&c->comm, world, id, rank));
+  // ncclCommInitRank is collective: every rank has read the id by now, the file has served its purpose
+  if (rank == 0 && world > 1) (void)unlink(unique_id_path);
   XDET_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (hipEvent_t& e : c->ev_packed) {
     XDET_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -202,7 +276,11 @@ int xdet_comm_init(void** comm_out, int rank, int world, const char* unique_id_p
 int xdet_comm_destroy(void* comm) {
   Comm* c = static_cast<Comm*>(comm);
   if (!c) return XDET_OK;
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  CommDeviceGuard guard(c->device);
+  if (c->stream && !c->dead) {
+    // drain under the watchdog: a destroy behind a dead peer must not hang either
+    if (hipEventRecord(c->ev_done, c->stream) == hipSuccess) (void)watchdog_wait(c, c->ev_done, "comm_destroy");
+  }
   delete c;
   return XDET_OK;
 }
@@ -237,6 +315,11 @@ int xdet_comm_allgather_detections(void* comm, const float* det_scores, const fl
   XDET_REQUIRE(c && det_scores && det_boxes && packed_local && gathered, "allgather_detections: NULL argument");
   XDET_REQUIRE(n_images > 0 && n_fg_classes > 0 && topk > 0 && n_producers >= 0, "allgather_detections: bad sizes");
   XDET_REQUIRE(n_producers == 0 || producer_streams, "allgather_detections: producer_streams is NULL");
+  if (c->dead) {
+    set_last_error("allgather_detections: the communicator was aborted by the watchdog");
+    return XDET_ERR_STATE;
+  }
+  CommDeviceGuard dev_guard(c->device);
   while ((int)c->ev_in.size() < n_producers) {
     hipEvent_t e;
     XDET_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -266,18 +349,58 @@ int xdet_comm_allgather_detections(void* comm, const float* det_scores, const fl
 int xdet_comm_wait(void* comm, void* stream) {
   Comm* c = static_cast<Comm*>(comm);
   XDET_REQUIRE(c, "comm is NULL");
+  CommDeviceGuard guard(c->device);
   if (stream) XDET_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), c->ev_done, 0));
-  else XDET_HIP(hipEventSynchronize(c->ev_done));
+  else return watchdog_wait(c, c->ev_done, "comm_wait");
   return XDET_OK;
 }
 
 int xdet_comm_allreduce_max(void* comm, double* value_host) {
   Comm* c = static_cast<Comm*>(comm);
   XDET_REQUIRE(c && value_host, "allreduce_max: NULL argument");
+  if (c->dead) {
+    set_last_error("allreduce_max: the communicator was aborted by the watchdog");
+    return XDET_ERR_STATE;
+  }
+  CommDeviceGuard guard(c->device);
   XDET_HIP(hipMemcpyAsync(c->d_scalar, value_host, sizeof(double), hipMemcpyHostToDevice, c->stream));
   XDET_RCCL(g_rccl.AllReduce(c->d_scalar, c->d_scalar + 1, 1, ncclDouble, ncclMax, c->comm, c->stream));
   XDET_HIP(hipMemcpyAsync(value_host, c->d_scalar + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  XDET_HIP(hipStreamSynchronize(c->stream));
+  XDET_HIP(hipEventRecord(c->ev_done, c->stream));
+  return watchdog_wait(c, c->ev_done, "allreduce_max");
+}
+
+// Small host-buffer all-gather (rank records, per-rank rates): send `bytes` from every rank, receive world * bytes in
+// rank order.  Staged through device memory and moved by ncclAllGather on the communicator's stream, i.e. over the
+// same transport as the detections -- what arrives proves which ranks took part.
+int xdet_comm_allgather_bytes(void* comm, const void* send_host, void* recv_host, size_t bytes) {
+  Comm* c = static_cast<Comm*>(comm);
+  XDET_REQUIRE(c && send_host && recv_host && bytes > 0 && bytes <= (1u << 20), "allgather_bytes: bad arguments (1 MiB per rank at most)");
+  if (c->dead) {
+    set_last_error("allgather_bytes: the communicator was aborted by the watchdog");
+    return XDET_ERR_STATE;
+  }
+  CommDeviceGuard guard(c->device);
+  const size_t need = bytes * (size_t)(c->world + 1);
+  if (need > c->d_bytes_cap) {
+    XDET_HIP(hipStreamSynchronize(c->stream));
+    if (c->d_bytes) (void)hipFree(c->d_bytes);
+    c->d_bytes = nullptr;
+    c->d_bytes_cap = 0;
+    XDET_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bytes), need));
+    c->d_bytes_cap = need;
+  }
+  XDET_HIP(hipMemcpyAsync(c->d_bytes, send_host, bytes, hipMemcpyHostToDevice, c->stream));
+  XDET_RCCL(g_rccl.AllGather(c->d_bytes, c->d_bytes + bytes, bytes, ncclChar, c->comm, c->stream));
+  XDET_HIP(hipMemcpyAsync(recv_host, c->d_bytes + bytes, bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+  XDET_HIP(hipEventRecord(c->ev_done, c->stream));
+  return watchdog_wait(c, c->ev_done, "allgather_bytes");
+}
+
+int xdet_comm_set_timeout(void* comm, double seconds) {
+  Comm* c = static_cast<Comm*>(comm);
+  XDET_REQUIRE(c && seconds > 0, "comm_set_timeout: need a communicator and a positive timeout");
+  c->timeout_s = seconds;
   return XDET_OK;
 }
 

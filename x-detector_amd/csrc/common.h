@@ -107,9 +107,12 @@ int launch_maxpool3x3s2_add(const float* in, const float* res, float* out, int N
 int launch_maxpool_v3s2_add(const float* in_hpooled, const float* res, float* out, int N, int H, int Wo, int C, int ld,
                             int Ho, int pad_t, hipStream_t s);
 // diagnostic: bad_per_image[n] = 1 if any element of image n is NaN or beyond +-limit
-int launch_range_check(const float* x, int N, size_t per_image, float limit, int* bad_per_image, hipStream_t s);
+// groups > 1: a stack of `groups` blocks of group_elems floats / group_pix pixels (the frequency bins of the spectral
+// large-separable convs); the image of an element is its position inside its block / per_image, rows past N are padding
+int launch_range_check(const float* x, int N, size_t per_image, float limit, int* bad_per_image, hipStream_t s,
+                       int groups = 1, size_t group_elems = 0);
 int launch_range_check_planes(const unsigned short* hi, int N, int64_t pix_per_image, int ld, int* bad_per_image,
-                              hipStream_t s);
+                              hipStream_t s, int groups = 1, int64_t group_pix = 0);
 int launch_relu_copy(const float* in, float* out, int64_t n, hipStream_t s);
 int launch_stem_conv3x3s2(const float* in_nchw, const float* w27x32, const float* scale, const float* shift,
                           unsigned short* hi, unsigned short* lo, int N, int S, hipStream_t s);

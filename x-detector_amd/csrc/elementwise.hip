@@ -573,13 +573,19 @@ int launch_maxpool_v3s2_add(const float* in_hpooled, const float* res, float* ou
 // NaN that follows does not survive the next ReLU (max(NaN, 0) = 0): without this pass an overflow ends as a silently
 // empty detection list.  BN-normalised checkpoints stay orders of magnitude inside the range; the pass is for
 // validating a new checkpoint once (it reads every activation again: ~+30 % time).
+// group4 > 0: the tensor is a stack of groups of group4 float4s (the frequency bins of the spectral large-separable
+// convs, rows [bin][n*F + o]); the image of an element is its index WITHIN the group / per_image4, rows past the
+// batch are padding
 __global__ __launch_bounds__(256) void range_check_kernel(const float4* __restrict__ x, int64_t n4, int64_t per_image4,
-                                                          float limit, int* __restrict__ bad) {
+                                                          float limit, int* __restrict__ bad, int64_t group4, int N) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const float4 v = x[i];
     const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
     const bool nan = v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w;
-    if (nan || !(m <= limit)) bad[i / per_image4] = 1;
+    if (nan || !(m <= limit)) {
+      const int64_t img = (group4 ? i % group4 : i) / per_image4;
+      if (img < N) bad[img] = 1;
+    }
   }
 }
 
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(256) void range_check_kernel(const float4* __restri
 // epilogues that feed the LDS-DMA kernel): hi = inf / NaN is how an element beyond the f16 range looks there.
 __global__ __launch_bounds__(256) void range_check_planes_kernel(const uint4* __restrict__ hi, int64_t n8, int c32n,
                                                                  int64_t pix_per_image, int64_t n_pix,
-                                                                 int* __restrict__ bad) {
+                                                                 int* __restrict__ bad, int64_t group_pix, int N) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
     const uint4 v = hi[i];
     const unsigned w[4] = {v.x, v.y, v.z, v.w};
@@ -596,30 +602,32 @@ __global__ __launch_bounds__(256) void range_check_planes_kernel(const uint4* __
     for (int k = 0; k < 4; ++k) b |= (w[k] & 0x7c00u) == 0x7c00u || (w[k] & 0x7c000000u) == 0x7c000000u;
     if (b) {
       const int64_t pix = (i >> 6) / c32n * 16 + ((i >> 2) & 15);      // 64 chunks of 8 halves per 1 KB block
-      if (pix < n_pix) bad[pix / pix_per_image] = 1;
+      const int64_t img = (group_pix ? pix % group_pix : pix) / pix_per_image;
+      if (pix < n_pix && img < N) bad[img] = 1;
     }
   }
 }
 
 int launch_range_check_planes(const unsigned short* hi, int N, int64_t pix_per_image, int ld, int* bad_per_image,
-                              hipStream_t s) {
-  const int64_t n_pix = (int64_t)N * pix_per_image;
+                              hipStream_t s, int groups, int64_t group_pix) {
+  const int64_t n_pix = groups > 1 ? (int64_t)groups * group_pix : (int64_t)N * pix_per_image;
   const int64_t n8 = cdiv(n_pix, 16) * 16 * ld / 8;
   if (n8 == 0) return XDET_OK;
   const int blocks = (int)std::min<int64_t>(cdiv(n8, 256), 256 * 16);
   hipLaunchKernelGGL(range_check_planes_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(hi), n8, ld >> 5,
-                     pix_per_image, n_pix, bad_per_image);
+                     pix_per_image, n_pix, bad_per_image, groups > 1 ? group_pix : (int64_t)0, N);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }
 
-int launch_range_check(const float* x, int N, size_t per_image, float limit, int* bad_per_image, hipStream_t s) {
-  XDET_REQUIRE(per_image % 4 == 0, "range_check: tensor size must be a multiple of 4");
-  const int64_t n4 = (int64_t)N * (int64_t)(per_image / 4);
+int launch_range_check(const float* x, int N, size_t per_image, float limit, int* bad_per_image, hipStream_t s,
+                       int groups, size_t group_elems) {
+  XDET_REQUIRE(per_image % 4 == 0 && group_elems % 4 == 0, "range_check: tensor size must be a multiple of 4");
+  const int64_t n4 = groups > 1 ? (int64_t)groups * (int64_t)(group_elems / 4) : (int64_t)N * (int64_t)(per_image / 4);
   if (n4 == 0) return XDET_OK;
   const int blocks = (int)std::min<int64_t>(cdiv(n4, 256), 256 * 16);
   hipLaunchKernelGGL(range_check_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x), n4,
-                     (int64_t)(per_image / 4), limit, bad_per_image);
+                     (int64_t)(per_image / 4), limit, bad_per_image, groups > 1 ? (int64_t)(group_elems / 4) : (int64_t)0, N);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }

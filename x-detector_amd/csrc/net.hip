@@ -676,6 +676,7 @@ struct LightHeadNet : Plan {
   bool large_sep_spectral = false;      // decided at build
   bool rpn_side_stream = true;          // option "rpn_stream" = "side" | "main"
   bool check_range = false;             // option "check_range" = "off" | "on": validate every activation against the f16 range
+  std::vector<std::function<int(int, hipStream_t)>> extra_range_checks;   // tensors that are not plain [N][pixels][ld] (DFT bins)
   bool stem_direct = false;             // block1_conv1 as the dedicated NCHW -> planes kernel
   const float* cur_images = nullptr;
   hipStream_t aux = nullptr;            // side stream of the RPN/proposal branch
@@ -900,6 +901,21 @@ struct LightHeadNet : Plan {
     XDET_TRY(alloc_bytes(rows * 2 * co_ld * 4 + 512, reinterpret_cast<void**>(&y2)));
     XDET_TRY(new_buf(F, F, co, &feat));
     const Buf o = out, ft = feat;
+    // check_range covers the DFT-domain tensors too.  A bin sums up to F samples (the DC bin all of them), so the f16
+    // range of the planes is reached at activations of ~65504 / F, and tmid is an un-normalised 15-tap conv output:
+    // this is where a checkpoint with large activations would overflow first.
+    f32_bufs.emplace_back(tmid, (size_t)F * F * mid2);
+    {
+      // (prop_ws.bad is carved later, in build(): the lambda reads it through `this` at call time)
+      auto mpad_rc = [F](int N) { return N * F <= 128 ? 128 : round_up(N * F, 256); };
+      extra_range_checks.push_back([=](int N, hipStream_t s) {
+        const int mp = mpad_rc(N);
+        XDET_TRY(launch_range_check_planes(xa_hi, N, F, 2 * cin_ld, prop_ws.bad, s, NB, mp));
+        XDET_TRY(launch_range_check_planes(xb_hi, N, F, 2 * mid2, prop_ws.bad, s, NB, mp));
+        XDET_TRY(launch_range_check(y1, N, (size_t)F * 2 * mid2, 65504.f, prop_ws.bad, s, NB, (size_t)mp * 2 * mid2));
+        return launch_range_check(y2, N, (size_t)F * 2 * co_ld, 65504.f, prop_ws.bad, s, NB, (size_t)mp * 2 * co_ld);
+      });
+    }
     const std::string pre = "large_sep_feature/Branch_0+1/";
     const double fl_a = 2.0 * F * F * (double)cin * mid2 * 15, fl_b = 2.0 * F * F * (double)mid2 * co * 15;
     // rows per bin: whole 256-row GEMM tiles; a single image or two (N*F <= 128) get the 128-row tile instead
@@ -1087,6 +1103,7 @@ struct LightHeadNet : Plan {
     if (check_range && net_precision != PREC_F32) {
       for (const auto& b : f32_bufs) XDET_TRY(launch_range_check(b.first, N, b.second, 65504.f, prop_ws.bad, s));
       for (const auto& b : planes_bufs) XDET_TRY(launch_range_check_planes(b.hi, N, b.pix_per_image, b.ld, prop_ws.bad, s));
+      for (const auto& f : extra_range_checks) XDET_TRY(f(N, s));
     }
     return bboxes_eval(N, shapes, bbox, ds, db, s);
   }
@@ -1260,6 +1277,20 @@ const char* xdet_last_error(void) { return g_last_error.c_str(); }
 int xdet_version(void) { return 1; }
 int xdet_device_count(int* n) { XDET_HIP(hipGetDeviceCount(n)); return XDET_OK; }
 int xdet_set_device(int dev) { XDET_HIP(hipSetDevice(dev)); return XDET_OK; }
+int xdet_device_pci_bus_id(int dev, char* buf, int buflen) {
+  XDET_REQUIRE(buf && buflen >= 16, "device_pci_bus_id: need a buffer of >= 16 bytes");
+  XDET_HIP(hipDeviceGetPCIBusId(buf, buflen, dev));
+  return XDET_OK;
+}
+int xdet_probe_ipc(void) {
+  void* p = nullptr;
+  XDET_HIP(hipMalloc(&p, 1 << 16));
+  hipIpcMemHandle_t h;
+  const hipError_t e = hipIpcGetMemHandle(&h, p);
+  (void)hipFree(p);
+  XDET_HIP(e);
+  return XDET_OK;
+}
 int xdet_set_default_precision(int mode) {
   XDET_REQUIRE(mode == PREC_F32 || mode == PREC_F16X3 || mode == PREC_F16, "precision must be 0 (f32), 1 (f16x3) or 2 (f16)");
   g_default_precision = mode;

@@ -128,7 +128,12 @@ __global__ __launch_bounds__(256) void dft_inv_kernel(const float* __restrict__ 
   for (int i = 0; i < F; ++i) {
     float4 t = make_float4(fmaf(acc[i].x, sc.x, sh.x), fmaf(acc[i].y, sc.y, sh.y), fmaf(acc[i].z, sc.z, sh.z),
                            fmaf(acc[i].w, sc.w, sh.w));
-    if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+    // NaN-propagating ReLU: fmaxf(NaN, 0) = 0 would turn an overflowed bin (hi = inf in the planes -> NaN out of the
+    // GEMM) into silent zeros in `feat`; kept as NaN it reaches the head logits and the always-on guard of bboxes_eval
+    if (relu) {
+      t.x = (t.x > 0.f || t.x != t.x) ? t.x : 0.f; t.y = (t.y > 0.f || t.y != t.y) ? t.y : 0.f;
+      t.z = (t.z > 0.f || t.z != t.z) ? t.z : 0.f; t.w = (t.w > 0.f || t.w != t.w) ? t.w : 0.f;
+    }
     *reinterpret_cast<float4*>(base + i * step) = t;
   }
 }

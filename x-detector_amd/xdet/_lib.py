@@ -54,6 +54,8 @@ SIGNATURES = {
     'xdet_version': (c_int, []),
     'xdet_device_count': (c_int, [ctypes.POINTER(c_int)]),
     'xdet_set_device': (c_int, [c_int]),
+    'xdet_device_pci_bus_id': (c_int, [c_int, ctypes.c_char_p, c_int]),
+    'xdet_probe_ipc': (c_int, []),
     'xdet_set_default_precision': (c_int, [c_int]),
     'xdet_get_default_precision': (c_int, []),
     'xdet_malloc': (c_int, [ctypes.POINTER(c_void_p), c_size_t]),
@@ -134,6 +136,8 @@ SIGNATURES = {
     'xdet_comm_wait': (c_int, [c_void_p, c_void_p]),
     'xdet_comm_allreduce_max': (c_int, [c_void_p, ctypes.POINTER(c_double)]),
     'xdet_comm_barrier': (c_int, [c_void_p]),
+    'xdet_comm_allgather_bytes': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    'xdet_comm_set_timeout': (c_int, [c_void_p, c_double]),
 }
 
 _lib = None
@@ -146,9 +150,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError('libxdet_hip.so is missing (%s): run `python __graft_entry__.py` / '
                               'xdet/build.py; there is no CPU fallback' % LIB_PATH)
-        # the host driver of these boxes only supports dmabuf IPC; RCCL's intra-node P2P (xdet_comm_*) fails with
-        # "hipIpcGetMemHandle: invalid argument" otherwise.  Read by the HSA runtime when it starts: set before loading.
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        # HSA_ENABLE_IPC_MODE_LEGACY is read by the HSA runtime when it starts, i.e. it must be decided before the
+        # first HIP call.  Only a multi-rank process needs device-memory IPC (RCCL's intra-node transport); whether
+        # the host driver wants the legacy or the dmabuf mode is probed once per launch (xdet.launch.ipc_env) --
+        # never forced on a single-GPU user.
+        if 'HSA_ENABLE_IPC_MODE_LEGACY' not in os.environ and int(os.environ.get('WORLD_SIZE', '1') or 1) > 1:
+            from .launch import ipc_env
+            os.environ.update(ipc_env())
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)      # AttributeError if the symbol is not exported

@@ -12,7 +12,7 @@ Everything between the uint8 image and those arrays runs on the GPU (F1 kernel, 
 import numpy as np
 
 from ._lib import lib, check
-from .runtime import to_device, synchronize
+from .runtime import DeviceBuffer, _host, to_device, synchronize
 
 DEMO_FLAGS = dict(num_classes=21, image_size=480, select_threshold=0.5, nms_threshold=0.3, nms_topk=20,
                   rpn_pre_nms_top_n=5000, rpn_post_nms_top_n=1000, rpn_nms_thres=0.7, rpn_min_size=16. / 480)
@@ -37,9 +37,15 @@ def light_head_simple_demo(np_image, detector, use_graph=False):
     # F1 writes the whitened, warped CHW planes straight into the detector's input buffer
     check(lib().xdet_preprocess_eval(d_img.ptr, img.shape[0], img.shape[1], detector._images.ptr, S,
                                      detector.stream.handle))
-    shape = to_device(np.array([[img.shape[0], img.shape[1]]], np.int32))
+    # the image-shape operand lives in ONE device buffer per detector, refreshed on the detector's stream in front of
+    # the forward: a captured graph bakes the pointer in (the cache is keyed on it), so a buffer allocated and freed per
+    # call would capture a new graph for every image and leave the old ones pointing at freed memory
+    if getattr(detector, '_demo_shape', None) is None:
+        detector._demo_shape = DeviceBuffer(8)
+    host_shape = np.array([[img.shape[0], img.shape[1]]], np.int32)
+    check(lib().xdet_memcpy_h2d(detector._demo_shape.ptr, _host(host_shape), 8, detector.stream.handle))
     detector._N = 1
-    detector.forward_device(1, use_graph=use_graph, image_shapes_ptr=shape.ptr)
+    detector.forward_device(1, use_graph=use_graph, image_shapes_ptr=detector._demo_shape.ptr)
     scores, boxes = detector.detections(1)           # [1, 20, topk], [1, 20, topk, 4]
     nc, k = scores.shape[1], scores.shape[2]
     labels = np.repeat(np.arange(1, nc + 1, dtype=np.int32), k)

@@ -150,6 +150,42 @@ class Communicator(object):
         from ._lib import lib, check
         check(lib().xdet_comm_barrier(self.handle))
 
+    def set_timeout(self, seconds):
+        """watchdog of every host wait on the communicator's stream (default 300 s / XDET_COMM_TIMEOUT_S): past it
+        the communicator is aborted and the call raises instead of hanging behind a dead peer."""
+        from ._lib import lib, check
+        check(lib().xdet_comm_set_timeout(self.handle, float(seconds)))
+
+    def allgather_bytes(self, payload):
+        """`payload` (bytes, the same length on every rank, <= 1 MiB) -> list of world payloads in rank order,
+        moved by ncclAllGather on the communicator's stream."""
+        from ._lib import lib, check
+        n = len(payload)
+        send = ctypes.create_string_buffer(bytes(payload), n)
+        recv = ctypes.create_string_buffer(n * self.world)
+        check(lib().xdet_comm_allgather_bytes(self.handle, send, recv, n))
+        return [recv.raw[i * n:(i + 1) * n] for i in range(self.world)]
+
+    def device_records(self, extra=None):
+        """every rank's (rank, hip device, PCI bus id, host, pid[, extra]) gathered THROUGH the collective: N distinct
+        (host, pci_bus_id) pairs in the result prove that N distinct GPUs took part.  `extra`: a small dict of
+        numbers per rank (e.g. its images/s)."""
+        import json
+        import socket
+        from ._lib import lib, check
+        info = self.info()
+        buf = ctypes.create_string_buffer(32)
+        check(lib().xdet_device_pci_bus_id(info['device'], buf, 32))
+        rec = {'rank': self.rank, 'hip_device': info['device'], 'pci_bus_id': buf.value.decode(),
+               'host': socket.gethostname(), 'pid': os.getpid()}
+        if extra:
+            rec.update(extra)
+        raw = json.dumps(rec).encode()
+        if len(raw) > 500:
+            raise ValueError('device record too large')
+        out = [json.loads(b.rstrip(b'\0').decode()) for b in self.allgather_bytes(raw.ljust(512, b'\0'))]
+        return out
+
     def close(self):
         if getattr(self, 'handle', None) is not None:
             from ._lib import lib
