@@ -245,6 +245,16 @@ int xdet_net_bboxes_eval(void* net, int N, const int* image_shapes, const float*
  * xdet_net_graph_count: number of graphs currently cached (tests). */
 int xdet_net_forward(void* net, const float* images_nchw, int N, const int* image_shapes, const float* bbox_img,
                      float* det_scores, float* det_boxes, int use_graph, void* stream);
+/* Activation pre-scale of the split-precision operands (modes 1 / 2).  An f16 hi part overflows beyond 65504 while the
+ * reference computes in f32 everywhere and has BN-less edges (net/xception_body.py:381-400,450-475).  Every tensor that
+ * is split into f16 planes carries a power-of-two exponent e: the planes hold x * 2^-e and the consuming contraction
+ * folds 2^e back into its epilogue scale -- both exact.  xdet_net_calibrate runs the forward on `images` (device,
+ * [N,3,S,S]) until no operand exceeds 4096 (16x headroom) and reports how many tensors got e != 0; a net whose
+ * activations are small keeps every exponent at 0 and its results bit for bit.  Cached graphs are dropped.
+ * xdet_net_plane_scales / _name: the exponents and what they belong to (exps may be NULL to query the count). */
+int xdet_net_calibrate(void* net, const float* images_nchw, int N, int* n_scaled, void* stream);
+int xdet_net_plane_scales(void* net, int max_n, int* n_out, int* exps);
+int xdet_net_plane_scale_name(void* net, int idx, char* buf, int buflen);
 int xdet_net_graph_count(void* net, int* count);
 /* per-kernel accounting of the last build: total dense FLOPs (2*MAC, unpadded) of one image */
 int xdet_net_flops_per_image(void* net, double* backbone, double* rpn, double* large_sep, double* head);

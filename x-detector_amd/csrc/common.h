@@ -116,10 +116,14 @@ int launch_range_check_planes(const unsigned short* hi, int N, int64_t pix_per_i
 int launch_relu_copy(const float* in, float* out, int64_t n, hipStream_t s);
 int launch_stem_conv3x3s2(const float* in_nchw, const float* w27x32, const float* scale, const float* shift,
                           unsigned short* hi, unsigned short* lo, int N, int S, hipStream_t s);
+// mul: the planes' activation pre-scale 2^-e (a power of two; 1 = none): hi + lo = x * mul
 int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, int64_t n_pix, int ld, int relu,
-                     hipStream_t s);
+                     hipStream_t s, float mul = 1.f);
 int launch_split_f32_subsample2(const float* in, unsigned short* hi, unsigned short* lo, int N, int H, int W, int ld,
-                                hipStream_t s, const float* scale = nullptr, const float* shift = nullptr);
+                                hipStream_t s, const float* scale = nullptr, const float* shift = nullptr, float mul = 1.f);
+// range calibration: largest |hi| of a plane (f16 bits) / largest |x| or max(x, 0) of an f32 tensor (f32 bits), atomicMax'ed into *out
+int launch_absmax_planes(const unsigned short* hi, int64_t n_halves, unsigned* out, hipStream_t s);
+int launch_absmax_f32(const float* x, int64_t n, int relu, unsigned* out, hipStream_t s);
 int launch_depthwise3x3_split(const float* in, const float* w9c, unsigned short* hi, unsigned short* lo, int N,
                               int H, int W, int C, int ld, int dil, int relu_in, hipStream_t s);
 

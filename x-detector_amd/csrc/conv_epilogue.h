@@ -7,6 +7,10 @@ namespace xdet {
 typedef float ep_f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 ep_f16x4 __attribute__((ext_vector_type(4)));
 
+// ReLU that keeps NaN: fmaxf(NaN, 0) = 0 would launder an overflowed split-precision operand (hi = inf -> NaN out
+// of the MFMAs) into a clean zero; !(v <= 0) is true for v > 0 and for NaN.  Same result as fmaxf for every other input.
+__device__ __forceinline__ float ep_relu(float v) { return !(v <= 0.f) ? v : 0.f; }
+
 // The MFMA accumulator layout gives each lane one
 // column and 16 scattered rows, i.e. 4-byte global stores (and residual loads).  Bounce each 32-row slab
 // of the wave tile through the (now idle) operand LDS so a lane owns 4 consecutive channels of a row:
@@ -63,7 +67,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, ep_f32x16 (&a
                          fmaf(a.w, sc4.w, sh4.w));
       if (p.res) { v[q].x += rr[q].x; v[q].y += rr[q].y; v[q].z += rr[q].z; v[q].w += rr[q].w; }
       if (p.relu_out) {
-        v[q].x = fmaxf(v[q].x, 0.f); v[q].y = fmaxf(v[q].y, 0.f); v[q].z = fmaxf(v[q].z, 0.f); v[q].w = fmaxf(v[q].w, 0.f);
+        v[q].x = ep_relu(v[q].x); v[q].y = ep_relu(v[q].y); v[q].z = ep_relu(v[q].z); v[q].w = ep_relu(v[q].w);
       }
     }
     if (p.res && i + 1 < TM) load_res(i + 1);
@@ -78,7 +82,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, ep_f32x16 (&a
             t.x = fmaf(t.x, psc.x, psh.x); t.y = fmaf(t.y, psc.y, psh.y);
             t.z = fmaf(t.z, psc.z, psh.z); t.w = fmaf(t.w, psc.w, psh.w);
           }
-          if (p.planes_relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+          if (p.planes_relu) { t.x = ep_relu(t.x); t.y = ep_relu(t.y); t.z = ep_relu(t.z); t.w = ep_relu(t.w); }
           const _Float16 h0 = (_Float16)t.x, h1 = (_Float16)t.y, h2 = (_Float16)t.z, h3 = (_Float16)t.w;
           ep_f16x4 hv = {h0, h1, h2, h3};
           ep_f16x4 lv = {(_Float16)(t.x - (float)h0), (_Float16)(t.y - (float)h1), (_Float16)(t.z - (float)h2),

@@ -356,9 +356,10 @@ __device__ __forceinline__ void split8(const float4 a, const float4 b, f16x8e* h
   }
 }
 
+// mul: a power of two (the tensor's activation pre-scale 2^-e, 1 by default): the planes hold x * mul
 __global__ __launch_bounds__(256) void split_f32_kernel(const float* __restrict__ in, unsigned short* __restrict__ hi,
                                                         unsigned short* __restrict__ lo, int64_t n_pix, int ld,
-                                                        int relu) {
+                                                        int relu, float mul) {
   const int c32n = ld >> 5;
   const int64_t n8 = ((n_pix + 15) >> 4) * c32n * 64;   // 16-B output chunks per plane (64 per 1 KB block)
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
@@ -373,6 +374,8 @@ __global__ __launch_bounds__(256) void split_f32_kernel(const float* __restrict_
       a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
       b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f);
     }
+    a.x *= mul; a.y *= mul; a.z *= mul; a.w *= mul;
+    b.x *= mul; b.y *= mul; b.z *= mul; b.w *= mul;
     f16x8e h, l;
     split8(a, b, &h, &l);
     *reinterpret_cast<f16x8e*>(hi + i * 8) = h;
@@ -381,12 +384,12 @@ __global__ __launch_bounds__(256) void split_f32_kernel(const float* __restrict_
 }
 
 int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, int64_t n_pix, int ld, int relu,
-                     hipStream_t s) {
+                     hipStream_t s, float mul) {
   XDET_REQUIRE(ld > 0 && ld % 32 == 0, "split: channel stride must be a multiple of 32");
   if (n_pix == 0) return XDET_OK;
   const int64_t n = cdiv(n_pix, 16) * 16 * ld;
   const int blocks = (int)std::min<int64_t>(cdiv(n / 8, 256), 256 * 32);
-  hipLaunchKernelGGL(split_f32_kernel, dim3(blocks), dim3(256), 0, s, in, hi, lo, n_pix, ld, relu);
+  hipLaunchKernelGGL(split_f32_kernel, dim3(blocks), dim3(256), 0, s, in, hi, lo, n_pix, ld, relu, mul);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(256) void split_f32_subsample2_kernel(const float* 
                                                                    unsigned short* __restrict__ hi,
                                                                    unsigned short* __restrict__ lo, int N, int H, int W,
                                                                    int Ho, int Wo, int ld, const float* __restrict__ scale,
-                                                                   const float* __restrict__ shift) {
+                                                                   const float* __restrict__ shift, float mul) {
   const int c32n = ld >> 5;
   const int64_t n_pix = (int64_t)N * Ho * Wo;
   const int64_t n8 = ((n_pix + 15) >> 4) * c32n * 64;
@@ -424,6 +427,8 @@ __global__ __launch_bounds__(256) void split_f32_subsample2_kernel(const float* 
       b.x = fmaxf(fmaf(b.x, s1.x, h1.x), 0.f); b.y = fmaxf(fmaf(b.y, s1.y, h1.y), 0.f);
       b.z = fmaxf(fmaf(b.z, s1.z, h1.z), 0.f); b.w = fmaxf(fmaf(b.w, s1.w, h1.w), 0.f);
     }
+    a.x *= mul; a.y *= mul; a.z *= mul; a.w *= mul;
+    b.x *= mul; b.y *= mul; b.z *= mul; b.w *= mul;
     f16x8e h, l;
     split8(a, b, &h, &l);
     *reinterpret_cast<f16x8e*>(hi + i * 8) = h;
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(256) void split_f32_subsample2_kernel(const float* 
 }
 
 int launch_split_f32_subsample2(const float* in, unsigned short* hi, unsigned short* lo, int N, int H, int W, int ld,
-                                hipStream_t s, const float* scale, const float* shift) {
+                                hipStream_t s, const float* scale, const float* shift, float mul) {
   XDET_REQUIRE(ld > 0 && ld % 32 == 0, "split: channel stride must be a multiple of 32");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int64_t n_pix = (int64_t)N * Ho * Wo;
@@ -440,7 +445,7 @@ int launch_split_f32_subsample2(const float* in, unsigned short* hi, unsigned sh
   const int64_t n = cdiv(n_pix, 16) * 16 * ld;
   const int blocks = (int)std::min<int64_t>(cdiv(n / 8, 256), 256 * 32);
   hipLaunchKernelGGL(split_f32_subsample2_kernel, dim3(blocks), dim3(256), 0, s, in, hi, lo, N, H, W, Ho, Wo, ld, scale,
-                     shift);
+                     shift, mul);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }
@@ -536,9 +541,14 @@ __global__ __launch_bounds__(256) void maxpool_v3s2_add_kernel(const float* __re
   const int n = band / bands_per_image;
   const int oy0 = (band - n * bands_per_image) * MP_ROWS;
   const float* base = in + (size_t)n * H * Wo * ld + (size_t)item * 4;      // item = ox * c4n + c4
-  const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  // (by value: `cond ? *ptr : ninf` is an lvalue conditional -- it took ninf's address and put it in scratch memory)
+  //  and the compiler turns `if (ok) v = *ptr` back into a load through a selected pointer: load a valid row always,
+  //  select on the VALUES)
   auto rowv = [&](int iy) {
-    return (unsigned)iy < (unsigned)H ? *reinterpret_cast<const float4*>(base + (size_t)iy * Wo * ld) : ninf;
+    const bool ok = (unsigned)iy < (unsigned)H;
+    float4 v = *reinterpret_cast<const float4*>(base + (size_t)(ok ? iy : 0) * Wo * ld);
+    v.x = ok ? v.x : -INFINITY; v.y = ok ? v.y : -INFINITY; v.z = ok ? v.z : -INFINITY; v.w = ok ? v.w : -INFINITY;
+    return v;
   };
   float4 carry = rowv(oy0 * 2 - pad_t);
   const int oy1 = min(Ho, oy0 + MP_ROWS);
@@ -628,6 +638,54 @@ int launch_range_check(const float* x, int N, size_t per_image, float limit, int
   const int blocks = (int)std::min<int64_t>(cdiv(n4, 256), 256 * 16);
   hipLaunchKernelGGL(range_check_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x), n4,
                      (int64_t)(per_image / 4), limit, bad_per_image, groups > 1 ? (int64_t)(group_elems / 4) : (int64_t)0, N);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
+// ---- range calibration (activation pre-scale of the split-precision planes, net.hip calibrate()) ----
+// largest |hi| of a split plane as f16 bits (inf / NaN sort above every finite value: bits >= 0x7c00)
+__global__ __launch_bounds__(256) void absmax_planes_kernel(const uint4* __restrict__ hi, int64_t n8, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 v = hi[i];
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m = max(m, max(w[k] & 0x7fffu, (w[k] >> 16) & 0x7fffu));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+// largest |x| (relu: largest max(x, 0)) of an f32 tensor as f32 bits (NaN / inf: bits >= 0x7f800000)
+__global__ __launch_bounds__(256) void absmax_f32_kernel(const float4* __restrict__ x, int64_t n4, int relu, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = x[i];
+    const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned b = __float_as_uint(f[k]);
+      if (relu && (b >> 31) && (b & 0x7fffffffu) <= 0x7f800000u) continue;    // negative (not NaN): ReLU maps it to 0
+      m = max(m, b & 0x7fffffffu);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+int launch_absmax_planes(const unsigned short* hi, int64_t n_halves, unsigned* out, hipStream_t s) {
+  const int64_t n8 = n_halves / 8;
+  if (n8 <= 0) return XDET_OK;
+  const int blocks = (int)std::min<int64_t>(cdiv(n8, 256), 256 * 8);
+  hipLaunchKernelGGL(absmax_planes_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(hi), n8, out);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+int launch_absmax_f32(const float* x, int64_t n, int relu, unsigned* out, hipStream_t s) {
+  const int64_t n4 = n / 4;
+  if (n4 <= 0) return XDET_OK;
+  const int blocks = (int)std::min<int64_t>(cdiv(n4, 256), 256 * 8);
+  hipLaunchKernelGGL(absmax_f32_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x), n4, relu, out);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }

@@ -7,6 +7,7 @@
 
 #include <array>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -116,8 +117,35 @@ struct ConvLayer : LayerBase {
   // tile's B operand is then one contiguous run
   unsigned short *d_wt_hi_b = nullptr, *d_wt_lo_b = nullptr;
   unsigned short* d_zeros = nullptr;   // 256 B of zeros on the layer's device: the source of out-of-image taps
+  // Activation pre-scale (split-precision range, Plan::calibrate): the A-operand planes hold x * 2^-in_exp and the
+  // epilogue scale carries 2^in_exp (exact: powers of two); a planes copy of the output is written as out * 2^-out_exp
+  // through the epilogue's pl_scale / pl_shift.  Both 0 unless a calibration found a tensor near the f16 range.
+  std::vector<float> h_scale;          // host copy of d_scale at in_exp = 0
+  int in_exp = 0, out_exp = 0;
+  float *d_pl_scale = nullptr, *d_pl_shift = nullptr;
+  int set_in_exp(int e) {
+    std::vector<float> v(h_scale);
+    for (float& x : v) x = ldexpf(x, e);
+    XDET_HIP(hipMemcpy(d_scale, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    in_exp = e;
+    return XDET_OK;
+  }
+  int set_out_exp(int e) {
+    const size_t n = (size_t)std::max(cout_pad, ld_out());
+    if (!d_pl_scale) {
+      XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_pl_scale), n * sizeof(float)));
+      XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_pl_shift), n * sizeof(float)));
+      XDET_HIP(hipMemset(d_pl_shift, 0, n * sizeof(float)));
+    }
+    std::vector<float> v(n, ldexpf(1.f, -e));
+    XDET_HIP(hipMemcpy(d_pl_scale, v.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    out_exp = e;
+    return XDET_OK;
+  }
 
   ~ConvLayer() override {
+    if (d_pl_scale) (void)hipFree(d_pl_scale);
+    if (d_pl_shift) (void)hipFree(d_pl_shift);
     if (d_zeros) (void)hipFree(d_zeros);
     if (d_wt_hi_b) (void)hipFree(d_wt_hi_b);
     if (d_wt_lo_b) (void)hipFree(d_wt_lo_b);
@@ -217,6 +245,7 @@ struct ConvLayer : LayerBase {
     }
     XDET_TRY(upload(sc, &d_scale));
     XDET_TRY(upload(sh, &d_shift));
+    h_scale = sc;
     return XDET_OK;
   }
 
@@ -282,6 +311,15 @@ struct ConvLayer : LayerBase {
 struct DepthwiseLayer : LayerBase {
   int C, dil, ld;
   float* d_w = nullptr;
+  std::vector<float> h_w;        // host copy of the taps: a planes-producing depthwise carries its activation pre-scale in them
+  int out_exp = 0;
+  int set_out_exp(int e) {       // every partial sum of the FMA chain scales exactly with a power of two
+    std::vector<float> v(h_w);
+    for (float& x : v) x = ldexpf(x, -e);
+    XDET_HIP(hipMemcpy(d_w, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    out_exp = e;
+    return XDET_OK;
+  }
   ~DepthwiseLayer() override { if (d_w) (void)hipFree(d_w); }
   int init(int C_, int dil_, const float* w33c1) {
     XDET_REQUIRE(C_ > 0 && dil_ > 0 && w33c1, "depthwise: bad arguments");
@@ -291,6 +329,7 @@ struct DepthwiseLayer : LayerBase {
     std::vector<float> w((size_t)9 * ld, 0.f);
     for (int t = 0; t < 9; ++t)
       for (int c = 0; c < C; ++c) w[(size_t)t * ld + c] = w33c1[(size_t)t * C + c];
+    h_w = w;
     return upload(w, &d_w);
   }
   int forward(const float* in, int N, int H, int W, int ld_, float* out, int relu_in, hipStream_t s) const {
@@ -307,6 +346,7 @@ struct Buf {
   unsigned short *hi = nullptr, *lo = nullptr;   // optional split-precision f16 planes of the same tensor
   bool planes_relu = false;                      // the planes hold relu(tensor)
   bool no_f32 = false;                           // only the planes are ever written (p stays unused)
+  int pidx = -1;                                 // entry of Plan::pscales: the planes hold x * 2^-exp
   int H = 0, W = 0, C = 0, ld = 0;
   size_t per_image() const { return (size_t)H * W * ld; }
 };
@@ -387,6 +427,33 @@ struct Plan {
     return XDET_OK;
   }
 
+  // ---- activation pre-scale of the split-precision operands ----
+  // An f16 hi part overflows beyond 65504 (the reference computes in f32 everywhere and has BN-less edges:
+  // net/xception_body.py:381-400,450-475).  Every tensor that exists as split planes -- in HBM, or inside a fused
+  // separable block -- has a power-of-two exponent e: the planes hold x * 2^-e and the consuming contraction folds 2^e
+  // back into its epilogue scale, both exact.  e = 0 (no change at all) unless calibrate() measures a tensor above
+  // kRangeTarget on a calibration batch.
+  struct PlaneScale {
+    std::string name;
+    int exp = 0;
+    const unsigned short* hi = nullptr;               // measured on the planes themselves ...
+    std::function<int64_t(int)> halves;               // ... over this many halves for a batch of N
+    const float* src = nullptr;                       // or (the operand a fused block keeps on the CU) bounded from its f32
+    size_t src_per_image = 0;                         // input: max|x| (after the input ReLU) * bound
+    int src_relu = 0;
+    float bound = 1.f;
+    std::vector<std::function<int(int)>> apply;       // re-derive the device parameters that carry 2^-e / 2^e
+    std::function<int(hipStream_t)> clear;            // optional: zero the padding a measurement would otherwise scan
+  };
+  std::vector<PlaneScale> pscales;
+  static constexpr float kRangeTarget = 4096.f;       // 16x below the f16 maximum: headroom for images unlike the calibration batch
+  float pmul(int pidx) const { return pidx >= 0 ? ldexpf(1.f, -pscales[pidx].exp) : 1.f; }
+  int set_plane_exp(int pidx, int e) {
+    pscales[pidx].exp = e;
+    for (auto& f : pscales[pidx].apply) XDET_TRY(f(e));
+    return XDET_OK;
+  }
+
   // ---- split-precision planes ----
   unsigned short* zeros = nullptr;
   int get_zeros() {
@@ -399,6 +466,17 @@ struct Plan {
     XDET_TRY(alloc_bytes(bytes, reinterpret_cast<void**>(&b->hi)));
     XDET_TRY(alloc_bytes(bytes, reinterpret_cast<void**>(&b->lo)));
     planes_bufs.push_back({b->hi, (int64_t)b->H * b->W, b->ld});
+    PlaneScale ps;
+    ps.hi = b->hi;
+    const int64_t pix = (int64_t)b->H * b->W;
+    const int ldp = b->ld;
+    ps.halves = [pix, ldp](int N) { return cdiv((int64_t)N * pix, 16) * 16 * ldp; };
+    // the last 16-pixel group of a batch smaller than max_batch also holds pixels of the next image, which only an
+    // earlier, larger batch ever wrote: zero the planes before a calibration measures them
+    unsigned short* hi_p = b->hi;
+    ps.clear = [hi_p, bytes](hipStream_t st) { XDET_HIP(hipMemsetAsync(hi_p, 0, bytes, st)); return (int)XDET_OK; };
+    b->pidx = (int)pscales.size();
+    pscales.push_back(ps);
     return get_zeros();
   }
   // element-wise f32 -> (hi, lo) f16 planes (optionally through a ReLU) for a tensor whose producer
@@ -408,8 +486,9 @@ struct Plan {
     out->hi = out->lo = nullptr;
     XDET_TRY(new_planes(out));
     const Buf i = in, o = *out;
+    pscales[o.pidx].name = name;
     ops.push_back({name, stage, 0.0, [=](int N, hipStream_t s) {
-                     return launch_split_f32(i.p, o.hi, o.lo, (int64_t)N * i.H * i.W, i.ld, relu, s);
+                     return launch_split_f32(i.p, o.hi, o.lo, (int64_t)N * i.H * i.W, i.ld, relu, s, pmul(o.pidx));
                    }});
     return XDET_OK;
   }
@@ -461,14 +540,27 @@ struct Plan {
       XDET_TRY(new_planes(out));
       out->planes_relu = emit == 2;
       out->no_f32 = emit == 3;
+      pscales[out->pidx].name = name + " (planes of the output)";
+      const bool folded_bn = bsc != nullptr;
+      pscales[out->pidx].apply.push_back([L, folded_bn](int e) {
+        if (folded_bn && e != 0) {
+          set_last_error("calibrate: a planes copy with a folded BN cannot carry a pre-scale");
+          return (int)XDET_ERR_UNSUPPORTED;
+        }
+        return folded_bn ? (int)XDET_OK : L->set_out_exp(e);
+      });
     }
+    if (in.hi && in.pidx >= 0) pscales[in.pidx].apply.push_back([L](int e) { return L->set_in_exp(e); });
     const Buf i = in, o = *out;
     const float* rp = res ? res->p : nullptr;
     const unsigned short* z = zeros;
     if (res) XDET_REQUIRE(res->H == Ho && res->W == Wo && res->ld == o.ld, "plan: residual shape mismatch");
     ops.push_back({name, stage, L->flops(in.H, in.W), [=](int N, hipStream_t s) {
+                     // the planes copy: relu(out * bn_scale + bn_shift) for a folded BN, else (relu?)(out) * 2^-out_exp
+                     const float* ps = bsc ? bsc : (L->out_exp ? L->d_pl_scale : nullptr);
+                     const float* ph = bsc ? bsh : (L->out_exp ? L->d_pl_shift : nullptr);
                      return L->forward(i.p, N, i.H, i.W, i.ld, o.no_f32 ? nullptr : o.p, o.ld, rp, relu_in, s, i.hi, i.lo,
-                                       z, o.hi, o.lo, (o.planes_relu || bsc) ? 1 : 0, bsc, bsh);
+                                       z, o.hi, o.lo, (o.planes_relu || bsc) ? 1 : 0, ps, ph);
                    }});
     return XDET_OK;
   }
@@ -480,6 +572,8 @@ struct Plan {
       *out = Buf();
       out->H = in.H; out->W = in.W; out->C = in.C; out->ld = in.ld;
       XDET_TRY(new_planes(out));
+      pscales[out->pidx].name = name;
+      pscales[out->pidx].apply.push_back([L](int e) { return L->set_out_exp(e); });
       const Buf i = in, o = *out;
       ops.push_back({name, stage, 0.0, [=](int N, hipStream_t s) {
                        return launch_depthwise3x3_split(i.p, L->d_w, o.hi, o.lo, N, i.H, i.W, i.C, i.ld, L->dil,
@@ -539,9 +633,10 @@ struct Plan {
       Buf sub;
       sub.H = (in.H + 1) / 2; sub.W = (in.W + 1) / 2; sub.C = in.C; sub.ld = in.ld; sub.no_f32 = true;
       XDET_TRY(new_planes(&sub));
+      pscales[sub.pidx].name = name + "/subsample_split";
       const Buf i = in, o = sub;
       ops.push_back({name + "/subsample_split", stage, 0.0, [=](int N, hipStream_t s) {
-                       return launch_split_f32_subsample2(i.p, o.hi, o.lo, N, i.H, i.W, i.ld, s, pre_sc, pre_sh);
+                       return launch_split_f32_subsample2(i.p, o.hi, o.lo, N, i.H, i.W, i.ld, s, pre_sc, pre_sh, pmul(o.pidx));
                      }});
       return add_conv(name, stage, sub, L, res, 0, out);
     }
@@ -551,6 +646,7 @@ struct Plan {
     if (patch_conv3x3 && L->dma_capable() && in.hi && !in.planes_relu && !relu_in && !res && emit_planes_next == 0 &&
         in.ld == 32 && conv3x3_patch_supported(k, k, in.C, L->cout_pad, stride, 1, pad_mode) && L->cout_pad == L->ld_out()) {
       XDET_TRY(new_buf(in.H - 2, in.W - 2, cout, out));
+      if (in.pidx >= 0) pscales[in.pidx].apply.push_back([L](int e) { return L->set_in_exp(e); });
       const Buf i = in, o = *out;
       ops.push_back({name + " [LDS-staged tile]", stage, L->flops(in.H, in.W), [=](int N, hipStream_t s) {
                        return launch_conv3x3_patch(i.hi, i.lo, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale, L->d_shift, o.p, N, i.H,
@@ -581,6 +677,25 @@ struct Plan {
     // two-kernel form below, which the wide 30x30 layers keep (their GEMM needs the big MFMA tiles).
     if (fuse_sepconv && L->dma_capable() && !res && emit_planes_next == 0 && !in.no_f32 &&
         sepconv_fused_supported(in.ld, L->cout_pad, dilation) && L->ld_out() <= L->cout_pad) {
+      {
+        // the depthwise result is split on the CU and never reaches HBM: its range is bounded from the block input,
+        // |dw[c]| <= max|relu?(x)| * sum_t |w[t, c]|, and the pre-scale rides in the taps / the pointwise epilogue scale
+        PlaneScale ps;
+        ps.name = name + " (depthwise result inside the fused block)";
+        ps.src = in.p;
+        ps.src_per_image = in.per_image();
+        ps.src_relu = pre_relu;
+        float bound = 0.f;
+        for (int c = 0; c < in.C; ++c) {
+          float a = 0.f;
+          for (int t = 0; t < 9; ++t) a += std::fabs(dk->v[(size_t)t * in.C + c]);
+          bound = std::max(bound, a);
+        }
+        ps.bound = bound;
+        ps.apply.push_back([D](int e) { return D->set_out_exp(e); });
+        ps.apply.push_back([L](int e) { return L->set_in_exp(e); });
+        pscales.push_back(ps);
+      }
       if (pool_res && fuse_hpool && in.H * in.W >= pool_fuse_min_pixels) {
         int Ho, Wo, pt, pl;
         same_pad(in.H, 3, 2, 1, &pt, &Ho);
@@ -712,6 +827,15 @@ struct LightHeadNet : Plan {
       x = Buf();
       x.H = x.W = (S - 3) / 2 + 1; x.C = 32; x.ld = 32; x.no_f32 = true;
       XDET_TRY(new_planes(&x));
+      pscales[x.pidx].name = "block1_conv1 [stem]";
+      pscales[x.pidx].apply.push_back([=](int e) {     // relu(x*sc + sh) * 2^-e = relu(x*(sc 2^-e) + sh 2^-e), exactly
+        std::vector<float> a(sc), b(sh);
+        for (float& v : a) v = ldexpf(v, -e);
+        for (float& v : b) v = ldexpf(v, -e);
+        XDET_HIP(hipMemcpy(d_sc, a.data(), 32 * 4, hipMemcpyHostToDevice));
+        XDET_HIP(hipMemcpy(d_sh, b.data(), 32 * 4, hipMemcpyHostToDevice));
+        return (int)XDET_OK;
+      });
       const Buf o = x;
       stem_direct = true;
       ops.push_back({"block1_conv1 [stem, NCHW in]", ST_BODY, 2.0 * o.H * o.W * 27.0 * 32.0, [=](int N, hipStream_t st) {
@@ -880,13 +1004,13 @@ struct LightHeadNet : Plan {
     }
     std::vector<float> tf, ti;
     spectral_tables(F, &tf, &ti);
-    float *d_tf, *d_ti, *d_ones, *d_ba, *d_sc, *d_sh;
+    float *d_tf, *d_tf_b, *d_ti, *d_ones, *d_ba, *d_sc, *d_sh;
     auto up = [&](const std::vector<float>& h, float** d) {
       XDET_TRY(alloc_bytes(h.size() * 4, reinterpret_cast<void**>(d), false));
       XDET_HIP(hipMemcpy(*d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
       return (int)XDET_OK;
     };
-    XDET_TRY(up(tf, &d_tf)); XDET_TRY(up(ti, &d_ti)); XDET_TRY(up(ones, &d_ones)); XDET_TRY(up(ba, &d_ba));
+    XDET_TRY(up(tf, &d_tf)); XDET_TRY(up(tf, &d_tf_b)); XDET_TRY(up(ti, &d_ti)); XDET_TRY(up(ones, &d_ones)); XDET_TRY(up(ba, &d_ba));
     XDET_TRY(up(sc, &d_sc)); XDET_TRY(up(sh, &d_sh));
     // workspace, sized for max_batch: rows of every bin are padded to a whole number of 256-row GEMM tiles
     const size_t mp_max = (size_t)round_up(max_batch * F, 256), rows = (size_t)NB * mp_max;
@@ -917,6 +1041,39 @@ struct LightHeadNet : Plan {
       });
     }
     const std::string pre = "large_sep_feature/Branch_0+1/";
+    {
+      // activation pre-scale of the DFT-domain operands: the forward transform is linear, so 2^-e rides in its table
+      // (one copy per transform) and 2^e in the per-bin GEMM's epilogue scale.  These are the tensors with the least
+      // headroom: a bin sums up to F samples, and the second one transforms an un-normalised 15-tap conv output.
+      auto mpad_ps = [F](int N) { return N * F <= 128 ? 128 : round_up(N * F, 256); };
+      const std::vector<float> tf_host = tf;
+      PlaneScale pa, pb;
+      pa.name = pre + "conv2d/dft_y (DFT-domain planes)";
+      pa.hi = xa_hi;
+      pa.halves = [=](int N) { return (int64_t)NB * mpad_ps(N) * 2 * cin_ld; };
+      pa.apply.push_back([=](int e) {
+        std::vector<float> t(tf_host);
+        for (float& v : t) v = ldexpf(v, -e);
+        XDET_HIP(hipMemcpy(d_tf, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+        return LA->set_in_exp(e);
+      });
+      pb.name = pre + "conv2d_1/dft_x (DFT-domain planes)";
+      pb.hi = xb_hi;
+      pb.halves = [=](int N) { return (int64_t)NB * mpad_ps(N) * 2 * mid2; };
+      pb.apply.push_back([=](int e) {
+        std::vector<float> t(tf_host);
+        for (float& v : t) v = ldexpf(v, -e);
+        XDET_HIP(hipMemcpy(d_tf_b, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+        return LB->set_in_exp(e);
+      });
+      // rows [N*F, m_pad) of a bin are padding that only an earlier, larger batch ever wrote: a measurement over
+      // whole bins must not see that batch's (possibly overflowed) values
+      const size_t bytes_a = rows * 2 * cin_ld * 2, bytes_b = rows * 2 * mid2 * 2;
+      pa.clear = [=](hipStream_t st) { XDET_HIP(hipMemsetAsync(xa_hi, 0, bytes_a, st)); return (int)XDET_OK; };
+      pb.clear = [=](hipStream_t st) { XDET_HIP(hipMemsetAsync(xb_hi, 0, bytes_b, st)); return (int)XDET_OK; };
+      pscales.push_back(pa);
+      pscales.push_back(pb);
+    }
     const double fl_a = 2.0 * F * F * (double)cin * mid2 * 15, fl_b = 2.0 * F * F * (double)mid2 * co * 15;
     // rows per bin: whole 256-row GEMM tiles; a single image or two (N*F <= 128) get the 128-row tile instead
     auto mpad = [F](int N) { return N * F <= 128 ? 128 : round_up(N * F, 256); };
@@ -933,7 +1090,7 @@ struct LightHeadNet : Plan {
                      return launch_dft_inv(y1, F, 2 * mid2, mid2, N, mpad(N), d_ti, d_ones, d_ba, 0, tmid, mid2, 0, s);
                    }});
     ops.push_back({pre + "conv2d_1/dft_x", ST_LSEP, -1.0, [=](int N, hipStream_t s) {
-                     return launch_dft_fwd(tmid, F, mid2, 1, N, mpad(N), d_tf, xb_hi, xb_lo, s);
+                     return launch_dft_fwd(tmid, F, mid2, 1, N, mpad(N), d_tf_b, xb_hi, xb_lo, s);
                    }});
     ops.push_back({pre + "conv2d_1 [spectral]", ST_LSEP, fl_b, [=](int N, hipStream_t s) {
                      return LB->forward(nullptr, 1, 1, NB * mpad(N), 2 * mid2, y2, 2 * co_ld, nullptr, 0, s, xb_hi, xb_lo,
@@ -1070,6 +1227,93 @@ struct LightHeadNet : Plan {
     return launch_bboxes_eval(cls_reg.p, cls_reg.ld, head_boxes, N, cfg.rpn_post_nms_top_n, cfg.num_classes,
                               shapes ? shapes : def_shapes, bbox ? bbox : def_bbox, cfg.image_size, cfg.image_size,
                               cfg.select_threshold, cfg.nms_threshold, cfg.nms_topk, ds, db, s, prop_ws.bad);
+  }
+  void drop_graphs() {
+    for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+    graphs.clear();
+    graph_order.clear();
+  }
+  // Choose the activation pre-scale exponents from a calibration batch (Plan::pscales).  Pass by pass: run the forward,
+  // take the largest magnitude of every split-precision operand (as stored, i.e. already scaled), and raise the exponent
+  // of the tensors above kRangeTarget.  A tensor that overflowed (inf / NaN in its hi plane) invalidates everything
+  // computed from it, so a pass stops adjusting at the first such tensor (+8 binades) and the next pass re-measures.
+  // Nets whose activations stay below the target keep every exponent at 0: nothing changes, bit for bit.
+  int calibrate(const float* images, int N, hipStream_t s, int* n_scaled) {
+    XDET_TRY(check(N));
+    XDET_REQUIRE(images != nullptr, "calibrate: images is NULL");
+    if (n_scaled) *n_scaled = 0;
+    if (net_precision == PREC_F32 || pscales.empty()) return XDET_OK;
+    drop_graphs();                                   // graphs bake kernel arguments (the split passes' multipliers)
+    const size_t slots = (size_t)N * (cfg.num_classes - 1) * cfg.nms_topk;
+    float *ds = nullptr, *db = nullptr;
+    unsigned* d_max = nullptr;
+    XDET_HIP(hipMalloc(reinterpret_cast<void**>(&ds), slots * 4));
+    XDET_HIP(hipMalloc(reinterpret_cast<void**>(&db), slots * 16));
+    XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_max), pscales.size() * sizeof(unsigned)));
+    std::vector<unsigned> h_max(pscales.size());
+    int rc = XDET_OK;
+    for (const PlaneScale& p : pscales)
+      if (p.clear && rc == XDET_OK) rc = p.clear(s);
+    const int max_passes = (int)pscales.size() + 4;
+    const bool verbose = getenv("XDET_CALIBRATE_VERBOSE") != nullptr;
+    int pass = 0;
+    for (; pass < max_passes && rc == XDET_OK; ++pass) {
+      if ((rc = hipMemsetAsync(d_max, 0, pscales.size() * sizeof(unsigned), s) == hipSuccess ? XDET_OK : XDET_ERR_HIP) != XDET_OK) break;
+      if ((rc = forward_eager(images, N, nullptr, nullptr, ds, db, s)) != XDET_OK) break;
+      for (size_t i = 0; i < pscales.size() && rc == XDET_OK; ++i) {
+        const PlaneScale& p = pscales[i];
+        rc = p.hi ? launch_absmax_planes(p.hi, p.halves(N), d_max + i, s)
+                  : launch_absmax_f32(p.src, (int64_t)N * (int64_t)p.src_per_image, p.src_relu, d_max + i, s);
+      }
+      if (rc != XDET_OK) break;
+      if (hipMemcpyAsync(h_max.data(), d_max, h_max.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess ||
+          hipStreamSynchronize(s) != hipSuccess) { rc = XDET_ERR_HIP; break; }
+      bool changed = false;
+      for (size_t i = 0; i < pscales.size() && rc == XDET_OK; ++i) {
+        const PlaneScale& p = pscales[i];
+        float m;                                     // magnitude of the operand as the MFMAs would see it now
+        bool broken;
+        if (p.hi) {
+          broken = h_max[i] >= 0x7c00u;
+          m = broken ? 0.f : f16_to_f32((unsigned short)h_max[i]);
+        } else {
+          broken = h_max[i] >= 0x7f800000u;
+          float x;
+          memcpy(&x, &h_max[i], 4);
+          m = broken ? 0.f : ldexpf(x * p.bound, -p.exp);
+          if (!broken && !(m <= 3.0e38f)) broken = true;
+        }
+        if (verbose && (broken || m > kRangeTarget))
+          fprintf(stderr, "xdet calibrate: pass %d  %-70s exp %d  max %s%g\n", pass, p.name.c_str(), p.exp,
+                  broken ? "inf/NaN " : "", (double)m);
+        if (broken) {
+          rc = set_plane_exp((int)i, p.exp + 8);
+          changed = true;
+          break;                                     // downstream tensors were computed from garbage: re-measure
+        }
+        if (m > kRangeTarget) {
+          int e = 0;
+          (void)frexpf(m / kRangeTarget, &e);        // m / target in [2^(e-1), 2^e)
+          rc = set_plane_exp((int)i, p.exp + e);
+          changed = true;
+        }
+      }
+      if (!changed) break;
+    }
+    (void)hipFree(ds);
+    (void)hipFree(db);
+    (void)hipFree(d_max);
+    XDET_TRY(rc);
+    if (pass >= max_passes) {
+      set_last_error("calibrate: the activation ranges did not settle (non-finite inputs or weights?)");
+      return XDET_ERR_STATE;
+    }
+    if (n_scaled) {
+      int n = 0;
+      for (const PlaneScale& p : pscales) n += p.exp != 0;
+      *n_scaled = n;
+    }
+    return XDET_OK;
   }
   int forward_eager(const float* images, int N, const int* shapes, const float* bbox, float* ds, float* db,
                     hipStream_t s) {
@@ -1672,6 +1916,26 @@ int xdet_net_forward(void* net, const float* images, int N, const int* image_sha
     it = n->graphs.find(key);
   }
   XDET_HIP(hipGraphLaunch(it->second, s));
+  return XDET_OK;
+}
+
+int xdet_net_calibrate(void* net, const float* images, int N, int* n_scaled, void* stream) {
+  LightHeadNet* n = static_cast<LightHeadNet*>(net);
+  XDET_REQUIRE(n, "net is NULL");
+  DeviceGuard guard(n->device);
+  return n->calibrate(images, N, S(stream), n_scaled);
+}
+int xdet_net_plane_scales(void* net, int max_n, int* n_out, int* exps) {
+  LightHeadNet* n = static_cast<LightHeadNet*>(net);
+  XDET_REQUIRE(n && n->built && n_out, "plane_scales: bad arguments");
+  *n_out = (int)n->pscales.size();
+  for (int i = 0; exps && i < max_n && i < *n_out; ++i) exps[i] = n->pscales[i].exp;
+  return XDET_OK;
+}
+int xdet_net_plane_scale_name(void* net, int idx, char* buf, int buflen) {
+  LightHeadNet* n = static_cast<LightHeadNet*>(net);
+  XDET_REQUIRE(n && n->built && buf && buflen > 0 && idx >= 0 && idx < (int)n->pscales.size(), "plane_scale_name: bad arguments");
+  snprintf(buf, buflen, "%s", n->pscales[idx].name.c_str());
   return XDET_OK;
 }
 

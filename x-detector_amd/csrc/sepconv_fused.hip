@@ -144,7 +144,13 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
   if (t_begin >= t_end) return;
   const int KC = p.ld >> 5;                       // channel chunks = K steps
 
-  for (int i = tid; i < 9 * p.ld; i += 256) s_w[i] = p.w9c[i];
+  // taps in LDS as [9][SF_KMAX]: a COMPILE-TIME row stride, so the nine tap reads of a chunk are one address register
+  // plus immediate offsets (with the tensor's runtime channel stride the compiler kept nine per-lane address registers
+  // and their nine bases alive across the chunk loop -- the registers the one-pass form was short of)
+  for (int i = tid; i < 9 * p.ld; i += 256) {
+    const int t = i / p.ld;
+    s_w[t * SF_KMAX + (i - t * p.ld)] = p.w9c[i];
+  }
 
   // ---- tile walk: N-pass fastest (same patch again, from L2), then ty, tx, image ----
   struct Coord { int nt, ty, tx, n; };
@@ -272,8 +278,8 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
         sf_f32x4 a[NP];
 #pragma unroll
         for (int k = 0; k < NP; ++k) a[k] = (sf_f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
+        auto tap_row = [&](auto KY) {
+          constexpr int ky = decltype(KY)::value;
           sf_f32x4 col[NP + 2], ww[3];
           const unsigned ra = t_addr + ky * (SF_ROW_F * 4), rb = t_hi + ky * (SF_ROW_F * 4);
           if (NP == 4) {
@@ -286,8 +292,9 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
             col[0] = sf_ds_read_f4<256>(ra); col[1] = sf_ds_read_f4<384>(ra); col[2] = sf_ds_read_f4<0>(rb);
             col[3] = sf_ds_read_f4<128>(rb);
           }
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) ww[kx] = sf_ds_read_f4<0>(w_addr + (unsigned)((ky * 3 + kx) * p.ld * 4));
+          ww[0] = sf_ds_read_f4<(ky * 3 + 0) * SF_KMAX * 4>(w_addr);
+          ww[1] = sf_ds_read_f4<(ky * 3 + 1) * SF_KMAX * 4>(w_addr);
+          ww[2] = sf_ds_read_f4<(ky * 3 + 2) * SF_KMAX * 4>(w_addr);
           if (NP == 4)
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(col[0]), "+v"(col[1]), "+v"(col[2]), "+v"(col[3]), "+v"(col[NP]), "+v"(col[NP + 1]),
@@ -309,7 +316,10 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
               a[k].x = fmaf(col[k + kx].x, ww[kx].x, a[k].x); a[k].y = fmaf(col[k + kx].y, ww[kx].y, a[k].y);
               a[k].z = fmaf(col[k + kx].z, ww[kx].z, a[k].z); a[k].w = fmaf(col[k + kx].w, ww[kx].w, a[k].w);
             }
-        }
+        };
+        tap_row(std::integral_constant<int, 0>{});
+        tap_row(std::integral_constant<int, 1>{});
+        tap_row(std::integral_constant<int, 2>{});
         // -- split into f16 hi/lo, A tile rows wave*32 + pxb + k (chunk-permuted like the conv kernel's DMA layout) --
 #pragma unroll
         for (int k = 0; k < NP; ++k) {

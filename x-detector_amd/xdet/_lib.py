@@ -112,6 +112,9 @@ SIGNATURES = {
     'xdet_net_head_decode': (c_int, [c_void_p, c_int, c_void_p]),
     'xdet_net_bboxes_eval': (c_int, [c_void_p, c_int, PI, PF, PF, PF, c_void_p]),
     'xdet_net_forward': (c_int, [c_void_p, PF, c_int, PI, PF, PF, PF, c_int, c_void_p]),
+    'xdet_net_calibrate': (c_int, [c_void_p, PF, c_int, ctypes.POINTER(c_int), c_void_p]),
+    'xdet_net_plane_scales': (c_int, [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    'xdet_net_plane_scale_name': (c_int, [c_void_p, c_int, ctypes.c_char_p, c_int]),
     'xdet_net_graph_count': (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     'xdet_net_flops_per_image': (c_int, [c_void_p] + [ctypes.POINTER(c_double)] * 4),
     'xdet_profile_enable': (c_int, [c_void_p, c_int, c_int]),
@@ -159,7 +162,12 @@ def lib():
             os.environ.update(ipc_env())
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(l, name)      # AttributeError if the symbol is not exported
+            try:
+                fn = getattr(l, name)  # AttributeError if the symbol is not exported
+            except AttributeError:
+                if os.environ.get('XDET_LIB'):
+                    continue           # an older build loaded for an A/B measurement: it simply lacks the newer entries
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = l

@@ -114,6 +114,28 @@ class LightHeadDetector(object):
                                      det_scores_ptr or self._det_scores.ptr, det_boxes_ptr or self._det_boxes.ptr,
                                      1 if use_graph else 0, self.stream.handle))
 
+    def calibrate(self, images_nchw):
+        """Choose the activation pre-scale of the split-precision operands from a calibration batch (whitened f32
+        [N,3,S,S], N <= max_batch): tensors whose magnitude comes near the f16 range of the hi/lo planes get a
+        power-of-two exponent (planes hold x * 2^-e, folded back exactly by the consumer).  Returns {name: e} of the
+        tensors that were scaled -- empty for a net whose activations are small, which then stays bit-identical."""
+        n = self.set_images(images_nchw)
+        k = ctypes.c_int()
+        check(lib().xdet_net_calibrate(self.handle, self._images.ptr, n, ctypes.byref(k), self.stream.handle))
+        return {name: e for name, e in self.plane_scales().items() if e}
+
+    def plane_scales(self):
+        cnt = ctypes.c_int()
+        check(lib().xdet_net_plane_scales(self.handle, 0, ctypes.byref(cnt), None))
+        ex = (ctypes.c_int * max(cnt.value, 1))()
+        check(lib().xdet_net_plane_scales(self.handle, cnt.value, ctypes.byref(cnt), ex))
+        buf = ctypes.create_string_buffer(256)
+        out = {}
+        for i in range(cnt.value):
+            check(lib().xdet_net_plane_scale_name(self.handle, i, buf, 256))
+            out['%d: %s' % (i, buf.value.decode())] = ex[i]
+        return out
+
     def detections(self, n=None):
         n = n or self._N
         nc, k = self.num_classes - 1, self.nms_topk
