@@ -176,3 +176,44 @@ def test_grad_errors():
         xdet.ps_roi_align_grad(feat, np.zeros((1, 2, 4), np.float32), z[:, :1], z.astype(np.int32), 2, 2, 'max')
     out = xdet.ps_roi_align_grad(feat, np.zeros((1, 2, 4), np.float32), z + 1, z.astype(np.int32), 2, 2, 'max')
     assert not out.any()          # all rois degenerate -> zero gradient
+
+
+@pytest.mark.parametrize('method', ['max', 'mean'])
+def test_randomized_sweep_against_the_c_oracle(method, oracle):
+    """both forms of the kernel (one channel per lane: NCHW; two channels per lane with 8-byte
+    corner loads: the net's NHWC form) against the C oracle on ~2.7e7 (element, sample) blends per method and form (1.1e8 in all): 24,000
+    random ROIs of every size class on the net's 30x30x490 map -- 1-pixel, sub-bin, border-clamped, full-image,
+    near-degenerate, centres on the map edge -- values AND argmax indices bit for bit."""
+    import xdet
+    from xdet._lib import lib, check
+    from xdet.runtime import DeviceBuffer, to_device, to_host
+    rng = np.random.default_rng(20260928)
+    n, h, w, g = 8, 30, 30, 7
+    c = 10 * g * g
+    feat = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    r = 3000
+    cy, cx = rng.uniform(0.0, 1.0, (n, r)), rng.uniform(0.0, 1.0, (n, r))
+    size = np.exp(rng.uniform(np.log(1e-3), np.log(1.2), (n, r, 2)))          # 0.03 px ... larger than the image
+    rois = np.stack([cy, cx, size[..., 0], size[..., 1]], -1).astype(np.float32)
+    rois[:, :50, 2:] = 1.0 / 30                                                 # exactly one pixel
+    rois[:, 50:60] = [0.5, 0.5, 1.0, 1.0]                                        # the whole image
+    rois[:, 60:70, :2] = [0.0, 1.0]                                              # centred on a corner
+    rois[:, 70:75, 2] = 0.0                                                      # degenerate: zero output
+    p, i = xdet.ps_roi_align(feat, rois, g, g, method)
+    po, io = oracle.ps_roi_align(feat, rois, g, g, method)
+    samples = (np.floor(np.clip(rois[..., 2], 1 / 30, 1) * h / g) + 1) * (np.floor(np.clip(rois[..., 3], 1 / 30, 1) * w / g) + 1)
+    print('%s: %d ROIs, ~%.2e (element, sample) blends per form' % (method, n * r, float(samples.sum()) * c))
+    assert np.array_equal(p, po)
+    assert np.array_equal(i, io)
+    # the same ROIs through the NHWC / padded-stride form the net runs (two channels per lane)
+    ldc = 512
+    nhwc = np.zeros((n, h, w, ldc), np.float32)
+    nhwc[..., :c] = feat.transpose(0, 2, 3, 1)
+    d_f, d_r = to_device(nhwc), to_device(rois)
+    d_p, d_i = DeviceBuffer(n * r * ldc * 4, zero=True), DeviceBuffer(n * r * ldc * 4, zero=True)
+    check(lib().xdet_psroialign_fwd(d_f.ptr, d_r.ptr, d_p.ptr, d_i.ptr, n, c, h, w, r, g, g, 1 if method == 'max' else 0,
+                                    1, ldc, ldc, 0, None))
+    p2 = to_host(d_p.ptr, (n, r, ldc), np.float32)[..., :c].reshape(n, r, g * g, 10)
+    i2 = to_host(d_i.ptr, (n, r, ldc), np.int32)[..., :c].reshape(n, r, g * g, 10)
+    assert np.array_equal(p2, po)
+    assert np.array_equal(i2, io)

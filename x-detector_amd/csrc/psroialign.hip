@@ -13,6 +13,8 @@
 // all elements of an ROI) is computed once per wave from scalar loads.  layout 0 = NCHW (the op's public contract), 1 = NHWC with channel stride ldc.
 #include "common.h"
 #include <cfloat>
+#include <cstdlib>
+#include <cstring>
 
 namespace xdet {
 
@@ -22,6 +24,11 @@ __device__ __forceinline__ float feat_at(const float* __restrict__ f, int layout
   return f[((n * H + y) * W + x) * ldc + c];
 }
 
+// VEC = channels per lane: 1 (any layout), or 2 for the NHWC form with an even bank -- a lane then owns two neighbouring
+// channels of one bin and takes each bilinear corner as ONE 8-byte load.  The kernel is bound by the address path of its
+// gathers (four per sample and element, every wave instruction touching ~7 different lines), not by the f64 blend: halving
+// the load instructions is what pays (a sample-table variant with 2.3x fewer vector instructions was SLOWER).
+template <int VEC>
 __global__ __launch_bounds__(256) void psroialign_fwd_kernel(const float* __restrict__ feat,
                                                              const float* __restrict__ rois,
                                                              float* __restrict__ pooled, int32_t* __restrict__ index,
@@ -85,15 +92,40 @@ __global__ __launch_bounds__(256) void psroialign_fwd_kernel(const float* __rest
   constexpr int JMAX = 8;
   const int sy = layout == 0 ? W : W * ldc, sx = layout == 0 ? 1 : ldc, sc = layout == 0 ? H * W : 1;
   const float* __restrict__ fimg = feat + (size_t)n * H * W * ldc;       // NCHW: ldc == C
-  for (int e = lane; e < C; e += 64) {
+  typedef float vecf __attribute__((ext_vector_type(VEC)));
+  auto ldv = [&](int off) {
+    vecf r;
+    if (VEC == 1) r[0] = fimg[off];
+    else r = *reinterpret_cast<const vecf*>(fimg + off);                   // 8-byte aligned: even offset (launch check)
+    return r;
+  };
+  for (int ev = lane; ev * VEC < C; ev += 64) {
+    const int e = ev * VEC;              // first of this lane's VEC channels (all in one bin: VEC divides bank)
     const int pos = e / bank;
     const int row = pos / gw;
     const int col = pos - row * gw;
     const int c_in = e;                  // pos*bank + ch
     const float x0 = xmin + bin_w * (float)col;
     const float y0 = ymin + bin_h * (float)row;
-    float acc = use_max ? -FLT_MAX : 0.f;
-    int arg = 0;
+    float acc[VEC];
+    int arg[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      acc[u] = use_max ? -FLT_MAX : 0.f;
+      arg[u] = 0;
+    }
+    auto blend = [&](double w00, double w10, double w01, float fxfy, vecf f00, vecf f10, vecf f01, vecf f11, int sidx) {
+#pragma unroll
+      for (int u = 0; u < VEC; ++u) {
+        const double v = w00 * f00[u] + w10 * f10[u] + w01 * f01[u] + fxfy * f11[u];
+        const float t = (float)v;
+        if (use_max) {
+          if (acc[u] < t) { acc[u] = t; arg[u] = sidx; }
+        } else {
+          acc[u] += t;
+        }
+      }
+    };
     if (n_w <= JMAX) {
       const int coff = c_in * sc;
       int xo0[JMAX], xo1[JMAX];
@@ -121,14 +153,9 @@ __global__ __launch_bounds__(256) void psroialign_fwd_kernel(const float* __rest
 #pragma unroll
         for (int j = 0; j < JMAX; ++j) {
           if (j < n_w) {
-            const float f00 = fimg[yo0 + xo0[j]], f10 = fimg[yo1 + xo0[j]], f01 = fimg[yo0 + xo1[j]], f11 = fimg[yo1 + xo1[j]];
-            const double v = wx0[j] * wy0 * f00 + wx0[j] * wy1 * f10 + wx1[j] * wy0 * f01 + fxs[j] * fy * f11;
-            const float t = (float)v;
-            if (use_max) {
-              if (acc < t) { acc = t; arg = n_w * i + j; }
-            } else {
-              acc += t;
-            }
+            const vecf f00 = ldv(yo0 + xo0[j]), f10 = ldv(yo1 + xo0[j]), f01 = ldv(yo0 + xo1[j]), f11 = ldv(yo1 + xo1[j]);
+            // (1.-fx)*(1.-fy)*f00 + (1.-fx)*fy*f10 + fx*(1.-fy)*f01 in double, fx*fy*f11 in float, summed left to right
+            blend(wx0[j] * wy0, wx0[j] * wy1, wx1[j] * wy0, fxs[j] * fy, f00, f10, f01, f11, n_w * i + j);
           }
         }
       }
@@ -143,22 +170,20 @@ __global__ __launch_bounds__(256) void psroialign_fwd_kernel(const float* __rest
           const int ix = (int)x;
           const float fx = x - (float)ix;
           const int ix1 = min(ix + 1, W - 1);
-          const double v = (1. - fx) * (1. - fy) * feat_at(feat, layout, ldc, H, W, n, c_in, iy, ix) +
-                           (1. - fx) * fy * feat_at(feat, layout, ldc, H, W, n, c_in, iy1, ix) +
-                           fx * (1. - fy) * feat_at(feat, layout, ldc, H, W, n, c_in, iy, ix1) +
-                           fx * fy * feat_at(feat, layout, ldc, H, W, n, c_in, iy1, ix1);
-          const float t = (float)v;
-          if (use_max) {
-            if (acc < t) { acc = t; arg = n_w * i + j; }
-          } else {
-            acc += t;
-          }
+          const int coff = c_in * sc;
+          const vecf f00 = ldv(iy * sy + ix * sx + coff), f10 = ldv(iy1 * sy + ix * sx + coff);
+          const vecf f01 = ldv(iy * sy + ix1 * sx + coff), f11 = ldv(iy1 * sy + ix1 * sx + coff);
+          blend((1. - fx) * (1. - fy), (1. - fx) * fy, fx * (1. - fy), fx * fy, f00, f10, f01, f11, n_w * i + j);
         }
       }
     }
-    if (!use_max) acc /= (float)(n_h * n_w);
-    prow[e] = acc;
-    if (irow) irow[e] = use_max ? arg : 0;
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      float a = acc[u];
+      if (!use_max) a /= (float)(n_h * n_w);
+      prow[e + u] = a;
+      if (irow) irow[e + u] = use_max ? arg[u] : 0;
+    }
   }
 }
 
@@ -173,9 +198,17 @@ int launch_psroialign(const float* feat, const float* rois, float* pooled, int32
   XDET_REQUIRE(ldc >= C && out_ld >= C, "channel strides must be >= C");
   if ((int64_t)N * R == 0) return XDET_OK;
   const int64_t blocks = cdiv(N, 8) * 8 * cdiv(R, 4);   // image n on XCD n & 7 (see the kernel)
-  hipLaunchKernelGGL(psroialign_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, feat, rois, pooled,
-                     index, N, C, H, W, R, gw, gh, use_max, layout, layout == 0 ? C : ldc, out_ld,
-                     rois_are_corners);
+  // two channels per lane (8-byte corner loads) where the layout allows it: NHWC, even bank and channel stride,
+  // 8-byte aligned map; XDET_PSROI=element forces the one-channel form (A/B measurements)
+  static const bool force1 = getenv("XDET_PSROI") && !strcmp(getenv("XDET_PSROI"), "element");
+  const int bank = C / (gw * gh);
+  if (!force1 && layout == 1 && bank % 2 == 0 && ldc % 2 == 0 && reinterpret_cast<uintptr_t>(feat) % 8 == 0)
+    hipLaunchKernelGGL(psroialign_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, feat, rois, pooled,
+                       index, N, C, H, W, R, gw, gh, use_max, layout, ldc, out_ld, rois_are_corners);
+  else
+    hipLaunchKernelGGL(psroialign_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, feat, rois, pooled,
+                       index, N, C, H, W, R, gw, gh, use_max, layout, layout == 0 ? C : ldc, out_ld,
+                       rois_are_corners);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }
