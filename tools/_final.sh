@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+TAG=${1:-r03a}
+bash tools/collect_profile.sh ${TAG} --ways 1 --batch 128 > /dev/null 2>&1
+bash tools/bench_lines.sh ${TAG}
+python bench.py > gpurun_out/profiles/${TAG}_bench_default_full.json 2> /dev/null
+python bench.py --no-cpu-baseline --no-parity --comm --voc-stream > gpurun_out/profiles/${TAG}_bench_comm_voc_world1.json 2>/dev/null
+ls gpurun_out/profiles | grep ${TAG} | head -40
