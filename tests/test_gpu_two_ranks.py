@@ -1,0 +1,176 @@
+"""The N > 1 code of libxdet_hip.so with TWO rank processes on the one GPU of the box.  RCCL refuses two ranks on one
+device, so the ranks load a test double (tests/fake_rccl: the eight RCCL entry points over a shared-memory segment,
+collectives enqueued on the caller's stream like the real ones) through XDET_RCCL_LIB.  Everything else is the product:
+xdet.launch (rank environment, id file), csrc/comm.hip (rendezvous, ncclCommInitRank, pack kernel + all-gather with the
+event protocol, scalar collectives, byte all-gather, watchdog), xdet.dist, bench.py's aggregation.  What this cannot
+show is that RCCL's own transports work between GPUs -- only that nothing on OUR side of the collective is wrong when
+world > 1 (a world-size-1 all-gather degenerates to a copy and hides rank-major layout / rendezvous / timing bugs)."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def fake_rccl():
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'fake_rccl'))
+    import build as fb
+    return fb.build()
+
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %(pkg)r)
+from xdet import dist as xd, weights as W
+from xdet._lib import lib, check
+from xdet.model import LightHeadDetector
+from xdet.runtime import DeviceBuffer, set_precision
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+check(lib().xdet_set_device(0))                      # both ranks share the box's one GPU
+comm = xd.Communicator(rank, world, timeout_s=120)
+assert comm.info()['rccl_version'] == 99999          # the test double, not RCCL
+B, S, R, nc, k = 3, 256, 50, 20, 200
+G = world * B
+imgs = W.synthetic_images(G, S, seed=31)
+lo, hi = xd.shard_range(G, rank, world)
+w = W.make_lighthead_weights(1234)
+set_precision('f16x3')
+det = LightHeadDetector(w, image_size=S, max_batch=G, rpn_post_nms_top_n=R)
+# reference: this rank also computes the WHOLE global batch by itself
+det.forward(imgs, use_graph=True)
+ref_s, ref_b = det.detections(G)
+pairs = [(DeviceBuffer(B * nc * k * 4, zero=True), DeviceBuffer(B * nc * k * 16, zero=True)) for _ in range(2)]
+det.set_images(imgs[lo:hi])
+for step in range(4):                                # back-to-back steps, alternating buffer pairs, no host sync
+    ds, db = pairs[step & 1]
+    det.forward_device(hi - lo, use_graph=True, det_scores_ptr=ds.ptr, det_boxes_ptr=db.ptr)
+    comm.allgather_detections(ds.ptr, db.ptr, hi - lo, nc, k, streams=[det.stream], double_buffered=True)
+g = comm.gathered()
+s, b = xd.unpack_detections(g)
+ok = g.shape == (G, nc, k, 5) and np.array_equal(s, ref_s) and np.array_equal(b, ref_b)   # rank-major == global order
+mx = comm.max_over_ranks(1.5 + rank)
+comm.barrier()
+recs = comm.device_records({'images_per_sec': 100.0 + rank})
+blobs = comm.allgather_bytes(bytes([rank]) * 64)
+out = {'rank': rank, 'ok': bool(ok), 'max': mx, 'ranks': [r['rank'] for r in recs], 'pci': [r['pci_bus_id'] for r in recs],
+       'pids': [r['pid'] for r in recs], 'rates': [r['images_per_sec'] for r in recs], 'blobs': [list(set(x)) for x in blobs],
+       'n_det': int((s > 0).sum())}
+open(os.path.join(%(out)r, 'rank_%%d.json' %% rank), 'w').write(json.dumps(out))
+comm.close()
+'''
+
+
+def _env(fake):
+    env = dict(os.environ, XDET_RCCL_LIB=fake, XDET_BIND_NUMA='0', XDET_OVERSUBSCRIBE_GPUS='1')
+    env.pop('RANK', None)
+    return env
+
+
+def test_two_ranks_gather_their_shards_in_rank_major_order(fake_rccl, tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % {'pkg': os.path.join(ROOT, 'x-detector_amd'), 'out': str(tmp_path)})
+    code = ('import sys; sys.path.insert(0, %r); from xdet.launch import launch_ranks; '
+            'sys.exit(launch_ranks([sys.executable, %r], 2, timeout=600))' % (os.path.join(ROOT, 'x-detector_amd'), str(script)))
+    p = subprocess.run([sys.executable, '-c', code], env=_env(fake_rccl), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    res = [json.load(open(tmp_path / ('rank_%d.json' % r))) for r in range(2)]
+    for r in res:
+        assert r['ok'], r                                    # every rank holds the whole global batch, in global order
+        assert r['max'] == 2.5                               # max over ranks
+        assert r['ranks'] == [0, 1] and r['blobs'] == [[0], [1]]
+        assert r['rates'] == [100.0, 101.0]
+        assert r['pci'][0] == r['pci'][1] and r['pids'][0] != r['pids'][1]      # two processes, one physical GPU
+        assert r['n_det'] > 100
+
+
+def test_bench_with_two_ranks(fake_rccl):
+    """`python bench.py --gpus 2`: the script spawns its two ranks itself; rank 0 prints ONE JSON line whose value is the
+    images of BOTH ranks over the max-over-ranks time."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--batch', '16', '--no-cpu-baseline', '--no-parity', '--no-roofline'], env=_env(fake_rccl),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 32 and d['scaling'] == 'weak'
+    c = d['comm']
+    assert c['world'] == 2 and c['ranks_seen'] == [0, 1] and c['distinct_gpus'] == 1      # honest: one physical GPU here
+    assert c['gathered_shape'] == [32, 20, 200, 5] and c['gathered_images_with_detections'] == 32
+    assert len(c['per_rank_images_per_sec']) == 2 and min(c['per_rank_images_per_sec']) > 0
+    # value = all ranks' images / the slowest rank's time: never above the sum of the per-rank rates
+    assert d['value'] <= sum(c['per_rank_images_per_sec']) * 1.001
+    assert abs(d['value'] - 2 * 16 * 3 / (d['ms_per_step'] * 3e-3)) < 1e-2 * d['value']
+
+
+def test_a_dead_peer_is_a_timeout_not_a_hang(fake_rccl, tmp_path):
+    """rank 1 disappears between two collectives; rank 0's next gather can never complete.  The communicator's watchdog
+    turns that into an error within XDET_COMM_TIMEOUT_S, the rank exits non-zero and the launcher returns -- instead
+    of rank 0 sitting in hipStreamSynchronize until someone notices."""
+    script = tmp_path / 'worker.py'
+    script.write_text(r'''
+import os, sys, time
+sys.path.insert(0, %(pkg)r)
+from xdet import dist as xd
+from xdet._lib import lib, check, XdetError
+from xdet.runtime import DeviceBuffer
+rank = int(os.environ['RANK'])
+check(lib().xdet_set_device(0))
+comm = xd.Communicator(rank, 2, timeout_s=120)
+ds, db = DeviceBuffer(20 * 200 * 4, zero=True), DeviceBuffer(20 * 200 * 16, zero=True)
+comm.allgather_detections(ds.ptr, db.ptr, 1, 20, 200)
+comm.wait()                                           # one healthy collective
+if rank == 1:
+    os._exit(0)                                       # gone, without a goodbye (exit code 0: only the hang can tell)
+time.sleep(1.0)
+comm.allgather_detections(ds.ptr, db.ptr, 1, 20, 200)
+t0 = time.time()
+try:
+    comm.wait()
+except XdetError as e:
+    open(os.path.join(%(out)r, 'watchdog.txt'), 'w').write('%%.1f %%s' %% (time.time() - t0, e))
+    os._exit(17)
+os._exit(0)
+''' % {'pkg': os.path.join(ROOT, 'x-detector_amd'), 'out': str(tmp_path)})
+    code = ('import sys; sys.path.insert(0, %r); from xdet.launch import launch_ranks; '
+            'sys.exit(launch_ranks([sys.executable, %r], 2, timeout=300))' % (os.path.join(ROOT, 'x-detector_amd'), str(script)))
+    t0 = time.time()
+    p = subprocess.run([sys.executable, '-c', code], env=dict(_env(fake_rccl), XDET_COMM_TIMEOUT_S='5'),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    dt = time.time() - t0
+    assert p.returncode == 17, (p.returncode, p.stderr.decode()[-2000:])
+    msg = open(tmp_path / 'watchdog.txt').read()
+    assert 'no progress on the communicator stream' in msg and 'aborted its communicator' in msg, msg
+    assert 4.0 <= float(msg.split()[0]) < 30.0 and dt < 120, (msg, dt)
+
+
+def test_bench_under_torch_distributed_run(fake_rccl):
+    """the driver's SCALE command line, verbatim, at N = 2: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- torch only launches; every rank is
+    bench.py, which imports no torch and finds its peers through the id file named after MASTER_PORT + the agent's pid."""
+    pytest.importorskip('torch')
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3',
+                        '--warmup', '1', '--batch', '16', '--no-cpu-baseline', '--no-parity', '--no-roofline'],
+                       env=_env(fake_rccl), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['comm']['world'] == 2 and d['comm']['ranks_seen'] == [0, 1]
+    assert d['comm']['gathered_shape'] == [32, 20, 200, 5] and d['value'] > 0

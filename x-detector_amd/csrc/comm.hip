@@ -62,9 +62,18 @@ static int load_rccl() {
   if (g_rccl.handle) return XDET_OK;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
+  // XDET_RCCL_LIB: another build of RCCL -- or the test double of tests/fake_rccl, which lets two rank processes run
+  // this file's N > 1 code on a one-GPU box (RCCL refuses two ranks on one device)
+  if (const char* over = getenv("XDET_RCCL_LIB")) {
+    h = dlopen(over, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) {
+      set_last_error(std::string("cannot load XDET_RCCL_LIB=") + over + ": " + dlerror());
+      return XDET_ERR_STATE;
+    }
+  }
   for (const char* n : names) {
-    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     if (h) break;
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
   }
   if (!h) {
     set_last_error(std::string("cannot load librccl.so: ") + dlerror());
