@@ -24,17 +24,93 @@ __device__ __forceinline__ float feat_at(const float* __restrict__ f, int layout
   return f[((n * H + y) * W + x) * ldc + c];
 }
 
+// Corner de-duplication for small bins (two-channel form).  A bin's n_h x n_w samples are less than a pixel apart
+// (step = bin / (int(bin) + 1) < 1), so their 4 n_h n_w bilinear corners fall on at most (n_h+1) x (n_w+1) distinct
+// pixels starting at the first sample's (iy, ix): 9 instead of 16 gathers for 2 x 2 samples, 16 instead of 36 for 3 x 3
+// -- and the gathers' address path is what bounds the kernel.  The lane loads that pixel grid once (8 bytes each) into its
+// own column of a small LDS array ([entry][lane]: conflict-free, no cross-lane traffic, no barrier) and takes every
+// sample's four corners from there at a per-lane index (registers cannot be indexed per lane; select chains measured
+// slower in round 2).  The clamped neighbours min(iy + 1, H - 1) / min(ix + 1, W - 1) are the grid's own clamped rows /
+// columns.  Values, order and typing of the blend are the kernel's: bit-exact.  Returns false (nothing accumulated) if a
+// sample's pixel does not lie within `its index` of the first one -- cannot happen for step < 1 in exact arithmetic; the
+// caller then takes the direct path.
+template <int NH, int NW, bool USE_MAX>
+__device__ __forceinline__ bool psroi_grid_bin(const float* __restrict__ fimg, float2* __restrict__ grid, int H, int W, int sy,
+                                               int sx, int coff, float x0, float y0, float step_w, float step_h, double half_w,
+                                               double half_h, float (&acc)[2], int (&arg)[2]) {
+  constexpr bool use_max = USE_MAX;
+  int bx[NW], by[NH];
+  float fx[NW], fy[NH];
+  int ix0 = 0, iy0 = 0;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const float x = (float)((double)(x0 + step_w * (float)j) + half_w);
+    const int ix = (int)x;
+    fx[j] = x - (float)ix;
+    if (j == 0) ix0 = ix;
+    bx[j] = ix - ix0;
+    ok = ok && (unsigned)bx[j] <= (unsigned)j;
+  }
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    const float y = (float)((double)(y0 + step_h * (float)i) + half_h);
+    const int iy = (int)y;
+    fy[i] = y - (float)iy;
+    if (i == 0) iy0 = iy;
+    by[i] = iy - iy0;
+    ok = ok && (unsigned)by[i] <= (unsigned)i;
+  }
+  if (!ok) return false;
+#pragma unroll
+  for (int a = 0; a <= NH; ++a) {
+    const int ro = min(iy0 + a, H - 1) * sy + coff;
+#pragma unroll
+    for (int b = 0; b <= NW; ++b)
+      grid[(a * (NW + 1) + b) * 64] = *reinterpret_cast<const float2*>(fimg + ro + min(ix0 + b, W - 1) * sx);
+    if (NH * NW > 4) __builtin_amdgcn_sched_barrier(0);      // one grid row in flight at a time (registers)
+  }
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    const double wy0 = 1. - fy[i], wy1 = fy[i];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const float2* g = grid + (by[i] * (NW + 1) + bx[j]) * 64;
+      const float2 f00 = g[0], f01 = g[64], f10 = g[(NW + 1) * 64], f11 = g[(NW + 2) * 64];
+      const double wx0 = 1. - fx[j], wx1 = fx[j];
+      const double w00 = wx0 * wy0, w10 = wx0 * wy1, w01 = wx1 * wy0;
+      const float fxfy = fx[j] * fy[i];
+      const float a00[2] = {f00.x, f00.y}, a10[2] = {f10.x, f10.y}, a01[2] = {f01.x, f01.y}, a11[2] = {f11.x, f11.y};
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const double v = w00 * a00[u] + w10 * a10[u] + w01 * a01[u] + fxfy * a11[u];
+        const float t = (float)v;
+        if (use_max) {
+          if (acc[u] < t) { acc[u] = t; arg[u] = NW * i + j; }
+        } else {
+          acc[u] += t;
+        }
+      }
+      if (NH * NW > 6) __builtin_amdgcn_sched_barrier(0);     // larger grids: one sample at a time (registers)
+    }
+    if (NH * NW > 4) __builtin_amdgcn_sched_barrier(0);
+  }
+  return true;
+}
+
 // VEC = channels per lane: 1 (any layout), or 2 for the NHWC form with an even bank -- a lane then owns two neighbouring
 // channels of one bin and takes each bilinear corner as ONE 8-byte load.  The kernel is bound by the address path of its
 // gathers (four per sample and element, every wave instruction touching ~7 different lines), not by the f64 blend: halving
 // the load instructions is what pays (a sample-table variant with 2.3x fewer vector instructions was SLOWER).
-template <int VEC>
-__global__ __launch_bounds__(256) void psroialign_fwd_kernel(const float* __restrict__ feat,
+template <int VEC, bool USE_MAX>
+__global__ __launch_bounds__(256, 4) void psroialign_fwd_kernel(const float* __restrict__ feat,
                                                              const float* __restrict__ rois,
                                                              float* __restrict__ pooled, int32_t* __restrict__ index,
                                                              int N, int C, int H, int W, int R, int gw, int gh,
-                                                             int use_max, int layout, int ldc, int out_ld,
-                                                             int corners) {
+                                                             int layout, int ldc, int out_ld, int corners, int dedup) {
+  constexpr int use_max = USE_MAX ? 1 : 0;
+  // pixel grids of psroi_grid_bin: [wave][entry <= 16][lane] (two-channel form only)
+  __shared__ __attribute__((aligned(8))) float2 s_grid[VEC == 2 ? 4 * 16 * 64 : 1];
   const int bank = C / (gw * gh);
   const int lane = threadIdx.x & 63;
   // XCD-aware ROI order.  Workgroups are dealt round-robin to the 8 XCDs (private L2s); with ROIs numbered
@@ -99,21 +175,14 @@ __global__ __launch_bounds__(256) void psroialign_fwd_kernel(const float* __rest
     else r = *reinterpret_cast<const vecf*>(fimg + off);                   // 8-byte aligned: even offset (launch check)
     return r;
   };
-  for (int ev = lane; ev * VEC < C; ev += 64) {
-    const int e = ev * VEC;              // first of this lane's VEC channels (all in one bin: VEC divides bank)
+  // one element (VEC channels of one bin) by direct corner loads: the general path
+  auto element_direct = [&](int e, float (&acc)[VEC], int (&arg)[VEC]) {
     const int pos = e / bank;
     const int row = pos / gw;
     const int col = pos - row * gw;
     const int c_in = e;                  // pos*bank + ch
     const float x0 = xmin + bin_w * (float)col;
     const float y0 = ymin + bin_h * (float)row;
-    float acc[VEC];
-    int arg[VEC];
-#pragma unroll
-    for (int u = 0; u < VEC; ++u) {
-      acc[u] = use_max ? -FLT_MAX : 0.f;
-      arg[u] = 0;
-    }
     auto blend = [&](double w00, double w10, double w01, float fxfy, vecf f00, vecf f10, vecf f01, vecf f11, int sidx) {
 #pragma unroll
       for (int u = 0; u < VEC; ++u) {
@@ -130,7 +199,7 @@ __global__ __launch_bounds__(256) void psroialign_fwd_kernel(const float* __rest
       const int coff = c_in * sc;
       int xo0[JMAX], xo1[JMAX];
       float fxs[JMAX];
-      double wx0[JMAX], wx1[JMAX];
+      double wx0[JMAX];                  // (fx as a double is one conversion at the use: 16 registers less)
 #pragma unroll
       for (int j = 0; j < JMAX; ++j) {
         if (j < n_w) {                   // wave-uniform
@@ -141,7 +210,6 @@ __global__ __launch_bounds__(256) void psroialign_fwd_kernel(const float* __rest
           xo1[j] = min(ix + 1, W - 1) * sx + coff;
           fxs[j] = fx;
           wx0[j] = 1. - fx;
-          wx1[j] = fx;
         }
       }
       for (int i = 0; i < n_h; ++i) {
@@ -155,7 +223,7 @@ __global__ __launch_bounds__(256) void psroialign_fwd_kernel(const float* __rest
           if (j < n_w) {
             const vecf f00 = ldv(yo0 + xo0[j]), f10 = ldv(yo1 + xo0[j]), f01 = ldv(yo0 + xo1[j]), f11 = ldv(yo1 + xo1[j]);
             // (1.-fx)*(1.-fy)*f00 + (1.-fx)*fy*f10 + fx*(1.-fy)*f01 in double, fx*fy*f11 in float, summed left to right
-            blend(wx0[j] * wy0, wx0[j] * wy1, wx1[j] * wy0, fxs[j] * fy, f00, f10, f01, f11, n_w * i + j);
+            blend(wx0[j] * wy0, wx0[j] * wy1, (double)fxs[j] * wy0, fxs[j] * fy, f00, f10, f01, f11, n_w * i + j);
           }
         }
       }
@@ -177,6 +245,8 @@ __global__ __launch_bounds__(256) void psroialign_fwd_kernel(const float* __rest
         }
       }
     }
+  };
+  auto finish = [&](int e, const float (&acc)[VEC], const int (&arg)[VEC]) {
 #pragma unroll
     for (int u = 0; u < VEC; ++u) {
       float a = acc[u];
@@ -184,6 +254,65 @@ __global__ __launch_bounds__(256) void psroialign_fwd_kernel(const float* __rest
       prow[e + u] = a;
       if (irow) irow[e + u] = use_max ? arg[u] : 0;
     }
+  };
+
+  // two separate element loops (not one loop with two bodies): the register allocation is then the larger of the two
+  // paths, not their union
+  // wave-uniform: bins whose pixel grid (n_h + 1) x (n_w + 1) fits the 16 LDS entries of a lane, corners de-duplicated
+  if (VEC == 2 && USE_MAX && dedup && n_h * n_w > 1 && (n_h + 1) * (n_w + 1) <= 16 && n_h <= 5 && n_w <= 5) {   // (max only: the mean form has no registers to spare)
+    float2* grid = s_grid + (threadIdx.x >> 6) * (16 * 64) + lane;
+    bool declined = false;
+    for (int ev = lane; ev * VEC < C; ev += 64) {
+      const int e = ev * VEC;
+      const int pos = e / bank;
+      const int row = pos / gw;
+      const int col = pos - row * gw;
+      const float x0 = xmin + bin_w * (float)col;
+      const float y0 = ymin + bin_h * (float)row;
+      float a2[2] = {use_max ? -FLT_MAX : 0.f, use_max ? -FLT_MAX : 0.f};
+      int g2[2] = {0, 0};
+      bool done = false;
+#define XDET_PSROI_GRID(NH, NW)                                                                                             \
+  case NH * 8 + NW:                                                                                                         \
+    done = psroi_grid_bin<NH, NW, USE_MAX>(fimg, grid, H, W, sy, sx, e * sc, x0, y0, step_w, step_h, half_w, half_h, a2, g2); \
+    break;
+      switch (n_h * 8 + n_w) {
+        XDET_PSROI_GRID(1, 2) XDET_PSROI_GRID(1, 3) XDET_PSROI_GRID(2, 1) XDET_PSROI_GRID(2, 2) XDET_PSROI_GRID(2, 3)
+        XDET_PSROI_GRID(3, 1) XDET_PSROI_GRID(3, 2) XDET_PSROI_GRID(3, 3)
+        XDET_PSROI_GRID(1, 4) XDET_PSROI_GRID(2, 4) XDET_PSROI_GRID(4, 1) XDET_PSROI_GRID(4, 2)
+        XDET_PSROI_GRID(1, 5) XDET_PSROI_GRID(5, 1)
+        default: break;
+      }
+#undef XDET_PSROI_GRID
+      // psroi_grid_bin declines a bin only if float rounding put a sample further from the first one than its index
+      // (never in exact arithmetic).  Then the whole ROI is redone by the direct loop below -- results are written per
+      // element and do not depend on the path, so the elements already stored are simply stored again.
+      if (__builtin_amdgcn_ballot_w64(!done) != 0) {
+        declined = true;
+        break;
+      }
+      float acc[VEC];
+      int arg[VEC];
+#pragma unroll
+      for (int u = 0; u < VEC; ++u) {
+        acc[u] = a2[u & 1];
+        arg[u] = g2[u & 1];
+      }
+      finish(e, acc, arg);
+    }
+    if (!declined) return;
+  }
+  for (int ev = lane; ev * VEC < C; ev += 64) {
+    const int e = ev * VEC;              // first of this lane's VEC channels (all in one bin: VEC divides bank)
+    float acc[VEC];
+    int arg[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      acc[u] = use_max ? -FLT_MAX : 0.f;
+      arg[u] = 0;
+    }
+    element_direct(e, acc, arg);
+    finish(e, acc, arg);
   }
 }
 
@@ -201,14 +330,17 @@ int launch_psroialign(const float* feat, const float* rois, float* pooled, int32
   // two channels per lane (8-byte corner loads) where the layout allows it: NHWC, even bank and channel stride,
   // 8-byte aligned map; XDET_PSROI=element forces the one-channel form (A/B measurements)
   static const bool force1 = getenv("XDET_PSROI") && !strcmp(getenv("XDET_PSROI"), "element");
+  static const int dedup = !(getenv("XDET_PSROI") && !strcmp(getenv("XDET_PSROI"), "nogrid"));
   const int bank = C / (gw * gh);
-  if (!force1 && layout == 1 && bank % 2 == 0 && ldc % 2 == 0 && reinterpret_cast<uintptr_t>(feat) % 8 == 0)
-    hipLaunchKernelGGL(psroialign_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, feat, rois, pooled,
-                       index, N, C, H, W, R, gw, gh, use_max, layout, ldc, out_ld, rois_are_corners);
-  else
-    hipLaunchKernelGGL(psroialign_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, feat, rois, pooled,
-                       index, N, C, H, W, R, gw, gh, use_max, layout, layout == 0 ? C : ldc, out_ld,
-                       rois_are_corners);
+  const bool two = !force1 && layout == 1 && bank % 2 == 0 && ldc % 2 == 0 && reinterpret_cast<uintptr_t>(feat) % 8 == 0;
+  const int cs = layout == 0 ? C : ldc;
+#define XDET_PSROI_LAUNCH(V, M)                                                                                        \
+  hipLaunchKernelGGL((psroialign_fwd_kernel<V, M>), dim3((unsigned)blocks), dim3(256), 0, s, feat, rois, pooled, index, N, C, \
+                     H, W, R, gw, gh, layout, cs, out_ld, rois_are_corners, (V) == 2 ? dedup : 0)
+  if (two && use_max) XDET_PSROI_LAUNCH(2, true);       // the net's form ('max', NHWC); 'mean' keeps one channel per lane
+  else if (use_max) XDET_PSROI_LAUNCH(1, true);
+  else XDET_PSROI_LAUNCH(1, false);
+#undef XDET_PSROI_LAUNCH
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }
