@@ -41,29 +41,43 @@ int launch_ext_decode_rois(const float* rois, const float* reg, int ld_reg, int6
   return XDET_OK;
 }
 
-__device__ __forceinline__ bool iou_gt_d(const float4 a, const float4 b, float thr) {
+// IoU(a, b) > thr as tf.image.non_max_suppression decides it (corners min/max-normalised, zero when either area is <= 0,
+// strict >), without a division on the fast path (as proposals.hip's iou_gt_fast): the correctly rounded
+// quotient can only disagree with the product test inside a 1e-5 relative band around the threshold, and only there
+// is the division evaluated.  The per-class NMS mask is ~45,000 IoUs per (image, class) workgroup.
+__device__ __forceinline__ bool iou_gt_fast_d(const float4 a, const float4 b, float thr) {
   const float ay0 = fminf(a.x, a.z), ay1 = fmaxf(a.x, a.z), ax0 = fminf(a.y, a.w), ax1 = fmaxf(a.y, a.w);
   const float by0 = fminf(b.x, b.z), by1 = fmaxf(b.x, b.z), bx0 = fminf(b.y, b.w), bx1 = fmaxf(b.y, b.w);
+  const float ih = fminf(ay1, by1) - fmaxf(ay0, by0);
+  const float iw = fminf(ax1, bx1) - fmaxf(ax0, bx0);
+  if (ih <= 0.f || iw <= 0.f) return false;          // no overlap: IoU = 0 <= thr (thr >= 0)
   const float aa = (ay1 - ay0) * (ax1 - ax0);
   const float ab = (by1 - by0) * (bx1 - bx0);
   if (aa <= 0.f || ab <= 0.f) return false;
-  const float ih = fmaxf(fminf(ay1, by1) - fmaxf(ay0, by0), 0.f);
-  const float iw = fmaxf(fminf(ax1, bx1) - fmaxf(ax0, bx0), 0.f);
   const float inter = ih * iw;
-  return inter / ((aa + ab) - inter) > thr;
+  const float uni = (aa + ab) - inter;
+  const float t = thr * uni;
+  if (inter > t * 1.00001f) return true;
+  if (inter < t * 0.99999f) return false;
+  return inter / uni > thr;
 }
 
-__device__ __forceinline__ u64 shfl_u64d(u64 v, int src) {
-  const unsigned lo = __shfl((unsigned)v, src), hi = __shfl((unsigned)(v >> 32), src);
+// lane `src` (wave-uniform) of a 64-bit value as a scalar: v_readlane, not a ds_bpermute round trip (proposals.hip)
+__device__ __forceinline__ u64 readlane_u64d(u64 v, int src) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
   return ((u64)hi << 32) | lo;
 }
 
 constexpr int EV_MAXR = 1024;   // ROIs per image supported by one workgroup
 constexpr int EV_MAXS = 512;    // 2*nms_topk upper bound (sorted candidates)
 constexpr int EV_W = EV_MAXS / 64;
+constexpr int EV_T = 1024;      // threads per workgroup
 
-// grid (num_classes-1, N), 256 threads
-__global__ __launch_bounds__(256) void bboxes_eval_kernel(const float* __restrict__ cls, int ld_cls,
+// grid (num_classes-1, N), EV_T threads.  One workgroup per (image, class) is all the parallelism a single image offers
+// (20 workgroups on 256 CUs), so the workgroup is as wide as it can be: the rank sort and the IoU mask are spread over
+// 16 waves instead of 4 (single-image latency; at large batches the total work is what counts and is unchanged).
+__global__ __launch_bounds__(EV_T) void bboxes_eval_kernel(const float* __restrict__ cls, int ld_cls,
                                                           const float* __restrict__ boxes, int R, int num_classes,
                                                           const int* __restrict__ image_shapes,
                                                           const float* __restrict__ bbox_img, int net_h, int net_w,
@@ -94,7 +108,7 @@ __global__ __launch_bounds__(256) void bboxes_eval_kernel(const float* __restric
   const float sx = ref.z - ref.x, sy = ref.w - ref.y;   // bboxes_resize scale (h, w)
 
   int local_valid = 0, local_bad = bad_per_image ? bad_per_image[n] : 0;   // (proposal stage: non-finite RPN outputs)
-  for (int r = tid; r < R; r += 256) {
+  for (int r = tid; r < R; r += EV_T) {
     const float* lg = cls + ((int64_t)n * R + r) * ld_cls;
     float m = lg[0];
     float lsum = lg[0];
@@ -136,7 +150,7 @@ __global__ __launch_bounds__(256) void bboxes_eval_kernel(const float* __restric
   const int max_sorted = min(2 * nms_topk, EV_MAXS);
   const int n_sorted = min(s_nvalid, max_sorted);            // bboxes_sort: top_k(min(n, 2*topk))
   // rank sort (descending score, ties -> lower ROI index)
-  for (int r = tid; r < R; r += 256) {
+  for (int r = tid; r < R; r += EV_T) {
     const u64 mine = keys[r];
     if (mine == 0ull) continue;
     int rank = 0;
@@ -150,14 +164,14 @@ __global__ __launch_bounds__(256) void bboxes_eval_kernel(const float* __restric
 
   // NMS bitmask: bit (i,j) for j > i
   const int w64 = (n_sorted + 63) / 64;
-  for (int t = tid; t < n_sorted * w64; t += 256) {
+  for (int t = tid; t < n_sorted * w64; t += EV_T) {
     const int i = t / w64, wq = t - i * w64;
     u64 bits = 0ull;
     const float4 me = sbox[i];
     const int jend = min(64, n_sorted - wq * 64);
     for (int j = 0; j < jend; ++j) {
       const int col = wq * 64 + j;
-      if (col > i && iou_gt_d(me, sbox[col], nms_thr)) bits |= 1ull << j;
+      if (col > i && iou_gt_fast_d(me, sbox[col], nms_thr)) bits |= 1ull << j;
     }
     mask[i * EV_W + wq] = bits;
   }
@@ -171,12 +185,12 @@ __global__ __launch_bounds__(256) void bboxes_eval_kernel(const float* __restric
     for (int cch = 0; cch < w64 && n_keep < nms_topk; ++cch) {
       const int i = cch * 64 + lane;
       const u64 diag = i < n_sorted ? mask[i * EV_W + cch] : 0ull;
-      u64 cur = shfl_u64d(removed, cch);
-      const int lim = min(64, n_sorted - cch * 64);
+      u64 cur = readlane_u64d(removed, cch);                   // scalar chain: cur, keepmask, row b are wave-uniform
+      const int lim = __builtin_amdgcn_readfirstlane(min(64, n_sorted - cch * 64));
       u64 keepmask = 0ull;
       int kc = n_keep;
       for (int b = 0; b < lim && kc < nms_topk; ++b) {
-        const u64 d = shfl_u64d(diag, b);
+        const u64 d = readlane_u64d(diag, b);
         if (!((cur >> b) & 1ull)) { keepmask |= 1ull << b; cur |= d; ++kc; }
       }
       if ((keepmask >> lane) & 1ull) s_keptidx[n_keep + __popcll(keepmask & ((1ull << lane) - 1ull))] = i;
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(256) void bboxes_eval_kernel(const float* __restric
   const int n_keep = s_nkeep;
   float* os = det_scores + ((int64_t)n * (num_classes - 1) + (c - 1)) * nms_topk;
   float* ob = det_boxes + ((int64_t)n * (num_classes - 1) + (c - 1)) * nms_topk * 4;
-  for (int k = tid; k < nms_topk; k += 256) {
+  for (int k = tid; k < nms_topk; k += EV_T) {
     float s = 0.f;
     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < n_keep) {
@@ -217,7 +231,7 @@ int launch_bboxes_eval(const float* cls, int ld_cls, const float* boxes, int N, 
   XDET_REQUIRE(nms_topk > 0 && 2 * nms_topk <= EV_MAXS, "bboxes_eval: nms_topk must be in 1..256");
   XDET_REQUIRE(num_classes >= 2 && num_classes <= ld_cls, "bboxes_eval: bad num_classes");
   if (N == 0) return XDET_OK;
-  hipLaunchKernelGGL(bboxes_eval_kernel, dim3(num_classes - 1, N), dim3(256), 0, s, cls, ld_cls, boxes, R,
+  hipLaunchKernelGGL(bboxes_eval_kernel, dim3(num_classes - 1, N), dim3(EV_T), 0, s, cls, ld_cls, boxes, R,
                      num_classes, image_shapes, bbox_img, net_h, net_w, select_thr, nms_thr, nms_topk, det_scores,
                      det_boxes, bad_per_image);
   XDET_LAUNCH_CHECK();

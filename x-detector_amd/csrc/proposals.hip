@@ -217,10 +217,38 @@ __global__ __launch_bounds__(1024) void prop_sort_kernel(const u64* __restrict__
   int P = 64;
   while (P < L) P <<= 1;
   const u64* k = cand + (int64_t)n * n_anchor;
-  for (int i = tid; i < P; i += 1024) keys[i] = i < L ? k[i] : 0ull;
+  for (int i = tid; i < max(P, 512); i += 1024) keys[i] = i < L ? k[i] : 0ull;   // (a wave's block is 512 keys)
   __syncthreads();
-  for (int kk = 2; kk <= P; kk <<= 1)
-    for (int j = kk >> 1; j > 0; j >>= 1) {
+  // Bitonic network, wave-synchronous where it can be.  Wave w owns the 512 keys [512 w, 512 w + 512): every
+  // compare-exchange with a stride below 512 stays inside one wave's block, and the LDS operations of one wave execute
+  // in order -- those stages need no workgroup barrier at all, only the compiler kept from reordering across them.  Of the
+  // 91 stages of an 8192-key sort, 81 are of that kind; the barriers drop from 91 to 15: 139 -> 67 us per image (on the
+  // critical path of a single-image forward).  Measured and dropped: three strides per LDS pass with eight keys per thread
+  // in registers (35 passes instead of 91) -- 92 us: a thread's eight keys are 64 B apart for the small strides, a 16-way
+  // bank conflict on every ds_read_b64 / ds_write_b64 of a third of the passes.
+  const int lane = tid & 63, base = (tid >> 6) * 512;
+  auto wave_stages = [&](int kk, int j_first) {          // strides j_first, j_first / 2, ..., 1 of merge size kk
+    if (base < P) {
+      for (int j = j_first; j > 0; j >>= 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int pr = lane + 64 * q;                  // pair index inside the block
+          const int i = base + (((pr & ~(j - 1)) << 1) | (pr & (j - 1)));
+          const int o = i + j;
+          const u64 a = keys[i], b = keys[o];
+          const bool desc = (i & kk) == 0;
+          if (desc ? a < b : a > b) { keys[i] = b; keys[o] = a; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+  };
+  for (int kk = 2; kk <= min(P, 512); kk <<= 1) wave_stages(kk, kk >> 1);
+  __syncthreads();
+  for (int kk = 1024; kk <= P; kk <<= 1) {
+    for (int j = kk >> 1; j >= 512; j >>= 1) {
       for (int i = tid; i < P; i += 1024) {
         const int o = i ^ j;
         if (o > i) {
@@ -231,6 +259,9 @@ __global__ __launch_bounds__(1024) void prop_sort_kernel(const u64* __restrict__
       }
       __syncthreads();
     }
+    wave_stages(kk, 256);
+    __syncthreads();
+  }
   const int m = min(L, pre_n);
   for (int r = tid; r < m; r += 1024) {
     const u64 key = keys[r];
@@ -310,8 +341,17 @@ __device__ __forceinline__ bool iou_gt(const float4 a, const float4 b, float thr
   return inter / ((aa + ab) - inter) > thr;
 }
 
-__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
-  const unsigned lo = __shfl((unsigned)v, src), hi = __shfl((unsigned)(v >> 32), src);
+// value of lane `src` (wave-uniform) as a scalar: v_readlane_b32, a few cycles, where __shfl() is a ds_bpermute round
+// trip through the LDS crossbar (~50 cycles) -- the serial resolve below is a 64-step dependent chain of these, and it,
+// not the IoU tests, was what the kernel's time went into (124 us per image on the single-image critical path)
+__device__ __forceinline__ u64 readlane_u64(u64 v, int src) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 readfirstlane_u64(u64 v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
   return ((u64)hi << 32) | lo;
 }
 
@@ -336,25 +376,26 @@ __device__ __forceinline__ bool iou_gt_fast(const float4 a, const float4 b, floa
 }
 
 // ---------------------------------------------------------------------------------------
-// Greedy NMS against the KEPT list (one workgroup of 8 waves per image).  tf.image.non_max_suppression
+// Greedy NMS against the KEPT list (one workgroup of NMS_WAVES waves per image).  tf.image.non_max_suppression
 // only ever compares a candidate with boxes that were kept before it, and stops at max_output_size: with
 // R = 300 kept boxes that is <= 64 x 300 IoUs per 64-candidate chunk and a few dozen chunks.  (The first
 // version built the full upper-triangular IoU bit matrix chip-wide -- 5000^2 / 2 IoUs per image, 200 MB of
 // mask for 64 images -- and scanned it: ~25x the CU time.)  Per chunk of 64 candidates (score order):
-//   1. every wave tests the chunk against a strided eighth of the kept boxes (kept box broadcast from
+//   1. every wave tests the chunk against a strided 1/NMS_WAVES of the kept boxes (kept box broadcast from
 //      LDS, candidate b in lane b), one ballot per wave -> bits of candidates already suppressed;
-//   2. the 64 x 64 intra-chunk matrix, eight column-strided parts OR-ed through LDS;
+//   2. the 64 x 64 intra-chunk matrix, NMS_WAVES column-strided parts OR-ed through LDS;
 //   3. wave 0 resolves the chunk serially (wave-uniform shuffles) and appends the survivors to the
 //      kept list.
 // Comparisons are iou_gt_fast(earlier, later, thr), strict >, visited in score order.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void nms_greedy_kernel(const float* __restrict__ sboxes, int* __restrict__ counts,
+constexpr int NMS_WAVES = 16;   // the kept-list test of a chunk (64 candidates x n_keep boxes) is split over this many waves
+__global__ __launch_bounds__(64 * NMS_WAVES) void nms_greedy_kernel(const float* __restrict__ sboxes, int* __restrict__ counts,
                                                          int pre_n, int post_n, float thr, int* __restrict__ kept) {
   extern __shared__ __attribute__((aligned(16))) unsigned char nmsg_smem[];
   float4* kbox = reinterpret_cast<float4*>(nmsg_smem);          // [post_n] boxes kept so far
   __shared__ float4 cb[64];
-  __shared__ u64 part_sup[8];
-  __shared__ u64 part_diag[8][64];
+  __shared__ u64 part_sup[NMS_WAVES];
+  __shared__ u64 part_diag[NMS_WAVES][64];
   __shared__ int s_keep;
   const int n = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -374,26 +415,29 @@ __global__ __launch_bounds__(512) void nms_greedy_kernel(const float* __restrict
     // 1. against the kept list
     bool hit = false;
     if (lane < rows)
-      for (int k = wave; k < n_keep; k += 8)
+      for (int k = wave; k < n_keep; k += NMS_WAVES)
         if (iou_gt_fast(kbox[k], me, thr)) { hit = true; break; }
     const u64 hb = __ballot(hit);
     if (lane == 0) part_sup[wave] = hb;
     // 2. intra-chunk: does candidate `lane` suppress a later candidate j of the chunk?
     u64 bits = 0ull;
     if (lane < rows)
-      for (int j = lane + 1 + wave; j < rows; j += 8)
+      for (int j = lane + 1 + wave; j < rows; j += NMS_WAVES)
         if (iou_gt_fast(me, cb[j], thr)) bits |= 1ull << j;
     part_diag[wave][lane] = bits;
     __syncthreads();
     // 3. serial resolve of the chunk
     if (wave == 0) {
-      u64 cur = 0ull, diag = 0ull;
+      u64 cur_v = 0ull, diag = 0ull;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) { cur |= part_sup[w]; diag |= part_diag[w][lane]; }
+      for (int w = 0; w < NMS_WAVES; ++w) { cur_v |= part_sup[w]; diag |= part_diag[w][lane]; }
+      // the chain runs on the scalar unit: `cur`, `keepmask` and the row of candidate b are wave-uniform
+      u64 cur = readfirstlane_u64(cur_v);
       u64 keepmask = 0ull;
       int kc = n_keep;
-      for (int b = 0; b < rows && kc < post_n; ++b) {
-        const u64 d = shfl_u64(diag, b);
+      const int rows_u = __builtin_amdgcn_readfirstlane(rows);
+      for (int b = 0; b < rows_u && kc < post_n; ++b) {
+        const u64 d = readlane_u64(diag, b);
         if (!((cur >> b) & 1ull)) { keepmask |= 1ull << b; cur |= d; ++kc; }
       }
       if ((keepmask >> lane) & 1ull) {
@@ -452,7 +496,7 @@ int launch_get_proposals(const float* objectness, const float* boxes, int N, int
     XDET_REQUIRE((size_t)post_n * 16 <= 96 * 1024, "get_proposals: rpn_post_nms_top_n too large (max 6144)");
     static DeviceOnce once;
     XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(nms_greedy_kernel), 96 * 1024));
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3(N), dim3(512), (size_t)post_n * 16, s, ws.sboxes, ws.counts, pre_n, post_n,
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(N), dim3(64 * NMS_WAVES), (size_t)post_n * 16, s, ws.sboxes, ws.counts, pre_n, post_n,
                        nms_thr, ws.kept);
     XDET_LAUNCH_CHECK();
   }
