@@ -55,8 +55,10 @@ HBM_MIN_BYTES_PER_IMAGE = (136.4e6 + 1.7e6 + 5.9e6) * 4 + 1.76e6 + 1.2e6 + 80e3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    # defaults: ~7 s of timed GPU work at the default batch (a 1.4 s region is over before a 5 s utilisation sampler
+    # looks once), still well within a minute with the instrumented repeat and the CPU leg
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=256, help='images per GPU per step')
     ap.add_argument('--ways', type=int, default=2,
                     help='the batch runs as this many concurrent sub-batches (net instances on their own HIP '
@@ -396,12 +398,14 @@ def main():
     if comm is not None and args.workload == 'lighthead':
         gathered = comm.gathered()                   # [world*B, C, K, 5]: proves every rank's shard arrived
     rows = []
+    KI = K                                           # steps the per-op event pairs cover
     if not args.no_roofline:
         if not profile:
             step(graph=False, only_first=True)       # eager warm-up of the instrumented leg
             sync_all()
             check(lib().xdet_profile_enable(net.handle, kind, 1))
-            for _ in range(K):
+            KI = min(K, 20)                          # the instrumented repeat: 20 steps are plenty for per-op means
+            for _ in range(KI):
                 step(graph=False, only_first=True)
             sync_all()
         rows = read_profile(net.handle, kind)
@@ -462,9 +466,9 @@ def main():
                     'hbm_min_bytes_per_image': int(HBM_MIN_BYTES_PER_IMAGE + 44.7e6 * 4 / sb) if args.workload == 'lighthead' and S == 480 else None,
                     'hbm_over_min': (round(ctr['hbm_bytes_per_image'] / (HBM_MIN_BYTES_PER_IMAGE + 44.7e6 * 4 / sb), 3)
                                      if ctr and ctr.get('hbm_bytes_per_image') and args.workload == 'lighthead' and S == 480 else None),
-                    'launches_per_step': conv_launches // K,
+                    'launches_per_step': conv_launches // KI,
                     'avg_launch_us': round(conv_ms * 1e3 / max(conv_launches, 1), 2),
-                    'kernel_ms_per_step': round(conv_ms / K, 3), 'gflop_per_image': round(flops_img / 1e9, 2),
+                    'kernel_ms_per_step': round(conv_ms / KI, 3), 'gflop_per_image': round(flops_img / 1e9, 2),
                     # the un-instrumented view: every algorithmic FLOP of the step over the timed wall clock
                     'frac_whole_step': round(B * flops_img / (ms_per_step * 1e-3) / 1e12 / peak, 4),
                     'config': 'one_stream: one sub-batch of %d images alone on the chip' % sb,
@@ -519,8 +523,8 @@ def main():
             tot = sum(r[1] for r in rows)
             for name, ms, cnt, f, _ in sorted(rows, key=lambda r: -r[1]):
                 tf = (f * sb * cnt / (ms * 1e-3) / 1e12) if (ms > 0 and f > 0) else 0
-                sys.stderr.write('%-52s %8.3f ms/step %5.1f%%  %7.1f TFLOP/s\n' % (name, ms / K, 100 * ms / tot, tf))
-            sys.stderr.write('planned ops %.3f ms/step of %.3f ms/step\n' % (tot / K, ms_per_step))
+                sys.stderr.write('%-52s %8.3f ms/step %5.1f%%  %7.1f TFLOP/s\n' % (name, ms / KI, 100 * ms / tot, tf))
+            sys.stderr.write('planned ops %.3f ms/step of %.3f ms/step\n' % (tot / KI, ms_per_step))
         print(json.dumps(out))
         sys.stdout.flush()
     if comm is not None:

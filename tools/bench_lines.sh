@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/profiles
 mkdir -p $OUT
 cd $REPO
-B="python bench.py --no-cpu-baseline"
+B="python bench.py --no-cpu-baseline --steps 20 --warmup 3"
 $B --ops > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench_ops.txt
 $B --no-parity --ways 1 --batch 128 > $OUT/${TAG}_bench_1way_b128.json 2>/dev/null
 $B --no-parity --batch 128 > $OUT/${TAG}_bench_2x64.json 2>/dev/null
