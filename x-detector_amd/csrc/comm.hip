@@ -392,7 +392,9 @@ int xdet_comm_allgather_bytes(void* comm, const void* send_host, void* recv_host
   CommDeviceGuard guard(c->device);
   const size_t need = bytes * (size_t)(c->world + 1);
   if (need > c->d_bytes_cap) {
-    XDET_HIP(hipStreamSynchronize(c->stream));
+    // (drain under the watchdog: an earlier collective behind a dead peer must not hang the reallocation either)
+    XDET_HIP(hipEventRecord(c->ev_done, c->stream));
+    XDET_TRY(watchdog_wait(c, c->ev_done, "allgather_bytes"));
     if (c->d_bytes) (void)hipFree(c->d_bytes);
     c->d_bytes = nullptr;
     c->d_bytes_cap = 0;

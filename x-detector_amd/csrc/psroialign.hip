@@ -159,10 +159,11 @@ __global__ __launch_bounds__(256, 4) void psroialign_fwd_kernel(const float* __r
   const double half_w = (double)step_w / 2.;
   const double half_h = (double)step_h / 2.;
 
-  // The kernel is VALU-bound (a per-sample f64 blend plus index arithmetic; fetch traffic and load count were
-  // both ruled out by measurement), so everything that does not depend on the sample row is hoisted: 32-bit element
-  // offsets from a per-image base pointer, and the x geometry of a bin's <= JMAX sample columns (integer columns,
-  // fractions and their double-precision weights 1.-fx / fx) once per element instead of once per sample.  Every
+  // Direct path (one gather per bilinear corner).  Everything that does not depend on the sample row is hoisted: 32-bit
+  // element offsets from a per-image base pointer, and the x geometry of a bin's <= JMAX sample columns (integer columns,
+  // fractions and the double-precision weight 1.-fx) once per element instead of once per sample.  (Round 2 read the
+  // kernel as VALU-bound; round 3 showed the gathers' address path is the bound: fewer instructions did not help, fewer
+  // and wider gathers did -- VEC = 2 and psroi_grid_bin above.)  Every
   // expression keeps the reference's typing and order: (1.-fx)*(1.-fy)*f00 + (1.-fx)*fy*f10 + fx*(1.-fy)*f01 in
   // double, fx*fy*f11 in float, summed left to right.
   constexpr int JMAX = 8;
