@@ -79,6 +79,9 @@ def parse():
     ap.add_argument('--comm', action='store_true',
                     help='create the RCCL communicator and all-gather the detections every step even at one rank '
                          '(always on for N > 1 and under torch.distributed.run)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='multi-GPU pre-flight: rendezvous, ONE all-gather of the per-rank device records over the '
+                         'collective library, print them (ranks_seen, distinct_gpus, which library) and exit -- seconds')
     ap.add_argument('--serial-rpn', action='store_true',
                     help='keep the RPN / proposal branch on the main stream (default: side stream under the '
                          'large-separable convs): per-kernel rocprofv3 durations without cross-stream sharing')
@@ -86,6 +89,10 @@ def parse():
                     help='block1_conv2: LDS-staged input tile (default) or the implicit-GEMM kernel (A/B measurements)')
     ap.add_argument('--pool', default='split', choices=['split', 'whole', 'split_all'],
                     help='entry-flow pools: horizontal half in the producing block (default, 237x237 block) or one kernel')
+    ap.add_argument('--sustain-seconds', type=float, default=10.0,
+                    help='after the K timed steps: an UN-timed-for-value leg of back-to-back steps of about this many '
+                         'seconds (reported as sustained_images_per_sec), so that a utilisation sampler with a period of '
+                         'seconds sees the GPU busy whatever --steps is; 0 = off')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=200, help='images of the bounded CPU-baseline sample (~10-20 s)')
     ap.add_argument('--cpu-batch', type=int, default=8, help='images per call of the C++ CPU baseline')
@@ -96,15 +103,54 @@ def parse():
     return ap.parse_args()
 
 
-def kernel_source_hash():
-    """identifies the kernel sources a profile was taken with (the GPU box has no .git)."""
-    h = hashlib.sha256()
+def _code_only(src):
+    """C/C++ source text without comments and without whitespace: what a profile depends on (a comment edit or a
+    re-indent must not invalidate the committed counters)."""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if c == '"' or c == "'":                       # string / char literal: copied verbatim
+            j = i + 1
+            while j < n and src[j] != c:
+                j += 2 if src[j] == '\\' else 1
+            out.append(src[i:j + 1])
+            i = j + 1
+        elif src.startswith('//', i):
+            j = src.find('\n', i)
+            i = n if j < 0 else j
+        elif src.startswith('/*', i):
+            j = src.find('*/', i + 2)
+            i = n if j < 0 else j + 2
+        elif c.isspace():
+            i += 1
+        else:
+            out.append(c)
+            i += 1
+    return ''.join(out)
+
+
+def kernel_source_hashes():
+    """{file: hash of its code} for every kernel source / header (the GPU box has no .git)."""
     d = os.path.join(ROOT, 'x-detector_amd', 'csrc')
+    out = {}
     for f in sorted(os.listdir(d)):
         if f.endswith(('.hip', '.h')):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), 'rb').read())
+            out[f] = hashlib.sha256(_code_only(open(os.path.join(d, f), errors='replace').read()).encode()).hexdigest()[:16]
+    return out
+
+
+def kernel_source_hash():
+    """one hash over all of them: identifies the kernel sources a profile was taken with."""
+    h = hashlib.sha256()
+    for f, v in sorted(kernel_source_hashes().items()):
+        h.update(f.encode())
+        h.update(v.encode())
     return h.hexdigest()[:16]
+
+
+# the sources the dominant conv kernel is compiled from: the per-launch counters of a committed profile are quoted
+# whenever THESE are unchanged (net.hip decides which layers are launched; it is listed with the per-image total)
+CONV_KERNEL_FILES = ('conv_mfma_dma.hip', 'conv_epilogue.h', 'conv_params.h')
 
 
 def read_profile(handle, kind):
@@ -145,25 +191,28 @@ def cpu_baseline(args, weights):
         fwd = getattr(O, 'lighthead_forward_fast', None) or O.lighthead_forward
         how = getattr(O, 'FAST_PATH_DESCRIPTION', 'NumPy fp32 + OpenBLAS')
         cb = max(1, args.cpu_batch)                                # images per call: more parallel work per layer
-        imgs = W.synthetic_images(cb, 480, seed=11)
-        fwd(imgs, weights, rpn_post_nms_top_n=args.proposals)      # warm-up (page-in, weight packing, thread sweep)
-        t = time.time()
-        done = 0
-        while done < n and (done < 3 or time.time() - t < args.cpu_seconds):     # bounded sample: ~cpu_seconds of CPU work
-            fwd(W.synthetic_images(cb, 480, seed=20 + done), weights, rpn_post_nms_top_n=args.proposals)
+        # inputs are synthesised BEFORE the clock starts (four different batches, cycled): the window times the forward only
+        batches = [W.synthetic_images(cb, 480, seed=20 + i) for i in range(4)]
+        fwd(batches[0], weights, rpn_post_nms_top_n=args.proposals)   # warm-up (page-in, weight packing, thread sweep)
+        t = time.perf_counter()
+        done = calls = 0
+        while done < n and (done < 3 or time.perf_counter() - t < args.cpu_seconds):   # bounded sample: ~cpu_seconds of CPU work
+            fwd(batches[calls % len(batches)], weights, rpn_post_nms_top_n=args.proposals)
             done += cb
-        dt = time.time() - t
+            calls += 1
+        dt = time.perf_counter() - t
         n = done
-        what = '%d 480x480 images (batches of %d) through the full forward (R=%d), %s' % (n, cb, args.proposals, how)
+        what = ('%d 480x480 images (%d calls of %d, inputs prepared outside the timed window) through the full forward '
+                '(R=%d), %s' % (n, calls, cb, args.proposals, how))
     else:
-        x = np.transpose(W.synthetic_images(1, 480, seed=11), (0, 2, 3, 1))
-        O.resnet50_trunk(x, weights)
-        t = time.time()
+        xs = [np.ascontiguousarray(np.transpose(W.synthetic_images(1, 480, seed=20 + i), (0, 2, 3, 1))) for i in range(4)]
+        O.resnet50_trunk(xs[0], weights)
+        t = time.perf_counter()
         done = 0
-        while done < n and (done < 3 or time.time() - t < args.cpu_seconds):
-            O.resnet50_trunk(np.transpose(W.synthetic_images(1, 480, seed=20 + done), (0, 2, 3, 1)), weights)
+        while done < n and (done < 3 or time.perf_counter() - t < args.cpu_seconds):
+            O.resnet50_trunk(xs[done % len(xs)], weights)
             done += 1
-        dt = time.time() - t
+        dt = time.perf_counter() - t
         n = done
         what = '%d x one 480x480 image through the ResNet-50 v2 trunk, NumPy fp32 + OpenBLAS' % n
     cores = None
@@ -180,27 +229,35 @@ def cpu_baseline(args, weights):
     if args.workload == 'lighthead' and getattr(O, '_fast_cache', None):
         tun = getattr(next(iter(O._fast_cache.values())), 'tuning', None)
         if tun:
-            out['thread_sweep_s_per_image'] = {str(k): round(v, 3) for k, v in tun.items()}
+            # the warm-up's thread-count sweep: seconds per CALL (of cpu_batch images) at each OpenMP thread count
+            out['thread_sweep_s_per_call'] = {str(k): round(v, 3) for k, v in tun.items()}
+            out['thread_sweep_images_per_call'] = max(1, args.cpu_batch)
     return out
 
 
-def counters_from_profiles(precision, src_hash, sub_batch):
+def counters_from_profiles(precision, sub_batch):
     """HBM bytes per conv launch and counter-based MFMA utilisation from the committed rocprofv3 --pmc
     passes (profiles/<tag>_summary.json, tools/summarize_profile.py; PMC collection cannot run inside the
-    bench itself).  A summary is quoted only if it was taken with THESE kernel sources (source_hash) and with launches
-    of the same size (one sub-batch stream of `sub_batch` images: the command the summary records)."""
+    bench itself).  A summary is quoted if it was taken with launches of the same size (one sub-batch stream of
+    `sub_batch` images: the command the summary records) and with the same CODE (comments / whitespace ignored) of the
+    files the quoted kernel is compiled from (CONV_KERNEL_FILES).  The whole-forward figure (hbm_bytes_per_image) sums
+    over every kernel: the files that changed since the profile are listed next to it (empty list = the profile is of
+    exactly these sources)."""
     if precision != 'f16x3':      # the committed PMC passes are of the default configuration only
         return None
     want = 'conv_dma_f16'
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_summary.json')), reverse=True):
+    now = kernel_source_hashes()
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_summary.json')), reverse=True):     # newest tag first (r04b > r04a > r03b)
         try:
             d = json.load(open(path))
         except Exception:
             continue
         if '--ways 1 --batch %d ' % sub_batch not in (d.get('command') or '') + ' ':
             continue
-        if d.get('source_hash') != src_hash:
+        then = d.get('source_hashes')
+        if not then or any(then.get(f) != now.get(f) for f in CONV_KERNEL_FILES):
             continue
+        changed = sorted(f for f in set(then) | set(now) if then.get(f) != now.get(f))
         tot = cnt = 0
         busy = act = 0.0
         for k, e in d.get('kernels', {}).items():
@@ -211,17 +268,9 @@ def counters_from_profiles(precision, src_hash, sub_batch):
                 busy += e['mfma_busy_cycles']
                 act += e['gui_active_cycles']
         if cnt:
-            per_img = d.get('hbm_bytes_per_image')
-            if per_img is None:
-                # summaries written before the field existed: the stats run's step count is in the recorded command
-                import re
-                m_s, m_w = re.search(r'--steps (\d+)', d.get('command', '')), re.search(r'--warmup (\d+)', d.get('command', ''))
-                if m_s and m_w:
-                    allb = sum(e.get('hbm_bytes_per_launch', 0) * e['calls'] for k, e in d['kernels'].items()
-                               if not k.startswith('__amd_rocclr'))
-                    per_img = int(allb / (int(m_s.group(1)) + int(m_w.group(1))) / sub_batch)
             return {'traffic': int(tot / cnt), 'mfma_busy_frac': round(busy / (act / 8.0 * 1024.0), 4) if act else None,
-                    'hbm_bytes_per_image': per_img, 'file': os.path.relpath(path, ROOT)}
+                    'hbm_bytes_per_image': d.get('hbm_bytes_per_image'), 'file': os.path.relpath(path, ROOT),
+                    'files_changed_since': changed}
     return None
 
 
@@ -288,6 +337,26 @@ def main():
     # under a launcher (RANK set) the collective path is exercised even for one rank
     use_comm = world > 1 or args.comm or 'RANK' in os.environ
     comm = xdist.Communicator(rank, world) if use_comm else None
+
+    if args.dry_run:
+        # pre-flight of a multi-GPU node: every rank's device record THROUGH the collective, nothing else
+        if comm is None:
+            comm = xdist.Communicator(rank, world)
+        t0 = time.perf_counter()
+        recs = comm.device_records({'numa_cpus': len(numa_cpus) if numa_cpus else None})
+        comm.barrier()
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            path, over = comm.library()
+            print(json.dumps({'dry_run': True, 'n_gpus': world,
+                              'comm': {'library': path, 'library_overridden': over,
+                                       'rccl_version': comm.info()['rccl_version'], 'world': world, 'devices': recs,
+                                       'ranks_seen': sorted(r['rank'] for r in recs),
+                                       'distinct_gpus': len({(r['host'], r['pci_bus_id']) for r in recs}),
+                                       'records_plus_barrier_s': round(dt, 3)}}))
+            sys.stdout.flush()
+        comm.close()
+        return
 
     B, K, Wm = args.batch, args.steps, args.warmup
     S = args.image_size
@@ -397,6 +466,27 @@ def main():
     dev_ms = evs[0].elapsed_ms(evs[K])
     if comm is not None and args.workload == 'lighthead':
         gathered = comm.gathered()                   # [world*B, C, K, 5]: proves every rank's shard arrived
+    dt_local = dt
+    if comm is not None:
+        dt = comm.max_over_ranks(dt)                 # the slowest rank's wall clock: what `value` is computed from
+    # sustained leg (not part of `value`): the same step back to back for ~sustain_seconds.  The step count is derived from
+    # the max-over-ranks time, i.e. identical on every rank (each step carries a collective).
+    sustained = None
+    if args.sustain_seconds > 0:
+        n_sus = max(1, int(np.ceil(args.sustain_seconds / (dt / K))))
+        sync_all()
+        t1 = time.perf_counter()
+        for k in range(n_sus):
+            step()
+            if k % 16 == 15:                         # bound the launch queue; a stream sync, not a collective
+                for nt in nets:
+                    nt.stream.synchronize()
+        sync_all()
+        ds = time.perf_counter() - t1
+        if comm is not None:
+            ds = comm.max_over_ranks(ds)
+        sustained = {'sustained_images_per_sec': round(world * B * n_sus / ds, 2), 'sustained_steps': n_sus,
+                     'sustained_seconds': round(ds, 2)}
     rows = []
     KI = K                                           # steps the per-op event pairs cover
     if not args.no_roofline:
@@ -415,9 +505,9 @@ def main():
     if comm is not None:
         # every rank's (rank, hip device, PCI bus id, host, its own images/s) through ncclAllGather: the line then
         # proves how many DISTINCT GPUs took part, and shows the per-rank rates behind the max-over-ranks value
-        dev_records = comm.device_records({'images_per_sec': round(B * K / dt, 1), 'ms_per_step': round(dt / K * 1e3, 3),
+        dev_records = comm.device_records({'images_per_sec': round(B * K / dt_local, 1),
+                                           'ms_per_step': round(dt_local / K * 1e3, 3),
                                            'numa_cpus': len(numa_cpus) if numa_cpus else None})
-        dt = comm.max_over_ranks(dt)
 
     if rank == 0:
         ms_per_step = dt / K * 1e3
@@ -435,7 +525,7 @@ def main():
             kname = 'conv_mfma_f32_kernel' if args.precision == 'f32' else 'conv_dma_f16_kernel (+conv_mfma_f16_kernel for the 5 small/strided convs)'
             src = kernel_source_hash()
             default_cfg = args.workload == 'lighthead' and args.proposals == 300
-            ctr = counters_from_profiles(args.precision, src, sb) if default_cfg else None
+            ctr = counters_from_profiles(args.precision, sb) if default_cfg else None
             # frac counts SURVEY 8d's algorithmic FLOPs (the direct-form count also for the two large-separable convs,
             # which run in the DFT domain and execute ~5x fewer).  The kernel-quality views next to it:
             #   frac_executed    = FLOPs actually executed / products per term (i.e. the algorithmic FLOPs of the form
@@ -459,10 +549,12 @@ def main():
                                      '~5x fewer than their algorithmic count x %d) / conv kernel time / peak' % (nprod, nprod),
                     'mfma_busy_frac_pmc': ctr['mfma_busy_frac'] if ctr else None,
                     'traffic': ctr['traffic'] if ctr else None,
-                    'traffic_unit': ('HBM bytes per conv launch (PMC FETCH_SIZE x2 + WRITE_SIZE), from %s, same kernel '
-                                     'sources (%s)' % (ctr['file'], src)) if ctr
-                    else 'no PMC pass committed for these kernel sources (%s) / this configuration' % src,
+                    'traffic_unit': ('HBM bytes per conv launch (PMC FETCH_SIZE x2 + WRITE_SIZE), from %s: same code of %s'
+                                     % (ctr['file'], ' / '.join(CONV_KERNEL_FILES))) if ctr
+                    else 'no PMC pass committed for this code of %s (%s) / this configuration' % (' / '.join(CONV_KERNEL_FILES), src),
                     'hbm_bytes_per_image': ctr['hbm_bytes_per_image'] if ctr else None,
+                    # sources whose code changed since that profile (the per-image total sums over every kernel)
+                    'hbm_profile_files_changed_since': ctr['files_changed_since'] if ctr else None,
                     'hbm_min_bytes_per_image': int(HBM_MIN_BYTES_PER_IMAGE + 44.7e6 * 4 / sb) if args.workload == 'lighthead' and S == 480 else None,
                     'hbm_over_min': (round(ctr['hbm_bytes_per_image'] / (HBM_MIN_BYTES_PER_IMAGE + 44.7e6 * 4 / sb), 3)
                                      if ctr and ctr.get('hbm_bytes_per_image') and args.workload == 'lighthead' and S == 480 else None),
@@ -501,10 +593,24 @@ def main():
             'gflop_per_image': {k: round(v / 1e9, 2) for k, v in fl.items()},
             'roofline': roof,
         }
+        if sustained:
+            out.update(sustained)
         if comm is not None:
             info = comm.info()
-            out['comm'] = {'transport': 'RCCL %d via libxdet_hip.so (xdet_comm_*), no torch' % info['rccl_version'],
+            lib_path, lib_over = comm.library()
+            rates = [r.get('images_per_sec') for r in dev_records] if dev_records else None
+            out['comm'] = {'transport': ('%s (version %d) via libxdet_hip.so (xdet_comm_*), no torch'
+                                         % ('XDET_RCCL_LIB stand-in, NOT RCCL' if lib_over else 'RCCL', info['rccl_version'])),
+                           'library': lib_path, 'library_overridden': lib_over,
                            'world': info['world'],
+                           # value / (N x the median of the ranks' own rates): 1.0 = the job runs at the rate of its typical
+                           # rank (the max-over-ranks time and the collectives cost nothing); the driver computes the
+                           # efficiency against its own N=1 run, this is the same curve read off ONE line
+                           'weak_scaling_efficiency_vs_rank_median': (round(value / (world * float(np.median(rates))), 4)
+                                                                      if rates and all(rates) else None),
+                           'expected_images_per_sec_if_linear': {'1': 3740, '2': 7400, '4': 14800, '8': 29500,
+                                                                 'from': 'DESIGN.md section 6 (per-GPU rate of the default '
+                                                                         'configuration x N, all-gather hidden)'},
                            # gathered through ncclAllGather: one record per rank
                            'devices': dev_records,
                            'ranks_seen': sorted(r['rank'] for r in dev_records) if dev_records else None,

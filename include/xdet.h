@@ -215,10 +215,12 @@ int xdet_net_set_weight(void* net, const char* name, const float* data_host, int
  *   "conv3x3" = "patch" | "gemm": block1_conv2 on the staged-tile kernel (default) or the implicit-GEMM kernel.
  *   "pool" = "split" | "whole" | "split_all": the horizontal half of the block2 / block3 max-pools in the producing
  *   block's epilogue (default) or the whole pool as its own kernel.
- *   "check_range" = "off" | "on": after each forward validate every activation tensor and split plane against the
- *   f16 range of the split-precision convs (|x| <= 65504, no inf / NaN); a violation marks the image's detection
- *   scores NaN (slot 0 of every class), as a non-finite RPN score or head logit always does.  A diagnostic for new
- *   checkpoints: the pass re-reads all activations. */
+ *   "check_range" = "off" | "on": after each forward validate everything that is turned into f16 against the f16 range --
+ *   every split plane (no inf / NaN in the hi plane; the planes hold x * 2^-e after xdet_net_calibrate), the f32 input
+ *   of a register-split conv (|x| <= 65504) and of a fused separable block (relu?(x) * sum|taps| * 2^-e <= 65504) -- and
+ *   every other activation tensor for NaN / inf; a violation marks the image's detection scores NaN (slot 0 of every
+ *   class), as a non-finite RPN score or head logit always does.  A diagnostic for new checkpoints: the pass re-reads
+ *   all activations. */
 int xdet_net_set_option(void* net, const char* key, const char* value);
 int xdet_net_build(void* net);     /* folds BN, transposes/pads weights, allocates the workspace */
 int xdet_net_destroy(void* net);
@@ -306,9 +308,11 @@ int xdet_resnet_destroy(void* net);
  *   moved by ncclAllGather on the communicator's stream (rank / device / PCI-bus-id records, per-rank rates).
  * Watchdog: every HOST wait on the communicator's stream (comm_wait(NULL), the scalar collectives, allgather_bytes,
  *   destroy) polls instead of blocking; when RCCL reports an asynchronous error or nothing completes for the
- *   timeout (XDET_COMM_TIMEOUT_S or xdet_comm_set_timeout, default 300 s) the communicator is aborted
+ *   timeout (XDET_COMM_TIMEOUT_S or xdet_comm_set_timeout, default 300 s: the length of ONE wait, so a caller whose
+ *   peers legitimately take longer between two collectives raises it) the communicator is aborted
  *   (ncclCommAbort) and the call returns XDET_ERR_STATE, as does every later call -- a rank whose peer died exits
- *   with an error instead of hanging in hipStreamSynchronize.
+ *   with an error instead of hanging in hipStreamSynchronize.  Host buffers of the scalar / byte collectives are
+ *   staged through pinned memory owned by the communicator, so no copy can block the host outside the watchdog.
  * Rank 0 removes a stale id file before it creates the id and removes its own once ncclCommInitRank has returned. */
 int xdet_comm_init(void** comm, int rank, int world, const char* unique_id_path, int timeout_s);
 int xdet_comm_destroy(void* comm);
@@ -322,6 +326,11 @@ int xdet_comm_allreduce_max(void* comm, double* value_host);
 int xdet_comm_barrier(void* comm);
 int xdet_comm_allgather_bytes(void* comm, const void* send_host, void* recv_host, size_t bytes);
 int xdet_comm_set_timeout(void* comm, double seconds);
+/* which shared object the collective entry points were bound from (realpath of dladdr(ncclAllGather)), and whether it
+ * was named by XDET_RCCL_LIB.  XDET_RCCL_LIB is honoured only together with XDET_ALLOW_RCCL_OVERRIDE=1 (the test double of
+ * tests/fake_rccl, another RCCL build); otherwise xdet_comm_init fails with XDET_ERR_STATE: a bench never runs silently
+ * on a stand-in.  Binds the library if no communicator exists yet. */
+int xdet_comm_library(char* path_buf, int buflen, int* overridden);
 
 #ifdef __cplusplus
 }

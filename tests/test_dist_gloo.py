@@ -233,6 +233,7 @@ def test_ipc_mode_is_set_only_when_the_probe_says_the_default_fails(monkeypatch)
     from xdet import launch
     monkeypatch.delenv('HSA_ENABLE_IPC_MODE_LEGACY', raising=False)
     monkeypatch.delenv('XDET_IPC_PROBE', raising=False)
+    monkeypatch.delenv('XDET_IPC_PROBED', raising=False)
     seen = []
 
     def probe_factory(default_ok, dmabuf_ok):
@@ -248,6 +249,11 @@ def test_ipc_mode_is_set_only_when_the_probe_says_the_default_fails(monkeypatch)
     n = len(seen)
     assert launch.ipc_env(probe_factory(False, True)) == {'HSA_ENABLE_IPC_MODE_LEGACY': '1'}  # the caller's word wins
     assert len(seen) == n                                                                     # ... without probing
+    # a rank started by xdet.launch: the launcher probed once for all ranks and says so (no N x 2 probe processes)
+    monkeypatch.delenv('HSA_ENABLE_IPC_MODE_LEGACY')
+    monkeypatch.setenv('XDET_IPC_PROBED', '1')
+    assert launch.ipc_env(probe_factory(False, True)) == {} and len(seen) == n
+    assert launch.rank_env(1, 2, '/x', base={}, ipc={})['XDET_IPC_PROBED'] == '1'
 
 
 def test_numa_cpus_of_a_pci_device(tmp_path):

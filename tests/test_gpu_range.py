@@ -82,3 +82,36 @@ def test_mid_tensors_beyond_the_f16_range(oracle, lh_weights, lsep):
     base = cool.forward(imgs, use_graph=True)
     worst = max(float(np.abs(got[i][c][0] - base[i][c][0]).max()) for i in range(2) for c in range(1, 21))
     assert worst < 2e-5, worst
+
+
+@pytest.mark.parametrize('lsep', ['spectral', 'direct'])
+def test_check_range_agrees_with_a_calibrated_net(lh_weights, lsep):
+    """after calibrate() f32 tensors beyond 65504 are legitimate -- their planes hold x * 2^-e, and the
+    spectral products y1 / y2 are never split at all.  check_range validates what is actually turned into f16 (the planes,
+    the fused blocks' on-CU operands, the inputs of register-split convs) and only NaN / inf elsewhere: a checkpoint that
+    NEEDED the calibration passes the validation afterwards, and still fails it before."""
+    from xdet._lib import XdetError
+    from xdet import weights as W
+    from xdet.model import LightHeadDetector
+    from xdet.runtime import set_precision
+    hot = _hot_weights(lh_weights)
+    imgs = W.synthetic_images(2, 256, seed=3)
+    set_precision('f16x3')
+    try:
+        det = LightHeadDetector(hot, image_size=256, max_batch=2, rpn_post_nms_top_n=100, large_sep=lsep, check_range=True)
+        plain = LightHeadDetector(hot, image_size=256, max_batch=2, rpn_post_nms_top_n=100, large_sep=lsep)
+    finally:
+        set_precision('f32')
+    with pytest.raises(XdetError):
+        det.forward(imgs)                                         # uncalibrated: the validation (or the NaN guard) fires
+    assert det.calibrate(imgs[:1])
+    plain.calibrate(imgs[:1])
+    got = det.forward(imgs)                                       # calibrated: mid tensors of ~3e5 in f32, and no complaint
+    ref = plain.forward(imgs)
+    for i in range(2):
+        for c in range(1, 21):
+            assert np.array_equal(got[i][c][0], ref[i][c][0]) and np.array_equal(got[i][c][1], ref[i][c][1])
+    # and it still catches a real overflow: an image far outside the calibration batch
+    imgs[1] *= 1e30
+    with pytest.raises(XdetError, match=r'image\(s\) \[1\]'):
+        det.forward(imgs)

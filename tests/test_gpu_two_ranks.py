@@ -70,7 +70,7 @@ comm.close()
 
 
 def _env(fake):
-    env = dict(os.environ, XDET_RCCL_LIB=fake, XDET_BIND_NUMA='0', XDET_OVERSUBSCRIBE_GPUS='1')
+    env = dict(os.environ, XDET_RCCL_LIB=fake, XDET_ALLOW_RCCL_OVERRIDE='1', XDET_BIND_NUMA='0', XDET_OVERSUBSCRIBE_GPUS='1')
     env.pop('RANK', None)
     return env
 
@@ -108,6 +108,8 @@ def test_bench_with_two_ranks(fake_rccl):
     assert c['world'] == 2 and c['ranks_seen'] == [0, 1] and c['distinct_gpus'] == 1      # honest: one physical GPU here
     assert c['gathered_shape'] == [32, 20, 200, 5] and c['gathered_images_with_detections'] == 32
     assert len(c['per_rank_images_per_sec']) == 2 and min(c['per_rank_images_per_sec']) > 0
+    assert c['library_overridden'] is True and 'fake_rccl' in c['library']     # the line says what carried the collectives
+    assert 0.3 < c['weak_scaling_efficiency_vs_rank_median'] <= 1.001
     # value = all ranks' images / the slowest rank's time: never above the sum of the per-rank rates
     assert d['value'] <= sum(c['per_rank_images_per_sec']) * 1.001
     assert abs(d['value'] - 2 * 16 * 3 / (d['ms_per_step'] * 3e-3)) < 1e-2 * d['value']
@@ -150,8 +152,76 @@ os._exit(0)
     dt = time.time() - t0
     assert p.returncode == 17, (p.returncode, p.stderr.decode()[-2000:])
     msg = open(tmp_path / 'watchdog.txt').read()
-    assert 'no progress on the communicator stream' in msg and 'aborted its communicator' in msg, msg
+    assert 'exceeded its timeout of 5 s' in msg and 'aborted its communicator' in msg, msg
     assert 4.0 <= float(msg.split()[0]) < 30.0 and dt < 120, (msg, dt)
+
+
+@pytest.mark.parametrize('call', ['barrier', 'max_over_ranks', 'allgather_bytes'])
+def test_a_dead_peer_under_the_host_buffer_collectives(fake_rccl, tmp_path, call):
+    """barrier / allreduce_max / allgather_bytes copy to and from HOST memory around their collective.  With
+    pageable host buffers the D2H copy itself blocks until the stream drains -- behind a dead peer, forever, before the
+    watchdog is polled.  They stage through pinned memory now: the same timeout as comm.wait()."""
+    script = tmp_path / 'worker.py'
+    script.write_text(r'''
+import os, sys, time
+sys.path.insert(0, %(pkg)r)
+from xdet import dist as xd
+from xdet._lib import lib, check, XdetError
+rank = int(os.environ['RANK'])
+check(lib().xdet_set_device(0))
+comm = xd.Communicator(rank, 2, timeout_s=120)
+comm.barrier()                                        # one healthy collective
+assert comm.max_over_ranks(1.0 + rank) == 2.0
+assert comm.allgather_bytes(bytes([rank]) * 8) == [bytes([0]) * 8, bytes([1]) * 8]
+if rank == 1:
+    os._exit(0)
+time.sleep(1.0)
+t0 = time.time()
+try:
+    %(call)s
+except XdetError as e:
+    open(os.path.join(%(out)r, 'watchdog.txt'), 'w').write('%%.1f %%s' %% (time.time() - t0, e))
+    os._exit(17)
+os._exit(0)
+''' % {'pkg': os.path.join(ROOT, 'x-detector_amd'), 'out': str(tmp_path),
+       'call': {'barrier': 'comm.barrier()', 'max_over_ranks': 'comm.max_over_ranks(3.0)',
+                'allgather_bytes': 'comm.allgather_bytes(b"x" * 100)'}[call]})
+    code = ('import sys; sys.path.insert(0, %r); from xdet.launch import launch_ranks; '
+            'sys.exit(launch_ranks([sys.executable, %r], 2, timeout=300))' % (os.path.join(ROOT, 'x-detector_amd'), str(script)))
+    t0 = time.time()
+    p = subprocess.run([sys.executable, '-c', code], env=dict(_env(fake_rccl), XDET_COMM_TIMEOUT_S='5'),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    dt = time.time() - t0
+    assert p.returncode == 17, (p.returncode, p.stderr.decode()[-2000:])
+    msg = open(tmp_path / 'watchdog.txt').read()
+    assert 'exceeded its timeout' in msg and 'aborted its communicator' in msg, msg
+    assert 4.0 <= float(msg.split()[0]) < 30.0 and dt < 120, (msg, dt)
+
+
+def test_a_stand_in_for_rccl_must_be_asked_for_twice(fake_rccl):
+    """XDET_RCCL_LIB alone is refused: a bench must not silently run its collectives on something that is not RCCL."""
+    env = _env(fake_rccl)
+    env.pop('XDET_ALLOW_RCCL_OVERRIDE')
+    code = ('import sys; sys.path.insert(0, %r); from xdet import dist as xd; from xdet._lib import lib, check, XdetError\n'
+            'check(lib().xdet_set_device(0))\n'
+            'try:\n    xd.Communicator(0, 1)\nexcept XdetError as e:\n    print(e); sys.exit(9)\n' % os.path.join(ROOT, 'x-detector_amd'))
+    p = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 9 and b'XDET_ALLOW_RCCL_OVERRIDE' in p.stdout, (p.returncode, p.stdout, p.stderr[-2000:])
+
+
+def test_dry_run_with_two_ranks(fake_rccl):
+    """`bench.py --gpus N --dry-run`: rendezvous + one all-gather of the device records + exit, in seconds -- what an
+    8-GPU node is asked first, before the long run."""
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], env=_env(fake_rccl),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d['dry_run'] is True and d['n_gpus'] == 2 and d['comm']['ranks_seen'] == [0, 1]
+    assert d['comm']['distinct_gpus'] == 1 and d['comm']['library_overridden'] is True
+    assert 'fake_rccl' in d['comm']['library'] and time.time() - t0 < 300
 
 
 def test_bench_under_torch_distributed_run(fake_rccl):

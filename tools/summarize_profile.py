@@ -13,8 +13,8 @@ summary then carries per kernel the summed counters and mfma_busy_frac = MFMA_BU
 (MI355X_MICROARCH.md: the counter ticks 32 cycles per v_mfma_f32_32x32x16 on the SIMD that executes it, summed
 over the 256 CUs x 4 SIMDs; rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs, i.e. 8 x the elapsed
 cycles -- both calibrated on the RPN 3x3 conv: 3.69e7 MFMAs x 32 = 1.18e9 expected, 1.14e9 counted; 1.0 ms at
-~2 GHz = 2.0e6 cycles, 15.9e6 counted), which bench.py quotes next to its arithmetic mfma_util.  source_hash identifies the kernel sources
-(bench.kernel_source_hash) so a stale summary is never quoted.
+~2 GHz = 2.0e6 cycles, 15.9e6 counted), which bench.py quotes next to its arithmetic mfma_util.  source_hashes identifies the code of every
+kernel source (bench.kernel_source_hashes: comments / whitespace ignored) so a stale summary is never quoted.
 
 HBM bytes follow MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are reported in KiB-units of
 1024 B; on gfx950 FETCH_SIZE under-counts wide coalesced reads by exactly 2x, so read bytes =
@@ -82,7 +82,8 @@ def main():
             wtr.writerows(rows)
     sys.path.insert(0, ROOT)
     import bench
-    summ = {'tag': a.tag, 'command': a.note, 'source_hash': bench.kernel_source_hash(), 'kernels': {}}
+    summ = {'tag': a.tag, 'command': a.note, 'source_hash': bench.kernel_source_hash(),
+            'source_hashes': bench.kernel_source_hashes(), 'kernels': {}}
     mf = pmc(a.mfma) if a.mfma else {}
     ga = pmc(a.active) if a.active else {}
     for k, r in stats.items():

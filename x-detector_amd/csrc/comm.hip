@@ -32,6 +32,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -56,6 +58,8 @@ struct RcclApi {
 
 static RcclApi g_rccl;
 static std::mutex g_rccl_mu;
+static bool g_rccl_overridden = false;   // bound through XDET_RCCL_LIB (+ XDET_ALLOW_RCCL_OVERRIDE=1)
+static std::string g_rccl_path;           // file the collective entry points were resolved from (dladdr)
 
 static int load_rccl() {
   std::lock_guard<std::mutex> lk(g_rccl_mu);
@@ -65,7 +69,16 @@ static int load_rccl() {
   // XDET_RCCL_LIB: another build of RCCL -- or the test double of tests/fake_rccl, which lets two rank processes run
   // this file's N > 1 code on a one-GPU box (RCCL refuses two ranks on one device)
   if (const char* over = getenv("XDET_RCCL_LIB")) {
+    // a stand-in must be asked for twice: a bench or a service must never run its collectives on something that is not
+    // RCCL because a test's environment leaked into it
+    const char* allow = getenv("XDET_ALLOW_RCCL_OVERRIDE");
+    if (!allow || strcmp(allow, "1") != 0) {
+      set_last_error(std::string("XDET_RCCL_LIB=") + over + " is set but XDET_ALLOW_RCCL_OVERRIDE=1 is not: refusing to bind "
+                     "another library in place of librccl.so");
+      return XDET_ERR_STATE;
+    }
     h = dlopen(over, RTLD_NOW | RTLD_GLOBAL);
+    g_rccl_overridden = true;
     if (!h) {
       set_last_error(std::string("cannot load XDET_RCCL_LIB=") + over + ": " + dlerror());
       return XDET_ERR_STATE;
@@ -98,6 +111,14 @@ static int load_rccl() {
 #undef XDET_SYM
   *reinterpret_cast<void**>(&a.CommAbort) = dlsym(h, "ncclCommAbort");
   *reinterpret_cast<void**>(&a.CommGetAsyncError) = dlsym(h, "ncclCommGetAsyncError");
+  {
+    Dl_info di;
+    memset(&di, 0, sizeof(di));
+    if (dladdr(reinterpret_cast<void*>(a.AllGather), &di) && di.dli_fname) {
+      char real[4096];
+      g_rccl_path = realpath(di.dli_fname, real) ? real : di.dli_fname;
+    }
+  }
   g_rccl = a;
   return XDET_OK;
 }
@@ -147,11 +168,29 @@ struct Comm {
   hipEvent_t ev_packed[2] = {nullptr, nullptr}, ev_done = nullptr;
   std::vector<hipEvent_t> ev_in;
   double* d_scalar = nullptr;     // device scratch of the scalar collectives (barrier, max)
+  // pinned host staging of the host-buffer collectives: a D2H copy into PAGEABLE memory blocks the host until the
+  // stream has drained, i.e. behind a dead peer it would hang inside hipMemcpyAsync before the watchdog is ever polled
+  char* h_pinned = nullptr;
+  size_t h_pinned_cap = 0;
   int64_t gathers = 0;
+  int pinned(size_t bytes) {
+    if (bytes <= h_pinned_cap) return XDET_OK;
+    if (h_pinned) (void)hipHostFree(h_pinned);
+    h_pinned = nullptr;
+    h_pinned_cap = 0;
+    XDET_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_pinned), std::max<size_t>(bytes, 4096), hipHostMallocDefault));
+    h_pinned_cap = std::max<size_t>(bytes, 4096);
+    return XDET_OK;
+  }
 
   ~Comm() {
     // a communicator the watchdog gave up on is aborted, not destroyed: ncclCommDestroy would wait for the dead peer
-    if (comm) (void)((dead && g_rccl.CommAbort) ? g_rccl.CommAbort(comm) : g_rccl.CommDestroy(comm));
+    // (without ncclCommAbort in the bound library the dead communicator is leaked on purpose)
+    if (comm) {
+      if (!dead) (void)g_rccl.CommDestroy(comm);
+      else if (g_rccl.CommAbort) (void)g_rccl.CommAbort(comm);
+    }
+    if (h_pinned) (void)hipHostFree(h_pinned);
     if (d_bytes) (void)hipFree(d_bytes);
     for (hipEvent_t e : ev_in) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_packed)
@@ -220,7 +259,8 @@ static int watchdog_wait(Comm* c, hipEvent_t ev, const char* what) {
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (why.empty() && el > c->timeout_s) {
       char buf[160];
-      snprintf(buf, sizeof(buf), "no progress on the communicator stream for %.0f s (a peer rank died or hangs)", el);
+      snprintf(buf, sizeof(buf), "this wait on the communicator stream exceeded its timeout of %.0f s (waited %.0f s; a peer rank "
+               "died, hangs, or legitimately needs longer: XDET_COMM_TIMEOUT_S / xdet_comm_set_timeout)", c->timeout_s, el);
       why = buf;
     }
     if (!why.empty()) {
@@ -372,11 +412,19 @@ int xdet_comm_allreduce_max(void* comm, double* value_host) {
     return XDET_ERR_STATE;
   }
   CommDeviceGuard guard(c->device);
-  XDET_HIP(hipMemcpyAsync(c->d_scalar, value_host, sizeof(double), hipMemcpyHostToDevice, c->stream));
-  XDET_RCCL(g_rccl.AllReduce(c->d_scalar, c->d_scalar + 1, 1, ncclDouble, ncclMax, c->comm, c->stream));
-  XDET_HIP(hipMemcpyAsync(value_host, c->d_scalar + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  // drain first: the staging buffer may still be the target of an earlier call's copy
   XDET_HIP(hipEventRecord(c->ev_done, c->stream));
-  return watchdog_wait(c, c->ev_done, "allreduce_max");
+  XDET_TRY(watchdog_wait(c, c->ev_done, "allreduce_max"));
+  XDET_TRY(c->pinned(2 * sizeof(double)));
+  double* hp = reinterpret_cast<double*>(c->h_pinned);
+  hp[0] = *value_host;
+  XDET_HIP(hipMemcpyAsync(c->d_scalar, hp, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  XDET_RCCL(g_rccl.AllReduce(c->d_scalar, c->d_scalar + 1, 1, ncclDouble, ncclMax, c->comm, c->stream));
+  XDET_HIP(hipMemcpyAsync(hp + 1, c->d_scalar + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  XDET_HIP(hipEventRecord(c->ev_done, c->stream));
+  XDET_TRY(watchdog_wait(c, c->ev_done, "allreduce_max"));
+  *value_host = hp[1];
+  return XDET_OK;
 }
 
 // Small host-buffer all-gather (rank records, per-rank rates): send `bytes` from every rank, receive world * bytes in
@@ -401,11 +449,26 @@ int xdet_comm_allgather_bytes(void* comm, const void* send_host, void* recv_host
     XDET_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bytes), need));
     c->d_bytes_cap = need;
   }
-  XDET_HIP(hipMemcpyAsync(c->d_bytes, send_host, bytes, hipMemcpyHostToDevice, c->stream));
-  XDET_RCCL(g_rccl.AllGather(c->d_bytes, c->d_bytes + bytes, bytes, ncclChar, c->comm, c->stream));
-  XDET_HIP(hipMemcpyAsync(recv_host, c->d_bytes + bytes, bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+  // through pinned staging: both copies are then truly asynchronous and the host only ever waits in the watchdog
   XDET_HIP(hipEventRecord(c->ev_done, c->stream));
-  return watchdog_wait(c, c->ev_done, "allgather_bytes");
+  XDET_TRY(watchdog_wait(c, c->ev_done, "allgather_bytes"));
+  XDET_TRY(c->pinned(need));
+  memcpy(c->h_pinned, send_host, bytes);
+  XDET_HIP(hipMemcpyAsync(c->d_bytes, c->h_pinned, bytes, hipMemcpyHostToDevice, c->stream));
+  XDET_RCCL(g_rccl.AllGather(c->d_bytes, c->d_bytes + bytes, bytes, ncclChar, c->comm, c->stream));
+  XDET_HIP(hipMemcpyAsync(c->h_pinned + bytes, c->d_bytes + bytes, bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+  XDET_HIP(hipEventRecord(c->ev_done, c->stream));
+  XDET_TRY(watchdog_wait(c, c->ev_done, "allgather_bytes"));
+  memcpy(recv_host, c->h_pinned + bytes, bytes * (size_t)c->world);
+  return XDET_OK;
+}
+
+int xdet_comm_library(char* path_buf, int buflen, int* overridden) {
+  XDET_REQUIRE(path_buf && buflen > 0, "comm_library: need a buffer");
+  XDET_TRY(load_rccl());
+  snprintf(path_buf, (size_t)buflen, "%s", g_rccl_path.c_str());
+  if (overridden) *overridden = g_rccl_overridden ? 1 : 0;
+  return XDET_OK;
 }
 
 int xdet_comm_set_timeout(void* comm, double seconds) {

@@ -53,44 +53,7 @@ static inline int ensure_dynamic_lds(DeviceOnce& once, const void* kern, int byt
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// ---- implicit-GEMM convolution on the f32 MFMA pipe (conv_mfma.hip) -------------------
-struct ConvParams {
-  const float* in;   // NHWC, channel stride ldi (padded channels are zero)
-  const float* wt;   // [Cout_pad][Kp], K contiguous, k = tap*Cin_p + ci   (f32 path)
-  const unsigned short* wt_hi;   // f16 planes of the (per-channel power-of-two scaled) matrix: split path
-  const unsigned short* wt_lo;
-  // A operand already split into f16 planes (conv_mfma_dma.hip), blocked [pixels/16][ldi/32][16][32]
-  // (pixel = n*H*W + y*W + x): 16 pixels x 32 channels are one contiguous 1 KB block
-  const unsigned short* in_hi;
-  const unsigned short* in_lo;
-  const unsigned short* zeros;   // >= 16 B of zeros: the source of out-of-image taps for the LDS DMA
-  float* out;        // NHWC, channel stride ldo; may be NULL when only the planes below are wanted
-  // optional second copy of the output as split planes [pix/16][ldo/32][16][32] for a consumer on the
-  // LDS-DMA path (saves its split pass); planes_relu: the planes hold max(out, 0) (a `relu -> conv` edge)
-  unsigned short* out_hi;
-  unsigned short* out_lo;
-  int planes_relu;
-  // optional per-channel affine applied to the planes copy before its ReLU (a following inference BN:
-  // planes = relu(out * pl_scale + pl_shift)); NULL = none
-  const float* pl_scale;
-  const float* pl_shift;
-  const float* scale;   // [Cout_pad] folded BN scale (1 for plain bias)
-  const float* shift;   // [Cout_pad] folded BN shift / bias
-  const float* res;     // optional residual, same N,Ho,Wo, channel stride ldr
-  int N, H, W, ldi;
-  int Ho, Wo, ldo, ldr;
-  int Cin_p;         // channels walked per tap (multiple of 32; 4 in small-cin mode)
-  int Kp;            // padded reduction length (multiple of 32)
-  int Cout_pad;      // multiple of the N tile
-  int KH, KW, stride, dil, pad_t, pad_l;
-  int M;             // N*Ho*Wo
-  int relu_in, relu_out;
-  // grouped GEMM (conv_mfma_dma.hip only; the frequency bins of the spectral large-separable conv): rows
-  // [g*group_rows, (g+1)*group_rows) of the M dimension use weight matrix g (wt_* + g*group_wt_stride halves)
-  // and scale/shift row g (+ g*Cout_pad).  group_rows is a multiple of every M tile; 0 = one group.
-  int group_rows;
-  long long group_wt_stride;
-};
+#include "conv_params.h"   // struct ConvParams: what every MFMA conv kernel is launched with
 int launch_conv_mfma_f32(const ConvParams& p, bool small_cin, int n_tile, hipStream_t s);
 // nsplit 3 = f16x3 (hi/lo f16 operands, f32-class accuracy), 1 = plain f16 operands
 int launch_conv_mfma_split(const ConvParams& p, bool small_cin, int n_tile, int nsplit, hipStream_t s);
@@ -109,8 +72,9 @@ int launch_maxpool_v3s2_add(const float* in_hpooled, const float* res, float* ou
 // diagnostic: bad_per_image[n] = 1 if any element of image n is NaN or beyond +-limit
 // groups > 1: a stack of `groups` blocks of group_elems floats / group_pix pixels (the frequency bins of the spectral
 // large-separable convs); the image of an element is its position inside its block / per_image, rows past N are padding
+// relu != 0: the tensor is consumed through a ReLU, only values above +limit count (NaN / inf always do)
 int launch_range_check(const float* x, int N, size_t per_image, float limit, int* bad_per_image, hipStream_t s,
-                       int groups = 1, size_t group_elems = 0);
+                       int groups = 1, size_t group_elems = 0, int relu = 0);
 int launch_range_check_planes(const unsigned short* hi, int N, int64_t pix_per_image, int ld, int* bad_per_image,
                               hipStream_t s, int groups = 1, int64_t group_pix = 0);
 int launch_relu_copy(const float* in, float* out, int64_t n, hipStream_t s);

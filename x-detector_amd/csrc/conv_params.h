@@ -1,0 +1,45 @@
+// Launch parameters of the MFMA convolution kernels (conv_mfma*.hip).  Its own header so that the profile
+// bookkeeping (bench.py CONV_KERNEL_FILES) can tell a change of the conv kernels' interface from any other edit of common.h.
+#pragma once
+
+namespace xdet {
+
+struct ConvParams {
+  const float* in;   // NHWC, channel stride ldi (padded channels are zero)
+  const float* wt;   // [Cout_pad][Kp], K contiguous, k = tap*Cin_p + ci   (f32 path)
+  const unsigned short* wt_hi;   // f16 planes of the (per-channel power-of-two scaled) matrix: split path
+  const unsigned short* wt_lo;
+  // A operand already split into f16 planes (conv_mfma_dma.hip), blocked [pixels/16][ldi/32][16][32]
+  // (pixel = n*H*W + y*W + x): 16 pixels x 32 channels are one contiguous 1 KB block
+  const unsigned short* in_hi;
+  const unsigned short* in_lo;
+  const unsigned short* zeros;   // >= 16 B of zeros: the source of out-of-image taps for the LDS DMA
+  float* out;        // NHWC, channel stride ldo; may be NULL when only the planes below are wanted
+  // optional second copy of the output as split planes [pix/16][ldo/32][16][32] for a consumer on the
+  // LDS-DMA path (saves its split pass); planes_relu: the planes hold max(out, 0) (a `relu -> conv` edge)
+  unsigned short* out_hi;
+  unsigned short* out_lo;
+  int planes_relu;
+  // optional per-channel affine applied to the planes copy before its ReLU (a following inference BN:
+  // planes = relu(out * pl_scale + pl_shift)); NULL = none
+  const float* pl_scale;
+  const float* pl_shift;
+  const float* scale;   // [Cout_pad] folded BN scale (1 for plain bias)
+  const float* shift;   // [Cout_pad] folded BN shift / bias
+  const float* res;     // optional residual, same N,Ho,Wo, channel stride ldr
+  int N, H, W, ldi;
+  int Ho, Wo, ldo, ldr;
+  int Cin_p;         // channels walked per tap (multiple of 32; 4 in small-cin mode)
+  int Kp;            // padded reduction length (multiple of 32)
+  int Cout_pad;      // multiple of the N tile
+  int KH, KW, stride, dil, pad_t, pad_l;
+  int M;             // N*Ho*Wo
+  int relu_in, relu_out;
+  // grouped GEMM (conv_mfma_dma.hip only; the frequency bins of the spectral large-separable conv): rows
+  // [g*group_rows, (g+1)*group_rows) of the M dimension use weight matrix g (wt_* + g*group_wt_stride halves)
+  // and scale/shift row g (+ g*Cout_pad).  group_rows is a multiple of every M tile; 0 = one group.
+  int group_rows;
+  long long group_wt_stride;
+};
+
+}  // namespace xdet

@@ -587,11 +587,14 @@ int launch_maxpool_v3s2_add(const float* in_hpooled, const float* res, float* ou
 // convs, rows [bin][n*F + o]); the image of an element is its index WITHIN the group / per_image4, rows past the
 // batch are padding
 __global__ __launch_bounds__(256) void range_check_kernel(const float4* __restrict__ x, int64_t n4, int64_t per_image4,
-                                                          float limit, int* __restrict__ bad, int64_t group4, int N) {
+                                                          float limit, int* __restrict__ bad, int64_t group4, int N, int relu) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const float4 v = x[i];
-    const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-    const bool nan = v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w;
+    // relu: the consumer reads max(x, 0) -- a large NEGATIVE value is harmless, only +values count against the limit
+    const float m = relu ? fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w))
+                         : fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    const float am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    const bool nan = v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w || !(am <= 3.4028235e38f);   // NaN or +-inf
     if (nan || !(m <= limit)) {
       const int64_t img = (group4 ? i % group4 : i) / per_image4;
       if (img < N) bad[img] = 1;
@@ -631,13 +634,13 @@ int launch_range_check_planes(const unsigned short* hi, int N, int64_t pix_per_i
 }
 
 int launch_range_check(const float* x, int N, size_t per_image, float limit, int* bad_per_image, hipStream_t s,
-                       int groups, size_t group_elems) {
+                       int groups, size_t group_elems, int relu) {
   XDET_REQUIRE(per_image % 4 == 0 && group_elems % 4 == 0, "range_check: tensor size must be a multiple of 4");
   const int64_t n4 = groups > 1 ? (int64_t)groups * (int64_t)(group_elems / 4) : (int64_t)N * (int64_t)(per_image / 4);
   if (n4 == 0) return XDET_OK;
   const int blocks = (int)std::min<int64_t>(cdiv(n4, 256), 256 * 16);
   hipLaunchKernelGGL(range_check_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x), n4,
-                     (int64_t)(per_image / 4), limit, bad_per_image, groups > 1 ? (int64_t)(group_elems / 4) : (int64_t)0, N);
+                     (int64_t)(per_image / 4), limit, bad_per_image, groups > 1 ? (int64_t)(group_elems / 4) : (int64_t)0, N, relu);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }

@@ -446,6 +446,26 @@ struct Plan {
     std::function<int(hipStream_t)> clear;            // optional: zero the padding a measurement would otherwise scan
   };
   std::vector<PlaneScale> pscales;
+  std::vector<const float*> f32_split_inputs;          // f32 tensors a register-split conv reads (no pre-scale exists for them)
+  // check_range: what an f32 tensor may hold.  Only two kinds of f32 tensors are ever turned into f16 without a planes
+  // tensor of their own (which range_check_planes sees directly): the input of a register-split conv (|x| <= 65504) and
+  // the input of a fused separable block, whose depthwise result is split on the CU (relu?(x) * sum|w| * 2^-e <= 65504).
+  // Everything else -- including tensors whose PLANES carry a pre-scale, and the spectral products y1 / y2, which are
+  // never split -- is legitimately beyond 65504 after a calibration and is only checked for NaN / inf.
+  void f32_limit(const float* p, float* limit, int* relu) const {
+    *limit = 3.4028235e38f;
+    *relu = 0;
+    bool any = false, all_relu = true;
+    for (const float* q : f32_split_inputs)
+      if (q == p) { *limit = std::min(*limit, 65504.f); any = true; all_relu = false; }
+    for (const PlaneScale& ps : pscales)
+      if (ps.src == p && ps.bound > 0.f) {
+        *limit = std::min(*limit, ldexpf(65504.f / ps.bound, ps.exp));
+        any = true;
+        all_relu = all_relu && ps.src_relu != 0;
+      }
+    *relu = any && all_relu;
+  }
   static constexpr float kRangeTarget = 4096.f;       // 16x below the f16 maximum: headroom for images unlike the calibration batch
   float pmul(int pidx) const { return pidx >= 0 ? ldexpf(1.f, -pscales[pidx].exp) : 1.f; }
   int set_plane_exp(int pidx, int e) {
@@ -531,6 +551,9 @@ struct Plan {
     } else {
       XDET_REQUIRE(!in.no_f32, "plan: this tensor exists as planes only");
       in.hi = in.lo = nullptr;
+      // this conv splits its f32 input in registers (conv_mfma_split.hip): no planes, no pre-scale -> the f32 tensor
+      // itself must stay inside the f16 range (check_range)
+      if (L->precision != PREC_F32) f32_split_inputs.push_back(in.p);
     }
     int Ho, Wo, a, b;
     L->out_shape(in.H, in.W, &Ho, &Wo, &a, &b);
@@ -1036,8 +1059,9 @@ struct LightHeadNet : Plan {
         const int mp = mpad_rc(N);
         XDET_TRY(launch_range_check_planes(xa_hi, N, F, 2 * cin_ld, prop_ws.bad, s, NB, mp));
         XDET_TRY(launch_range_check_planes(xb_hi, N, F, 2 * mid2, prop_ws.bad, s, NB, mp));
-        XDET_TRY(launch_range_check(y1, N, (size_t)F * 2 * mid2, 65504.f, prop_ws.bad, s, NB, (size_t)mp * 2 * mid2));
-        return launch_range_check(y2, N, (size_t)F * 2 * co_ld, 65504.f, prop_ws.bad, s, NB, (size_t)mp * 2 * co_ld);
+        // the per-bin products are f32 and never split: NaN / inf only
+        XDET_TRY(launch_range_check(y1, N, (size_t)F * 2 * mid2, 3.4028235e38f, prop_ws.bad, s, NB, (size_t)mp * 2 * mid2));
+        return launch_range_check(y2, N, (size_t)F * 2 * co_ld, 3.4028235e38f, prop_ws.bad, s, NB, (size_t)mp * 2 * co_ld);
       });
     }
     const std::string pre = "large_sep_feature/Branch_0+1/";
@@ -1345,7 +1369,12 @@ struct LightHeadNet : Plan {
     XDET_TRY(get_head(N, s));
     XDET_TRY(head_decode(N, s));
     if (check_range && net_precision != PREC_F32) {
-      for (const auto& b : f32_bufs) XDET_TRY(launch_range_check(b.first, N, b.second, 65504.f, prop_ws.bad, s));
+      for (const auto& b : f32_bufs) {
+        float limit;
+        int relu;
+        f32_limit(b.first, &limit, &relu);
+        XDET_TRY(launch_range_check(b.first, N, b.second, limit, prop_ws.bad, s, 1, 0, relu));
+      }
       for (const auto& b : planes_bufs) XDET_TRY(launch_range_check_planes(b.hi, N, b.pix_per_image, b.ld, prop_ws.bad, s));
       for (const auto& f : extra_range_checks) XDET_TRY(f(N, s));
     }

@@ -141,6 +141,7 @@ SIGNATURES = {
     'xdet_comm_barrier': (c_int, [c_void_p]),
     'xdet_comm_allgather_bytes': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     'xdet_comm_set_timeout': (c_int, [c_void_p, c_double]),
+    'xdet_comm_library': (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_int)]),
 }
 
 _lib = None

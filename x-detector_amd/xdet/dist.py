@@ -101,6 +101,15 @@ class Communicator(object):
         check(lib().xdet_comm_info(self.handle, *[ctypes.byref(x) for x in v]))
         return dict(zip(('rank', 'world', 'device', 'rccl_version'), [x.value for x in v]))
 
+    @staticmethod
+    def library():
+        """(path of the shared object the collective entry points were bound from, named-by-XDET_RCCL_LIB?)"""
+        from ._lib import lib, check
+        buf = ctypes.create_string_buffer(4096)
+        over = ctypes.c_int()
+        check(lib().xdet_comm_library(buf, 4096, ctypes.byref(over)))
+        return buf.value.decode('utf-8', 'replace'), bool(over.value)
+
     def _ensure(self, n_images, nc, topk):
         from .runtime import DeviceBuffer
         key = (n_images, nc, topk)

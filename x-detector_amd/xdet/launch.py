@@ -57,6 +57,8 @@ def ipc_env(probe=_probe_ipc):
         return {'HSA_ENABLE_IPC_MODE_LEGACY': os.environ['HSA_ENABLE_IPC_MODE_LEGACY']}
     if os.environ.get('XDET_IPC_PROBE'):          # we ARE the probe process: never recurse
         return {}
+    if os.environ.get('XDET_IPC_PROBED') == '1':  # a rank of xdet.launch: the launcher probed once for all of them (N
+        return {}                                 # ranks x two HIP-initialising probe processes would contend for the GPUs)
     if probe is _probe_ipc and _ipc_cache is not None:
         return dict(_ipc_cache)
     out = {}
@@ -117,6 +119,7 @@ def rank_env(rank, world, id_file, base=None, ipc=None):
     env.update({'RANK': str(rank), 'LOCAL_RANK': str(rank), 'WORLD_SIZE': str(world),
                 'LOCAL_WORLD_SIZE': str(world), 'XDET_COMM_ID_FILE': id_file})
     env.update(ipc_env() if ipc is None else ipc)
+    env['XDET_IPC_PROBED'] = '1'        # the launcher decided the IPC mode once: the ranks' lib() must not probe again
     env.setdefault('XDET_BIND_NUMA', '1')
     env.setdefault('NCCL_DEBUG', 'WARN')
     env.setdefault('NCCL_DEBUG_FILE', '/dev/stderr')
