@@ -64,6 +64,7 @@ def parse():
                     help='the batch runs as this many concurrent sub-batches (net instances on their own HIP '
                          'streams): the partial last round of one launch is filled by the other stream')
     ap.add_argument('--workload', default='lighthead', choices=['lighthead', 'resnet50'])
+    ap.add_argument('--resnet-ways', type=int, default=2, help='resnet50 workload: concurrent sub-batches (see --ways)')
     ap.add_argument('--image-size', type=int, default=480,
                     help='network input size: 480 (the metric) or 800 (BASELINE config 5 shape; implies --no-parity '
                          '--no-cpu-baseline, whose legs are 480x480)')
@@ -93,6 +94,7 @@ def parse():
                     help='after the K timed steps: an UN-timed-for-value leg of back-to-back steps of about this many '
                          'seconds (reported as sustained_images_per_sec), so that a utilisation sampler with a period of '
                          'seconds sees the GPU busy whatever --steps is; 0 = off')
+    ap.add_argument('--no-ksplit', action='store_true', help='RPN conv / narrow head GEMM on the plain kernels (A/B runs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=200, help='images of the bounded CPU-baseline sample (~10-20 s)')
     ap.add_argument('--cpu-batch', type=int, default=8, help='images per call of the C++ CPU baseline')
@@ -372,7 +374,7 @@ def main():
         sb = B // ways                               # images per sub-batch / net instance
         nets = [LightHeadDetector(weights, image_size=S, max_batch=sb, rpn_post_nms_top_n=args.proposals,
                                   rpn_stream='main' if args.serial_rpn else 'side', conv3x3=args.conv3x3,
-                                  pool=args.pool)
+                                  pool=args.pool, ksplit=not args.no_ksplit)
                 for _ in range(ways)]
         net = nets[0]
         kind = 0
@@ -426,17 +428,29 @@ def main():
     else:
         from xdet.resnet import ResNet50Trunk
         weights = W.make_resnet50_weights(4321)
-        net = ResNet50Trunk(weights, image_size=480, max_batch=B)
+        # --resnet-ways N: the batch as N concurrent sub-batches (trunk instances on their own streams), as the detector's
+        # --ways: at batch 8 most launches are 60-230 workgroups of 30-50 us, and two independent streams fill each
+        # other's tails and launch gaps (batch 8: 3697 -> 3931 images/s, same box).  Default 2; 1 = the configuration of
+        # every ResNet line before round 4.
+        ways = max(1, min(args.resnet_ways, B))
+        if B % ways:
+            raise SystemExit('--batch must be a multiple of --resnet-ways')
+        sb = B // ways
+        nets = [ResNet50Trunk(weights, image_size=480, max_batch=sb) for _ in range(ways)]
+        net = nets[0]
         kind = 1
         flops_img = net.flops_per_image()
         fl = {'backbone': flops_img}
-        net.set_images(W.synthetic_images(B, 480, seed=100 + rank))
+        imgs = W.synthetic_images(B, 480, seed=100 + rank)
+        for i, nt in enumerate(nets):
+            nt.set_images(imgs[i * sb:(i + 1) * sb])
 
         use_graph = not args.eager
-        nets, sb, ways = [net], B, 1
 
         def step(graph=None, only_first=False):
-            net.forward_device(B, use_graph=use_graph if graph is None else graph)
+            g = use_graph if graph is None else graph
+            for nt in (nets[:1] if only_first else nets):
+                nt.forward_device(sb, use_graph=g)
 
     def sync_all():
         for nt in nets:

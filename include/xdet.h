@@ -107,6 +107,14 @@ int xdet_conv_create(void** layer, int kh, int kw, int cin, int cout, int stride
 int xdet_conv_forward(void* layer, const float* in, int N, int H, int W, int ld_in, float* out, int ld_out,
                       const float* residual, int relu_in, void* stream);
 int xdet_conv_out_shape(void* layer, int H, int W, int* Ho, int* Wo);
+/* Fixed split of the reduction (csrc/conv_mfma_ksplit.hip; layers fed with planes only): the K steps are cut into
+ * `ksplit` equal ranges and the result is the left fold ((p_0 + p_1) + ...) of the per-range sums -- a constant of the
+ * layer, so results do not depend on the batch.  The net builders choose it from the layer geometry (ResNet-50 stages
+ * 3-4, net/resnet_v2.py:142-184; the RPN conv / head GEMMs of a single image); this entry sets it on a stand-alone layer.
+ * ksplit 0 = back to the plain kernels, 1 = the split-K kernel with one range (bit-identical to the plain kernels).
+ * mode 0 = ranges in parallel when tiles * ksplit <= 448 else one workgroup per tile, 1 / 2 = force either (the two are
+ * bit-identical); max_parallel_tiles sizes the scratch slabs of the parallel mode. */
+int xdet_conv_set_ksplit(void* layer, int ksplit, int mode, int max_parallel_tiles);
 /* Split-precision operand planes (modes 1/2): x = hi + lo, both f16, blocked
  * [ceil(n_pix/16)][ld/32][16][32] with n_pix = N*H*W (16 pixels x 32 channels = one contiguous 1 KB
  * block: what one LDS-DMA instruction of a conv tile ingests); a plane holds ceil(n_pix/16)*16*ld halves.  xdet_split_f32 (x NHWC [n_pix][ld], ld % 32 == 0) writes them element-wise (optionally through a ReLU); xdet_conv_forward_planes runs a
@@ -215,6 +223,8 @@ int xdet_net_set_weight(void* net, const char* name, const float* data_host, int
  *   "conv3x3" = "patch" | "gemm": block1_conv2 on the staged-tile kernel (default) or the implicit-GEMM kernel.
  *   "pool" = "split" | "whole" | "split_all": the horizontal half of the block2 / block3 max-pools in the producing
  *   block's epilogue (default) or the whole pool as its own kernel.
+ *   "ksplit" = "on" | "off": the RPN 3x3 conv and the 2048 -> 25 head GEMM (a single image: 32 / 3 tiles against 207 / 64
+ *   K steps) on the fixed split-K kernel (default; results identical at every batch size) or on the plain kernels.
  *   "check_range" = "off" | "on": after each forward validate everything that is turned into f16 against the f16 range --
  *   every split plane (no inf / NaN in the hi plane; the planes hold x * 2^-e after xdet_net_calibrate), the f32 input
  *   of a register-split conv (|x| <= 65504) and of a fused separable block (relu?(x) * sum|taps| * 2^-e <= 65504) -- and
@@ -283,6 +293,9 @@ int xdet_resnet_forward(void* net, const float* images_nchw, int N, float* out_n
 /* the same forward as a replayed hipGraph (captured on the first call with a given (N, images, out) tuple; needs an
  * explicit stream; falls back to the eager form while per-op profiling is enabled) */
 int xdet_resnet_forward_graph(void* net, const float* images_nchw, int N, float* out_nhwc, void* stream);
+/* activation pre-scale of the trunk's split-precision operands, as xdet_net_calibrate (xdet_net_plane_scales / _name accept
+ * a trunk handle too).  Handles are checked: an entry point given the other net type's handle returns XDET_ERR_INVALID_ARG. */
+int xdet_resnet_calibrate(void* net, const float* images_nchw, int N, int* n_scaled, void* stream);
 int xdet_resnet_out_shape(void* net, int* Ho, int* Wo, int* C);
 int xdet_resnet_flops_per_image(void* net, double* flops);
 int xdet_resnet_destroy(void* net);

@@ -89,3 +89,12 @@ def test_product_package_never_imports_the_oracle():
                 assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), os.path.join(d, f)
                 assert 'lighthead_oracle' not in src and 'liboracle' not in src and 'psroialign_ref' not in src
     assert 'import torch' not in open(os.path.join(pkg, 'xdet', 'model.py')).read()
+
+
+def test_no_kernel_symbol_is_left_undefined(built):
+    """A __global__ template whose body the HOST pass of hipcc cannot instantiate (e.g. an `unsigned` handed to an `int`
+    parameter of a device builtin inside a lambda) gets no stub and no handle: the object links, the library builds, and
+    dlopen fails on the GPU box with `undefined symbol: ...kernel...`.  Caught here instead: nothing of ours may be undefined."""
+    out = subprocess.run(['nm', '-D', '-C', '--undefined-only', built], stdout=subprocess.PIPE, check=True).stdout.decode()
+    ours = [l.strip() for l in out.splitlines() if 'xdet' in l]
+    assert not ours, ours

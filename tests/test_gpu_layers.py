@@ -366,3 +366,129 @@ def test_fused_block_and_split_pool_random_shapes():
         assert np.array_equal(fused.numpy(), op(xd, relu_in=relu_in, fused=False).numpy()), tag
         whole = max_pool_3x3_s2_same_add(fused, rd).numpy()
         assert np.array_equal(separable_block_then_pool_add(op, xd, rd, relu_in=relu_in).numpy(), whole), tag
+
+
+KSPLIT_CASES = [
+    # (N, H, W, cin, cout, kh, kw, stride, padding)    -- the layers the split-K kernel was built for, at small sizes
+    (8, 15, 15, 512, 512, 3, 3, 1, 'SAME'),            # ResNet-50 stage 4 3x3 at BASELINE config 2's batch (144 K steps, 15 M tiles)
+    (2, 30, 30, 256, 256, 3, 3, 1, 'SAME'),            # stage 3 3x3
+    (2, 15, 15, 2048, 512, 1, 1, 1, 'SAME'),           # stage 4 reducing 1x1 (64 K steps)
+    (1, 30, 30, 728, 512, 3, 3, 1, 'SAME'),            # RPN 3x3 of one image (207 K steps on 8 x 4 tiles)
+    (1, 300, 1, 2048, 25, 1, 1, 1, 'VALID'),           # head fc_cls+fc_loc (N tile 64, 3 M tiles)
+    (3, 17, 19, 96, 130, 3, 3, 1, 'SAME'),             # ragged: M tail, cout not a tile multiple (N tile 64), 27 K steps
+    (1, 60, 60, 128, 128, 3, 3, 2, 'SAME'),            # strided 3x3 reading planes (ResNet stage openers)
+]
+
+
+@pytest.mark.parametrize('case', KSPLIT_CASES)
+@pytest.mark.parametrize('prec', ['f16x3', 'f16'])
+def test_ksplit_modes_are_bit_identical_and_match_the_plain_kernel(case, prec, oracle):
+    """csrc/conv_mfma_ksplit.hip: (i) with ONE range the kernel reproduces the plain LDS-DMA kernels bit for bit (same
+    per-element product order); (ii) for every ksplit the parallel-ranges mode (scratch slabs + last-arriver fold) and
+    the one-workgroup-per-tile mode (fold at the range boundaries) give the SAME bits -- the split is a property of the
+    layer, the mode a property of the launch; (iii) every split stays within the usual tolerance of the oracle; and the
+    ticket counters clean up after themselves (a second launch gives the same bits)."""
+    from xdet.ops import Conv2D
+    from xdet.runtime import DeviceTensor, set_precision
+    N, H, W, cin, cout, kh, kw, stride, padding = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.standard_normal((N, H, W, cin)).astype(np.float32)
+    k = (rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.standard_normal(cout).astype(np.float32)
+    ref = np.maximum(oracle.conv2d(x, k, stride, padding, 1) * scale + shift, 0)
+    res = None
+    set_precision(prec)
+    try:
+        xd = DeviceTensor.from_numpy(x)
+        conv = Conv2D(k, stride, padding, 1, scale, shift, relu=True)
+        plain = conv(xd, planes=True).numpy()
+        out = {}
+        for S in (1, 2, 3, 4, 8):
+            for mode in (1, 2):
+                conv.set_ksplit(S, mode, 64)
+                a = conv(xd, planes=True).numpy()
+                b = conv(xd, planes=True).numpy()               # tickets were reset by the last arriver
+                assert np.array_equal(a, b), (S, mode)
+                out[(S, mode)] = a
+            assert np.array_equal(out[(S, 1)], out[(S, 2)]), S    # parallel == sequential, bit for bit
+            close(out[(S, 1)], ref, 3e-5 if prec == 'f16x3' else 2e-2)
+        assert np.array_equal(out[(1, 1)], plain)                 # one range == the plain kernels
+        conv.set_ksplit(4, 0, 448)                                # mode by grid size
+        assert np.array_equal(conv(xd, planes=True).numpy(), out[(4, 1)])
+        # residual + the f32 output's companions are the shared epilogue's business: one check through it
+        res = rng.standard_normal(ref.shape).astype(np.float32)
+        conv.set_ksplit(2, 1, 64)
+        y = conv(xd, residual=DeviceTensor.from_numpy(res), planes=True).numpy()
+        conv.set_ksplit(0)
+        y0 = conv(xd, residual=DeviceTensor.from_numpy(res), planes=True).numpy()
+    finally:
+        set_precision('f32')
+    close(y, np.maximum(oracle.conv2d(x, k, stride, padding, 1) * scale + shift + res, 0), 3e-5 if prec == 'f16x3' else 2e-2)
+    close(y, y0, 3e-6 if prec == 'f16x3' else 2e-2)
+
+
+def test_ksplit_is_batch_invariant():
+    """an image's rows do not depend on the batch it arrives in, although small batches run the ranges in parallel and
+    large ones sequentially (mode 0: by grid size)."""
+    from xdet.ops import Conv2D
+    from xdet.runtime import DeviceTensor, set_precision
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((40, 15, 15, 512)).astype(np.float32)
+    k = (rng.standard_normal((3, 3, 512, 512)) / np.sqrt(9 * 512)).astype(np.float32)
+    set_precision('f16x3')
+    try:
+        conv = Conv2D(k, 1, 'SAME', 1, None, None, relu=False)
+        conv.set_ksplit(4, 0, 448 // 4)
+        big = conv(DeviceTensor.from_numpy(x), planes=True).numpy()          # 71 M tiles x 4 N tiles x 4 > 448: sequential
+        for n0, n in ((0, 1), (7, 3), (20, 8)):
+            small = conv(DeviceTensor.from_numpy(x[n0:n0 + n]), planes=True).numpy()   # parallel ranges
+            assert np.array_equal(small, big[n0:n0 + n]), (n0, n)
+    finally:
+        set_precision('f32')
+
+
+@pytest.mark.parametrize('dil', [1, 2])
+def test_depthwise_tile_kernel_beyond_2gib(dil):
+    """the 397 x 397 x 128 tensor of the 800 x 800 input at batch 96 is 7.7 GB; the tile kernel's DMA uses
+    32-bit buffer offsets and round 3 sent the whole tensor to the slow per-row kernel.  Now the launcher cuts the batch
+    into ranges of whole images below 2 GiB (26 + 2 here): same bits as image-by-image calls, also across the cut."""
+    from xdet.ops import DepthwiseConv2D
+    from xdet.runtime import DeviceTensor
+    N, H, W, C = 28, 397, 397, 128                       # 80.7 MB per image: 26 images per range
+    rng = np.random.default_rng(6)
+    two = rng.standard_normal((2, H, W, C)).astype(np.float32)
+    dk = rng.standard_normal((3, 3, C, 1)).astype(np.float32) / 3
+    op = DepthwiseConv2D(dk, dil)
+    x = np.concatenate([two] * 14)
+    xd = DeviceTensor.from_numpy(x)
+    del x
+    y = op(xd, relu_in=True).numpy()
+    ref = op(DeviceTensor.from_numpy(two), relu_in=True).numpy()
+    for k in range(14):                                  # images 26, 27 sit behind the cut
+        assert np.array_equal(y[2 * k:2 * k + 2], ref), k
+
+
+def test_ksplit_fold_in_the_large_tile_kernel_is_the_same_function():
+    """the RPN 3x3 conv carries ksplit = 8 (a single image is 32 tiles against 207 K steps).  At bench-size batches its grid
+    is large and the layer runs on the 256 x 128 LDS-DMA kernel, which folds its accumulators at the range boundaries
+    (FOLD) -- the same expression tree as the parallel-ranges launch a single image takes: same bits."""
+    from xdet.ops import Conv2D
+    from xdet.runtime import DeviceTensor, set_precision
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((48, 30, 30, 728)).astype(np.float32)
+    k = (rng.standard_normal((3, 3, 728, 512)) / np.sqrt(9 * 728)).astype(np.float32)
+    b = rng.standard_normal(512).astype(np.float32)
+    set_precision('f16x3')
+    try:
+        conv = Conv2D(k, 1, 'SAME', 1, None, b, relu=True)
+        conv.set_ksplit(8, 0, 448 // 8)
+        big = conv(DeviceTensor.from_numpy(x), planes=True).numpy()          # 169 x 4 tiles of 256 x 128: the FOLD kernel
+        for n0, n in ((0, 1), (17, 1), (40, 2)):
+            small = conv(DeviceTensor.from_numpy(x[n0:n0 + n]), planes=True).numpy()   # 8 .. 16 M tiles: parallel ranges
+            assert np.array_equal(small, big[n0:n0 + n]), (n0, n)
+        conv.set_ksplit(8, 2, 0)                                             # ... and the split-K kernel's own sequential mode
+        assert np.array_equal(conv(DeviceTensor.from_numpy(x[:3]), planes=True).numpy(), big[:3])
+    finally:
+        set_precision('f32')
+

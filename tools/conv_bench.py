@@ -23,11 +23,28 @@ SHAPES = [  # name, H, W, cin, cout, kh, kw, stride, pad
     ('lsep 15x1 2048->512 @30', 30, 30, 2048, 512, 15, 1, 1, 'SAME'),
     ('lsep 1x15 512->490 @30', 30, 30, 512, 490, 1, 15, 1, 'SAME'),
     ('fc 490->2048 (R=300)', 300, 1, 490, 2048, 1, 1, 1, 'VALID'),
+    ('head 2048->25 (R=300)', 300, 1, 2048, 25, 1, 1, 1, 'VALID'),
+]
+
+
+RESNET_SHAPES = [  # ResNet-50 v2 stages 3-4 (net/resnet_v2.py:142-184) + the detector's small-M layers
+    ('r3 1x1 1024->256 @30', 30, 30, 1024, 256, 1, 1, 1, 'SAME'),
+    ('r3 3x3 256->256 @30', 30, 30, 256, 256, 3, 3, 1, 'SAME'),
+    ('r3 1x1 256->1024 @30', 30, 30, 256, 1024, 1, 1, 1, 'SAME'),
+    ('r4 1x1 2048->512 @15', 15, 15, 2048, 512, 1, 1, 1, 'SAME'),
+    ('r4 3x3 512->512 @15', 15, 15, 512, 512, 3, 3, 1, 'SAME'),
+    ('r4 1x1 512->2048 @15', 15, 15, 512, 2048, 1, 1, 1, 'SAME'),
+    ('r2 1x1 512->128 @60', 60, 60, 512, 128, 1, 1, 1, 'SAME'),
+    ('r2 3x3 128->128 @60', 60, 60, 128, 128, 3, 3, 1, 'SAME'),
+    ('r2 1x1 128->512 @60', 60, 60, 128, 512, 1, 1, 1, 'SAME'),
 ]
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--resnet', action='store_true', help='the ResNet-50 stage 2-4 shapes instead of the detector list')
+    ap.add_argument('--ksplit', default='', help='comma list of split factors to time with --planes on the split-K kernel '
+                                                 '(0 = the plain kernels); each as parallel-ranges / one-workgroup-per-tile')
     ap.add_argument('--precision', default='f32')
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--iters', type=int, default=20)
@@ -36,7 +53,7 @@ def main():
     ap.add_argument('--custom', action='append', default=[],
                     help='extra 1x1 GEMM shape "H,W,cin,cout" (replaces the built-in list); repeatable')
     a = ap.parse_args()
-    shapes = SHAPES
+    shapes = RESNET_SHAPES if a.resnet else SHAPES
     if a.custom:
         shapes = []
         for c in a.custom:
@@ -63,6 +80,22 @@ def main():
             check(lib().xdet_split_f32(x.ptr, hi.ptr, lo.ptr, a.batch * H * W, x.ld, 0, st.handle))
             check(lib().xdet_conv_forward_planes(L.handle, hi.ptr, lo.ptr, a.batch, H, W, x.ld, y.ptr, y.ld, None, st.handle))
             st.synchronize()
+        if a.planes and a.ksplit:
+            res = []
+            for S in [int(v) for v in a.ksplit.split(',')]:
+                for mode in ((0,) if S == 0 else (1, 2) if S > 1 else (2,)):
+                    L.set_ksplit(S, mode, 512)
+                    for _ in range(3):
+                        check(lib().xdet_conv_forward_planes(L.handle, hi.ptr, lo.ptr, a.batch, H, W, x.ld, y.ptr, y.ld, None, st.handle))
+                    st.synchronize()
+                    e0.record(st)
+                    for _ in range(a.iters):
+                        check(lib().xdet_conv_forward_planes(L.handle, hi.ptr, lo.ptr, a.batch, H, W, x.ld, y.ptr, y.ld, None, st.handle))
+                    e1.record(st)
+                    st.synchronize()
+                    res.append('S=%d%s %.1fus' % (S, {0: '', 1: 'p', 2: 's'}[mode] if S else '(plain)', e0.elapsed_ms(e1) / a.iters * 1e3))
+            print('%-28s B=%-3d %s' % (name, a.batch, '  '.join(res)))
+            continue
         e0.record(st)
         for _ in range(a.iters):
             if a.planes:

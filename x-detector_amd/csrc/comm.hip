@@ -258,7 +258,7 @@ static int watchdog_wait(Comm* c, hipEvent_t ev, const char* what) {
     }
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (why.empty() && el > c->timeout_s) {
-      char buf[160];
+      char buf[320];
       snprintf(buf, sizeof(buf), "this wait on the communicator stream exceeded its timeout of %.0f s (waited %.0f s; a peer rank "
                "died, hangs, or legitimately needs longer: XDET_COMM_TIMEOUT_S / xdet_comm_set_timeout)", c->timeout_s, el);
       why = buf;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/xdet.h"   // XDET_OK / XDET_ERR_* codes
+#include "conv_params.h"   // struct ConvParams: what every MFMA conv kernel is launched with
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
@@ -53,11 +54,18 @@ static inline int ensure_dynamic_lds(DeviceOnce& once, const void* kern, int byt
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-#include "conv_params.h"   // struct ConvParams: what every MFMA conv kernel is launched with
+// ---- implicit-GEMM convolutions on the MFMA pipe (conv_mfma*.hip; struct ConvParams: conv_params.h) ----
 int launch_conv_mfma_f32(const ConvParams& p, bool small_cin, int n_tile, hipStream_t s);
 // nsplit 3 = f16x3 (hi/lo f16 operands, f32-class accuracy), 1 = plain f16 operands
 int launch_conv_mfma_split(const ConvParams& p, bool small_cin, int n_tile, int nsplit, hipStream_t s);
 int launch_conv_mfma_dma(const ConvParams& p, int n_tile, int nsplit, hipStream_t s);
+// fixed split-K (conv_mfma_ksplit.hip): mode 0 = parallel ranges when the grid is small, else one workgroup per tile
+// walking all ranges; 1 / 2 force either (tests).  scratch_tiles = tiles the layer's scratch was sized for.
+bool conv_dma_fold_applicable(const ConvParams& p, int n_tile, int nsplit);   // conv_mfma_dma.hip: the fold in the 256 x 128 kernel
+int launch_conv_mfma_dma_fold(const ConvParams& p, hipStream_t s);
+int64_t conv_ksplit_tiles(int64_t M, int cout_pad, int n_tile);
+bool conv_ksplit_supported(int kh, int kw, int64_t n_pix_in, int ld_in, int cin_p, int cout_pad);
+int launch_conv_mfma_ksplit(const ConvParams& p, int n_tile, int nsplit, int mode, int64_t scratch_tiles, hipStream_t s);
 enum { PREC_F32 = 0, PREC_F16X3 = 1, PREC_F16 = 2 };
 
 // ---- element-wise / window kernels (elementwise.hip) ---------------------------------

@@ -34,7 +34,19 @@ typedef unsigned short u16;
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),              \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE>
+// PW (pointwise: 1x1, stride 1, no padding -- 30 of the detector's 46 contractions, all of the dominant ones): the DMA
+// sources are raw BUFFER loads whose per-lane offsets never change along K -- a 16-pixel x 32-channel block of the planes
+// and a 16-row x 32-deep block of the K-blocked weights are both 1 KB runs, 1 KB further per K step -- so a piece is an
+// M0 update plus one `buffer_load_dwordx4 ... lds` with the step's offset in an SGPR: no per-lane address arithmetic, no
+// zero-page select (rows past M are sent out of bounds and read zeros).  The generic form spends ~55 VALU and ~70 SALU
+// instructions per K step on addresses next to its 48 MFMAs, and every issue slot between two MFMAs costs matrix-pipe time
+// (MI355X_MICROARCH.md).  Same bytes into the same LDS places: results are bit-identical (tests/test_gpu_layers.py).
+// FOLD: the layer's reduction is DEFINED with a fixed split (p.ksplit ranges of whole channel chunks, result = the left
+// fold of the per-range sums: conv_mfma_ksplit.hip, which runs the ranges on separate workgroups when the grid is small).
+// At large batch this kernel walks all ranges in its one K pipeline and folds its accumulators at the range boundaries:
+// the same expression tree, the same bits, without scratch traffic -- on the 256 x 128 tile, whose 64 accumulator registers
+// per wave leave room for the running total.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE, bool PW = false, bool FOLD = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(ConvParams p_in) {
   static_assert(NSTAGE == 2, "two LDS stages");
   constexpr int NW = WAVES_M * WAVES_N;          // waves per workgroup (4 or 8)
@@ -116,11 +128,52 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
   const int ntaps = p.KH * p.KW;
   const unsigned c32n = (unsigned)(p.ldi >> 5);   // channel blocks per 16-pixel group of a split plane
 
+  // PW: buffer resources over the whole planes / weight tensors (host: each below 4 GiB) and the K-invariant per-lane
+  // byte offsets of this wave's pieces
+  __amdgpu_buffer_rsrc_t r_ah, r_al, r_bh, r_bl;
+  unsigned a_vo[A_IT], b_vo[B_IT];
+  if (PW) {
+    const unsigned a_bytes = (unsigned)(((size_t)((p.M + 15) >> 4) * c32n) << 10);
+    const unsigned b_bytes = (unsigned)((size_t)nk * p.Cout_pad * 64);
+    r_ah = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.in_hi), 0, (int)a_bytes, 0x00020000);
+    r_al = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(NSPLIT > 1 ? p.in_lo : p.in_hi), 0, (int)a_bytes, 0x00020000);
+    r_bh = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.wt_hi), 0, (int)b_bytes, 0x00020000);
+    r_bl = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(NSPLIT > 1 ? p.wt_lo : p.wt_hi), 0, (int)b_bytes, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < A_IT; ++q) {
+      const int rt = (wave * A_IT + q) * 16 + lr;
+      const int m = m0 + rt;                       // input pixel == output pixel
+      a_vo[q] = m < p.M ? (((unsigned)(m >> 4) * c32n) << 10) + (unsigned)((((m & 15) << 5) + achunk[q]) * 2) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int q = 0; q < B_IT; ++q) b_vo[q] = (unsigned)(boff[q] * 2);
+  }
+
   auto issue = [&](int kt, int buf) {
     u16* Ah = smem16 + buf * STAGE;
     u16* Al = Ah + BM * ROWB;
     u16* Bh = Al + BM * ROWB;
     u16* Bl = Bh + BN * ROWB;
+    if (PW) {
+      const unsigned a_so = (unsigned)kt << 10;                      // channel block kt of every 16-pixel group
+      const unsigned b_so = (unsigned)kt * (unsigned)p.Cout_pad * 64u;   // K block kt of the weights
+#pragma unroll
+      for (int q = 0; q < A_IT; ++q) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_ah, (__attribute__((address_space(3))) void*)(Ah + (wave * A_IT + q) * 16 * ROWB),
+                                                 16, (int)a_vo[q], (int)a_so, 0, 0);
+        if (NSPLIT > 1)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_al, (__attribute__((address_space(3))) void*)(Al + (wave * A_IT + q) * 16 * ROWB),
+                                                   16, (int)a_vo[q], (int)a_so, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < B_IT; ++q) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_bh, (__attribute__((address_space(3))) void*)(Bh + (wave * B_IT + q) * 16 * ROWB),
+                                                 16, (int)b_vo[q], (int)b_so, 0, 0);
+        if (NSPLIT > 1)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_bl, (__attribute__((address_space(3))) void*)(Bl + (wave * B_IT + q) * 16 * ROWB),
+                                                   16, (int)b_vo[q], (int)b_so, 0, 0);
+      }
+    } else {
     // K order: channel chunk outer, filter tap inner.  The KH*KW shifted views of one 32-channel
     // slab are consumed back to back, so a multi-tap conv (3x3, 15x1, 1x15) pulls each activation
     // line over the fabric once and takes the other taps from L2; tap-outer order streamed the
@@ -148,6 +201,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
     for (int q = 0; q < B_IT; ++q) {
       XDET_GLDS16(p.wt_hi + boff[q] + k0, Bh + (wave * B_IT + q) * 16 * ROWB);
       if (NSPLIT > 1) XDET_GLDS16(p.wt_lo + boff[q] + k0, Bl + (wave * B_IT + q) * 16 * ROWB);
+    }
     }
   };
 
@@ -184,6 +238,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
   //     DMA      stage kt+2 -> the buffer stage kt just vacated (a whole step to land)
   //     ds_read  half 0 of stage kt+1      -> set A      (lands under the MFMAs below)
   //     MFMA     half 1 of stage kt        (set B)
+  // FOLD state: steps per range = (channel chunks per range) x taps, as conv_mfma_ksplit.hip defines the ranges
+  f32x16 tot[FOLD ? TM : 1][FOLD ? TN : 1];
+  int fold_steps = 1 << 30, next_fold = 1 << 30;
+  bool first_range = true;
+  if constexpr (FOLD) {
+    const int ncc = p.Cin_p >> 5, S = p.ksplit > 0 ? p.ksplit : 1;
+    fold_steps = ((ncc + S - 1) / S) * ntaps;
+    next_fold = fold_steps;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+  }
+  // JN = live 32-column blocks of this wave's tile (TN, or fewer in the last N tile of a layer whose channel count is
+  // padded up to the tile: 728 -> 768 leaves the 24th block of 28 layers all zero).  A wave whose last block is padding
+  // skips its MFMAs and fragment reads -- same results (the block is never stored), 1/24 of those layers' matrix work.
+  auto main_loop = [&](auto JN_) {
+  constexpr int JN = decltype(JN_)::value;
   auto load_frags = [&](int buf, int ks, f16x8* ah, f16x8* al, f16x8* bh, f16x8* bl) {
     const u16* Ah = smem16 + buf * STAGE;
     const u16* Al = Ah + BM * ROWB;
@@ -197,7 +271,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
       if (NSPLIT > 1) al[i] = *reinterpret_cast<const f16x8*>(Al + o);
     }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
+    for (int j = 0; j < JN; ++j) {
       const int o = boffs[j] + ((c ^ bsw[j]) << 3);
       bh[j] = *reinterpret_cast<const f16x8*>(Bh + o);
       if (NSPLIT > 1) bl[j] = *reinterpret_cast<const f16x8*>(Bl + o);
@@ -208,18 +282,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < JN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < JN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < JN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
   };
 
@@ -236,6 +310,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
   auto step = [&](int kt, auto steady) {
     constexpr bool STEADY = decltype(steady)::value;
     const int buf = kt & 1;
+    if constexpr (FOLD) {
+      if (kt == next_fold) {                     // range boundary: every MFMA of the range before it has been issued
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            tot[i][j] = first_range ? acc[i][j] : tot[i][j] + acc[i][j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          }
+        first_range = false;
+        next_fold += fold_steps;
+      }
+    }
     load_frags(buf, 1, a1h, a1l, b1h, b1l);
     __builtin_amdgcn_sched_barrier(0);
     mma(a0h, a0l, b0h, b0l);
@@ -249,8 +337,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
     mma(a1h, a1l, b1h, b1l);
     if (STEADY) {
       constexpr int NPIECE = (A_IT + B_IT) * (NSPLIT > 1 ? 2 : 1);
-      constexpr int NMMA = TM * TN * (NSPLIT > 1 ? 3 : 1);
-      constexpr int NRD = (TM + TN) * (NSPLIT > 1 ? 2 : 1);
+      constexpr int NMMA = TM * JN * (NSPLIT > 1 ? 3 : 1);
+      constexpr int NRD = (TM + JN) * (NSPLIT > 1 ? 2 : 1);
       __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
 #pragma unroll
       for (int k = 0; k < NPIECE; ++k) {
@@ -263,7 +351,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
   int kt = 0;
   for (; kt + 2 < nk; ++kt) step(kt, std::true_type{});
   for (; kt < nk; ++kt) step(kt, std::false_type{});
+  };
+  // live column blocks: columns at or beyond ldo (= round_up(cout, 32)) are padding of the N tile
+  const int jn_live = (p.ldo - (n0 + wn * WN) + 31) >> 5;      // wave-uniform
+  static_assert(TN == 2, "the tiles of this kernel are two column blocks per wave");
+  // (pointwise form only: the generic form has no registers to spare for a second copy of the loop's address state)
+  if constexpr (PW) {
+    if (jn_live == 1 && p.skip_dead != 0) main_loop(std::integral_constant<int, 1>{});
+    else main_loop(std::integral_constant<int, TN>{});
+  } else {
+    main_loop(std::integral_constant<int, TN>{});
+  }
 
+  if constexpr (FOLD) {
+    if (!first_range) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = tot[i][j] + acc[i][j];
+    }
+  }
   conv_epilogue<WM, WN, TM, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wm, wn, m0, n0);
 }
 
@@ -286,7 +393,7 @@ __device__ __forceinline__ f16x8 cd_ds_read_b128(unsigned addr) {
   return r;
 }
 
-template <int NSPLIT>
+template <int NSPLIT, bool PW = false>
 __global__ __launch_bounds__(256) void conv_dma_deep_kernel(ConvParams p_in) {
   constexpr int BM = 128, BN = 64, NW = 4;
   constexpr int PAIR = 2;                          // K steps per barrier
@@ -356,12 +463,48 @@ __global__ __launch_bounds__(256) void conv_dma_deep_kernel(ConvParams p_in) {
   const int ntaps = p.KH * p.KW;
   const unsigned c32n = (unsigned)(p.ldi >> 5);
 
+  // PW (1x1, stride 1): raw buffer loads with K-invariant per-lane offsets, see conv_dma_f16_kernel
+  unsigned a_vo[A_IT], b_vo[B_IT];
+  unsigned a_bytes = 0, b_bytes = 0;
+  if (PW) {
+    a_bytes = (unsigned)(((size_t)((p.M + 15) >> 4) * c32n) << 10);
+    b_bytes = (unsigned)((size_t)nk * p.Cout_pad * 64);
+#pragma unroll
+    for (int q = 0; q < A_IT; ++q) {
+      const int rt = (wave * A_IT + q) * 16 + lr;
+      const int m = m0 + rt;
+      a_vo[q] = m < p.M ? (((unsigned)(m >> 4) * c32n) << 10) + (unsigned)((((m & 15) << 5) + achunk[q]) * 2) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int q = 0; q < B_IT; ++q) b_vo[q] = (unsigned)(boff[q] * 2);
+  }
+
   auto issue = [&](int kt, int buf) {              // always PIECES instructions
     u16* Ah = smem16 + buf * STAGE;
     u16* Al = Ah + BM * ROWB;
     u16* Bh = Al + BM * ROWB;
     u16* Bl = Bh + BN * ROWB;
     const bool live = kt < nk;
+    if (PW) {
+      // a stage past the end reads a zero-length buffer: every lane out of bounds, zeros
+      const __amdgpu_buffer_rsrc_t r_ah = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.in_hi), 0, live ? (int)a_bytes : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t r_al = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(NSPLIT > 1 ? p.in_lo : p.in_hi), 0, live ? (int)a_bytes : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t r_bh = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.wt_hi), 0, live ? (int)b_bytes : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t r_bl = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(NSPLIT > 1 ? p.wt_lo : p.wt_hi), 0, live ? (int)b_bytes : 0, 0x00020000);
+      const unsigned a_so = (unsigned)kt << 10, b_so = (unsigned)kt * (unsigned)p.Cout_pad * 64u;
+#pragma unroll
+      for (int q = 0; q < A_IT; ++q) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_ah, (__attribute__((address_space(3))) void*)(Ah + (wave * A_IT + q) * 16 * ROWB), 16, (int)a_vo[q], (int)a_so, 0, 0);
+        if (NSPLIT > 1)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_al, (__attribute__((address_space(3))) void*)(Al + (wave * A_IT + q) * 16 * ROWB), 16, (int)a_vo[q], (int)a_so, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < B_IT; ++q) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_bh, (__attribute__((address_space(3))) void*)(Bh + (wave * B_IT + q) * 16 * ROWB), 16, (int)b_vo[q], (int)b_so, 0, 0);
+        if (NSPLIT > 1)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_bl, (__attribute__((address_space(3))) void*)(Bl + (wave * B_IT + q) * 16 * ROWB), 16, (int)b_vo[q], (int)b_so, 0, 0);
+      }
+    } else {
     const int cc = kt / ntaps;
     const int tap = kt - cc * ntaps;
     const int ky = tap / p.KW;
@@ -380,6 +523,7 @@ __global__ __launch_bounds__(256) void conv_dma_deep_kernel(ConvParams p_in) {
     for (int q = 0; q < B_IT; ++q) {
       XDET_GLDS16(live ? p.wt_hi + boff[q] + k0 : p.zeros, Bh + (wave * B_IT + q) * 16 * ROWB);
       if (NSPLIT > 1) XDET_GLDS16(live ? p.wt_lo + boff[q] + k0 : p.zeros, Bl + (wave * B_IT + q) * 16 * ROWB);
+    }
     }
   };
 
@@ -457,10 +601,20 @@ __global__ __launch_bounds__(256) void conv_dma_deep_kernel(ConvParams p_in) {
   conv_epilogue<32, 64, 1, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wave, 0, m0, n0);
 }
 
-template <int NSPLIT>
+// pointwise layers whose planes and weights stay below 4 GiB (32-bit buffer offsets) take the buffer-load form
+static bool pw_eligible(const ConvParams& p) {
+  static const bool off = getenv("XDET_CONV_PW") && !strcmp(getenv("XDET_CONV_PW"), "0");   // A/B runs
+  if (off || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad_t != 0 || p.pad_l != 0 || p.H != p.Ho || p.W != p.Wo) return false;
+  const size_t a_bytes = ((size_t)((p.M + 15) >> 4) * (size_t)(p.ldi >> 5)) << 10;
+  const size_t b_bytes = (size_t)(p.Kp / 32) * p.Cout_pad * 64;
+  return a_bytes < ((size_t)1 << 32) && b_bytes < ((size_t)1 << 32) && p.Cin_p == p.Kp;
+}
+
+template <int NSPLIT, bool PW = false>
 static int launch_deep(const ConvParams& p, hipStream_t s) {
+  if (!PW && pw_eligible(p)) return launch_deep<NSPLIT, true>(p, s);
   constexpr size_t lds = (size_t)6 * (2 * 128 + 2 * 64) * 32 * sizeof(u16);
-  auto kern = conv_dma_deep_kernel<NSPLIT>;
+  auto kern = conv_dma_deep_kernel<NSPLIT, PW>;
   static DeviceOnce once;
   XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
   dim3 grid((unsigned)(cdiv(cdiv(p.M, 128), 8) * 8 * (p.Cout_pad / 64)));
@@ -473,10 +627,11 @@ static int launch_deep(const ConvParams& p, hipStream_t s) {
   return XDET_OK;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE = 2>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE = 2, bool PW = false>
 static int launch_d(const ConvParams& p, hipStream_t s) {
+  if (!PW && pw_eligible(p)) return launch_d<BM, BN, WAVES_M, WAVES_N, NSPLIT, NSTAGE, true>(p, s);
   constexpr size_t lds = (size_t)NSTAGE * (2 * BM + 2 * BN) * 32 * sizeof(u16);
-  auto kern = conv_dma_f16_kernel<BM, BN, WAVES_M, WAVES_N, NSPLIT, NSTAGE>;
+  auto kern = conv_dma_f16_kernel<BM, BN, WAVES_M, WAVES_N, NSPLIT, NSTAGE, PW>;
   static DeviceOnce once;
   XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
   dim3 grid((unsigned)(cdiv(cdiv(p.M, BM), 8) * 8 * (p.Cout_pad / BN)));
@@ -489,7 +644,25 @@ static int launch_d(const ConvParams& p, hipStream_t s) {
   return XDET_OK;
 }
 
-int launch_conv_mfma_dma(const ConvParams& p, int n_tile, int nsplit, hipStream_t s) {
+// the large-batch form of a layer whose reduction carries a fixed split (see FOLD above); false = not applicable here
+bool conv_dma_fold_applicable(const ConvParams& p, int n_tile, int nsplit) {
+  return n_tile == 128 && nsplit == 3 && p.group_rows == 0 && p.ksplit > 1 && cdiv(p.M, 256) * (p.Cout_pad / 128) >= 170;
+}
+int launch_conv_mfma_dma_fold(const ConvParams& p, hipStream_t s) {
+  constexpr size_t lds = (size_t)2 * (2 * 256 + 2 * 128) * 32 * sizeof(u16);
+  auto kern = conv_dma_f16_kernel<256, 128, 4, 2, 3, 2, false, true>;
+  static DeviceOnce once;
+  XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
+  dim3 grid((unsigned)(cdiv(cdiv(p.M, 256), 8) * 8 * (p.Cout_pad / 128)));
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
+int launch_conv_mfma_dma(const ConvParams& p_in, int n_tile, int nsplit, hipStream_t s) {
+  static const bool no_skip = getenv("XDET_CONV_SKIP_DEAD") && !strcmp(getenv("XDET_CONV_SKIP_DEAD"), "0");   // A/B runs
+  ConvParams p = p_in;
+  p.skip_dead = no_skip ? 0 : 1;
   XDET_REQUIRE(p.Kp % 32 == 0 && p.Cin_p % 32 == 0 && p.ldi >= p.Cin_p && p.ldi % 8 == 0,
                "conv(dma): channel counts must be padded to 32");
   XDET_REQUIRE(p.Cout_pad % n_tile == 0, "conv(dma): Cout_pad must be a multiple of the N tile");

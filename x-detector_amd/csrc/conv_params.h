@@ -40,6 +40,12 @@ struct ConvParams {
   // and scale/shift row g (+ g*Cout_pad).  group_rows is a multiple of every M tile; 0 = one group.
   int group_rows;
   long long group_wt_stride;
+  // fixed split of the reduction (conv_mfma_ksplit.hip only): the K steps are cut into `ksplit` equal ranges and the
+  // result is the left fold of the per-range sums; ks_partial = scratch slabs [tiles][ksplit][128 x N tile] f32 of
+  // the mode that runs the ranges in parallel
+  int skip_dead = 1;   // conv_dma_f16_kernel: waves skip 32-column blocks that are pure padding of the N tile (0: A/B runs)
+  int ksplit = 1;
+  float* ks_partial = nullptr;
 };
 
 }  // namespace xdet

@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256) void depthwise3x3_tile_kernel(const float* __r
                                                                 unsigned short* __restrict__ hi,
                                                                 unsigned short* __restrict__ lo, int N, int H, int W,
                                                                 int ld, int relu_in, int ntiles, int TY, int TX,
-                                                                int tiles_per_block) {
+                                                                int tiles_per_block, int n_first) {
+  // `in` points at image n_first of the tensor and N images are covered (one launch per range of images below 2 GiB:
+  // the DMA's buffer offsets are 32-bit); `out` / `hi` / `lo` are the whole tensor's, indexed with n_first + n
   static_assert(DT_X + 2 * DIL <= DT_P, "patch row does not fit the LDS pitch");
   constexpr int DT_ROWS = DT_R + 2 * DIL, DT_TILE_F = DT_ROWS * DT_P * 32;   // floats per LDS tile buffer
   constexpr int NC = 4 + 2 * DIL;                                          // input pixels a strip of 4 needs
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_tile_kernel(const float* __r
           acc[k].z = fmaf(v.z, ww.z, acc[k].z); acc[k].w = fmaf(v.w, ww.w, acc[k].w);
         }
       }
-    dw_store_strip<SPLIT>(acc, out, hi, lo, ((int64_t)n * H + y) * W, x0 + strip * 4, W, ld, c);
+    dw_store_strip<SPLIT>(acc, out, hi, lo, ((int64_t)(n_first + n) * H + y) * W, x0 + strip * 4, W, ld, c);
   }
 }
 
@@ -297,25 +299,35 @@ static int launch_dw(const float* in, const float* w9c, float* out, unsigned sho
   const int yblocks = (int)cdiv(items, 256);
   const dim3 grid((unsigned)(cdiv(nrows, 8) * 8 * yblocks));
   const bool split = hi != nullptr;
-  // the LDS-pipelined tile kernel; its 32-bit buffer offsets need the tensor below 2 GiB, else the per-row kernel
-  if (ld % 32 == 0 && (int64_t)N * H * W * ld * 4 < ((int64_t)1 << 31)) {
+  // the LDS-pipelined tile kernel; its 32-bit buffer offsets cover 2 GiB: one launch per range of whole images below that
+  // (the 397 x 397 x 128 tensor of the 800 x 800 input at batch 96 is 7.7 GB; round 3 sent it to the per-row kernel:
+  // 11.7 % of that workload's GPU time).  A single image beyond 2 GiB still takes the per-row kernel.
+  const int64_t per_image = (int64_t)H * W * ld * 4;
+  if (ld % 32 == 0 && per_image < ((int64_t)1 << 31)) {
+    const int n_max = (int)std::max<int64_t>(1, (((int64_t)1 << 31) - 1) / per_image);
     const int TY = (int)cdiv(H, DT_R), TX = (int)cdiv(W, DT_X);
-    const int64_t nt = (int64_t)(ld / 32) * N * TY * TX;
     const size_t lds = (size_t)2 * (DT_R + 2 * dil) * DT_P * 32 * sizeof(float);
-    const int blocks = (int)std::min<int64_t>(nt, lds > 80 * 1024 ? 256 : 512);   // workgroups per CU that fit in LDS
-    const int tpb = (int)cdiv(nt, blocks);
-    const dim3 g((unsigned)cdiv(nt, tpb));
-    if (dil == 1) {
-      if (split) hipLaunchKernelGGL((depthwise3x3_tile_kernel<1, true>), g, dim3(256), lds, s, in, w9c, out, hi, lo, N, H, W, ld, relu_in, (int)nt, TY, TX, tpb);
-      else hipLaunchKernelGGL((depthwise3x3_tile_kernel<1, false>), g, dim3(256), lds, s, in, w9c, out, hi, lo, N, H, W, ld, relu_in, (int)nt, TY, TX, tpb);
-    } else {
+    if (dil == 2) {
       static DeviceOnce once_t, once_f;
       XDET_TRY(ensure_dynamic_lds(once_t, reinterpret_cast<const void*>(depthwise3x3_tile_kernel<2, true>), (int)lds));
       XDET_TRY(ensure_dynamic_lds(once_f, reinterpret_cast<const void*>(depthwise3x3_tile_kernel<2, false>), (int)lds));
-      if (split) hipLaunchKernelGGL((depthwise3x3_tile_kernel<2, true>), g, dim3(256), lds, s, in, w9c, out, hi, lo, N, H, W, ld, relu_in, (int)nt, TY, TX, tpb);
-      else hipLaunchKernelGGL((depthwise3x3_tile_kernel<2, false>), g, dim3(256), lds, s, in, w9c, out, hi, lo, N, H, W, ld, relu_in, (int)nt, TY, TX, tpb);
     }
-    XDET_LAUNCH_CHECK();
+    for (int nb = 0; nb < N; nb += n_max) {
+      const int n = std::min(n_max, N - nb);
+      const float* in_r = in + (size_t)nb * H * W * ld;
+      const int64_t nt = (int64_t)(ld / 32) * n * TY * TX;
+      const int blocks = (int)std::min<int64_t>(nt, lds > 80 * 1024 ? 256 : 512);   // workgroups per CU that fit in LDS
+      const int tpb = (int)cdiv(nt, blocks);
+      const dim3 g((unsigned)cdiv(nt, tpb));
+      if (dil == 1) {
+        if (split) hipLaunchKernelGGL((depthwise3x3_tile_kernel<1, true>), g, dim3(256), lds, s, in_r, w9c, out, hi, lo, n, H, W, ld, relu_in, (int)nt, TY, TX, tpb, nb);
+        else hipLaunchKernelGGL((depthwise3x3_tile_kernel<1, false>), g, dim3(256), lds, s, in_r, w9c, out, hi, lo, n, H, W, ld, relu_in, (int)nt, TY, TX, tpb, nb);
+      } else {
+        if (split) hipLaunchKernelGGL((depthwise3x3_tile_kernel<2, true>), g, dim3(256), lds, s, in_r, w9c, out, hi, lo, n, H, W, ld, relu_in, (int)nt, TY, TX, tpb, nb);
+        else hipLaunchKernelGGL((depthwise3x3_tile_kernel<2, false>), g, dim3(256), lds, s, in_r, w9c, out, hi, lo, n, H, W, ld, relu_in, (int)nt, TY, TX, tpb, nb);
+      }
+      XDET_LAUNCH_CHECK();
+    }
     return XDET_OK;
   }
   if (dil == 1 && !split) hipLaunchKernelGGL((depthwise3x3_kernel<1, false>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows, yblocks);

@@ -122,6 +122,24 @@ struct ConvLayer : LayerBase {
   // through the epilogue's pl_scale / pl_shift.  Both 0 unless a calibration found a tensor near the f16 range.
   std::vector<float> h_scale;          // host copy of d_scale at in_exp = 0
   int in_exp = 0, out_exp = 0;
+  // Fixed split of the reduction (conv_mfma_ksplit.hip): a constant of the LAYER, set at plan time; once enabled the
+  // layer runs on that kernel at every batch size (its two modes are bit-identical), so results never depend on the batch.
+  int ksplit = 0;                      // 0 = the layer is not on the split-K kernel
+  int ks_mode = 0;                     // 0 = by grid size, 1 = parallel ranges, 2 = one workgroup per tile (tests)
+  int64_t ks_tiles = 0;                // tiles the scratch below was sized for
+  float* d_ks_partial = nullptr;
+  int enable_ksplit(int S, int64_t max_parallel_tiles) {
+    XDET_REQUIRE(S >= 1 && S <= 16 && dma_capable() && groups == 1, "ksplit: 1..16 ranges, a split-precision non-grouped layer");
+    if (d_ks_partial) (void)hipFree(d_ks_partial);
+    d_ks_partial = nullptr;
+    ks_tiles = std::max<int64_t>(max_parallel_tiles, 1);
+    if (S > 1) {
+      const size_t slab = (size_t)128 * (cout_pad % 128 == 0 ? 128 : 64) * sizeof(float);
+      XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_ks_partial), (size_t)ks_tiles * S * slab));
+    }
+    ksplit = S;
+    return XDET_OK;
+  }
   float *d_pl_scale = nullptr, *d_pl_shift = nullptr;
   int set_in_exp(int e) {
     std::vector<float> v(h_scale);
@@ -130,20 +148,36 @@ struct ConvLayer : LayerBase {
     in_exp = e;
     return XDET_OK;
   }
+  // planes copy of the output: relu?(out * pl_scale + pl_shift).  Without a folded BN pl = (2^-e, 0); with one (the
+  // pre-activation of the next ResNet block, net/resnet_v2.py:142-156) pl = (bn_scale 2^-e, bn_shift 2^-e):
+  // relu(x s + h) 2^-e = relu(x (s 2^-e) + h 2^-e), exactly.
+  std::vector<float> h_pl_bn_scale, h_pl_bn_shift;   // the folded BN at e = 0 (empty: none)
+  bool planes_bn() const { return !h_pl_bn_scale.empty(); }
+  int set_planes_bn(const std::vector<float>& sc, const std::vector<float>& sh) {
+    h_pl_bn_scale = sc;
+    h_pl_bn_shift = sh;
+    return set_out_exp(0);
+  }
   int set_out_exp(int e) {
     const size_t n = (size_t)std::max(cout_pad, ld_out());
     if (!d_pl_scale) {
       XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_pl_scale), n * sizeof(float)));
       XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_pl_shift), n * sizeof(float)));
-      XDET_HIP(hipMemset(d_pl_shift, 0, n * sizeof(float)));
     }
-    std::vector<float> v(n, ldexpf(1.f, -e));
-    XDET_HIP(hipMemcpy(d_pl_scale, v.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<float> a(n, ldexpf(1.f, -e)), b(n, 0.f);
+    if (planes_bn())
+      for (size_t i = 0; i < n; ++i) {
+        a[i] = i < h_pl_bn_scale.size() ? ldexpf(h_pl_bn_scale[i], -e) : 0.f;
+        b[i] = i < h_pl_bn_shift.size() ? ldexpf(h_pl_bn_shift[i], -e) : 0.f;
+      }
+    XDET_HIP(hipMemcpy(d_pl_scale, a.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    XDET_HIP(hipMemcpy(d_pl_shift, b.data(), n * sizeof(float), hipMemcpyHostToDevice));
     out_exp = e;
     return XDET_OK;
   }
 
   ~ConvLayer() override {
+    if (d_ks_partial) (void)hipFree(d_ks_partial);
     if (d_pl_scale) (void)hipFree(d_pl_scale);
     if (d_pl_shift) (void)hipFree(d_pl_shift);
     if (d_zeros) (void)hipFree(d_zeros);
@@ -300,6 +334,10 @@ struct ConvLayer : LayerBase {
     if (in_hi) {   // A operand already split into f16 planes by its producer: LDS-DMA kernel
       XDET_REQUIRE(!small_cin && relu_in == 0, "conv(dma): needs >= 32 input channels and no ReLU-on-load");
       p.wt_hi = d_wt_hi_b; p.wt_lo = d_wt_lo_b;   // K-blocked copies
+      if (ksplit >= 1 && groups == 1 && conv_ksplit_supported(kh, kw, (int64_t)N * H * W, ldi, cin_p, cout_pad)) {
+        p.ksplit = ksplit; p.ks_partial = d_ks_partial;
+        return launch_conv_mfma_ksplit(p, cout_pad % 128 == 0 ? 128 : 64, precision == PREC_F16X3 ? 3 : 1, ks_mode, ks_tiles, s);
+      }
       return launch_conv_mfma_dma(p, n_tile, precision == PREC_F16X3 ? 3 : 1, s);
     }
     return launch_conv_mfma_split(p, small_cin, n_tile, precision == PREC_F16X3 ? 3 : 1, s);
@@ -363,6 +401,7 @@ struct Op {
 struct ProfRec { int op; hipEvent_t a, b; };
 
 struct Plan {
+  int plan_kind = -1; // 0 = LightHeadNet, 1 = ResNetTrunk: the C-ABI takes void* handles and checks what it was given
   int device = 0;     // HIP device the plan's weights and workspace live on (current device at creation)
   int max_batch = 1;
   bool profiling = false;
@@ -474,6 +513,80 @@ struct Plan {
     return XDET_OK;
   }
 
+  // Choose the activation pre-scale exponents from a calibration batch.  Pass by pass: run the forward (`run`),
+  // take the largest magnitude of every split-precision operand (as stored, i.e. already scaled), and raise the exponent
+  // of the tensors above kRangeTarget.  A tensor that overflowed (inf / NaN in its hi plane) invalidates everything
+  // computed from it, so a pass stops adjusting at the first such tensor (+8 binades) and the next pass re-measures.
+  // Plans whose activations stay below the target keep every exponent at 0: nothing changes, bit for bit.
+  int calibrate_planes(int N, hipStream_t s, int* n_scaled, const std::function<int(hipStream_t)>& run) {
+    if (n_scaled) *n_scaled = 0;
+    if (pscales.empty()) return XDET_OK;
+    unsigned* d_max = nullptr;
+    XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_max), pscales.size() * sizeof(unsigned)));
+    std::vector<unsigned> h_max(pscales.size());
+    int rc = XDET_OK;
+    for (const PlaneScale& p : pscales)
+      if (p.clear && rc == XDET_OK) rc = p.clear(s);
+    const int max_passes = (int)pscales.size() + 4;
+    const bool verbose = getenv("XDET_CALIBRATE_VERBOSE") != nullptr;
+    int pass = 0;
+    for (; pass < max_passes && rc == XDET_OK; ++pass) {
+      if ((rc = hipMemsetAsync(d_max, 0, pscales.size() * sizeof(unsigned), s) == hipSuccess ? XDET_OK : XDET_ERR_HIP) != XDET_OK) break;
+      if ((rc = run(s)) != XDET_OK) break;
+      for (size_t i = 0; i < pscales.size() && rc == XDET_OK; ++i) {
+        const PlaneScale& p = pscales[i];
+        rc = p.hi ? launch_absmax_planes(p.hi, p.halves(N), d_max + i, s)
+                  : launch_absmax_f32(p.src, (int64_t)N * (int64_t)p.src_per_image, p.src_relu, d_max + i, s);
+      }
+      if (rc != XDET_OK) break;
+      if (hipMemcpyAsync(h_max.data(), d_max, h_max.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess ||
+          hipStreamSynchronize(s) != hipSuccess) { rc = XDET_ERR_HIP; break; }
+      bool changed = false;
+      for (size_t i = 0; i < pscales.size() && rc == XDET_OK; ++i) {
+        const PlaneScale& p = pscales[i];
+        float m;                                     // magnitude of the operand as the MFMAs would see it now
+        bool broken;
+        if (p.hi) {
+          broken = h_max[i] >= 0x7c00u;
+          m = broken ? 0.f : f16_to_f32((unsigned short)h_max[i]);
+        } else {
+          broken = h_max[i] >= 0x7f800000u;
+          float x;
+          memcpy(&x, &h_max[i], 4);
+          m = broken ? 0.f : ldexpf(x * p.bound, -p.exp);
+          if (!broken && !(m <= 3.0e38f)) broken = true;
+        }
+        if (verbose && (broken || m > kRangeTarget))
+          fprintf(stderr, "xdet calibrate: pass %d  %-70s exp %d  max %s%g\n", pass, p.name.c_str(), p.exp,
+                  broken ? "inf/NaN " : "", (double)m);
+        if (broken) {
+          rc = set_plane_exp((int)i, p.exp + 8);
+          changed = true;
+          break;                                     // downstream tensors were computed from garbage: re-measure
+        }
+        if (m > kRangeTarget) {
+          int e = 0;
+          (void)frexpf(m / kRangeTarget, &e);        // m / target in [2^(e-1), 2^e)
+          rc = set_plane_exp((int)i, p.exp + e);
+          changed = true;
+        }
+      }
+      if (!changed) break;
+    }
+    (void)hipFree(d_max);
+    XDET_TRY(rc);
+    if (pass >= max_passes) {
+      set_last_error("calibrate: the activation ranges did not settle (non-finite inputs or weights?)");
+      return XDET_ERR_STATE;
+    }
+    if (n_scaled) {
+      int n = 0;
+      for (const PlaneScale& p : pscales) n += p.exp != 0;
+      *n_scaled = n;
+    }
+    return XDET_OK;
+  }
+
   // ---- split-precision planes ----
   unsigned short* zeros = nullptr;
   int get_zeros() {
@@ -521,7 +634,29 @@ struct Plan {
   // With emit_bn_scale/shift set (device arrays, ld floats) the planes copy is relu(out*scale+shift):
   // a following BN+ReLU pre-activation folded into this conv's epilogue.
   int emit_planes_next = 0;
-  const float *emit_bn_scale = nullptr, *emit_bn_shift = nullptr;
+  std::vector<float> emit_bn_scale, emit_bn_shift;   // host, ld floats each (empty: no folded BN)
+  // Split-K policy (conv_mfma_ksplit.hip).  ksplit_design_batch > 0: a conv whose grid at THAT batch size (a constant
+  // of the plan: 8 for the ResNet trunk = BASELINE config 2, 1 for the detector's single-image latency path) leaves
+  // most of the 256 CUs idle gets its K steps cut into S ranges, S = what fills the chip at the design batch, at
+  // least 8 steps per range.  S depends on the layer and the plan constant only -- never on the batch of a call.
+  int ksplit_design_batch = 0;
+  bool ksplit_next = false;            // builders of plans that split only some layers set this before add_conv
+  bool ksplit_all = false;
+  static int pow2_floor(int64_t v) { int r = 1; while ((int64_t)r * 2 <= v) r *= 2; return r; }
+  int maybe_ksplit(ConvLayer* L, int Hi, int Wi, int Ho, int Wo) {
+    const bool want = ksplit_design_batch > 0 && (ksplit_all || ksplit_next);
+    ksplit_next = false;
+    if (!want || !L->dma_capable() || L->groups != 1 || L->cout_pad % 64 != 0) return XDET_OK;
+    if (!conv_ksplit_supported(L->kh, L->kw, (int64_t)max_batch * Hi * Wi, L->ld_in(), L->cin_p, L->cout_pad)) return XDET_OK;
+    const int bn = L->cout_pad % 128 == 0 ? 128 : 64, nk = L->kp / 32;
+    const int64_t tiles = conv_ksplit_tiles((int64_t)ksplit_design_batch * Ho * Wo, L->cout_pad, bn);
+    static const int max_s = getenv("XDET_KSPLIT_MAX") ? atoi(getenv("XDET_KSPLIT_MAX")) : 8;      // A/B knobs
+    static const int max_tiles = getenv("XDET_KSPLIT_TILES") ? atoi(getenv("XDET_KSPLIT_TILES")) : 128;
+    if (tiles > max_tiles || nk < 16) return XDET_OK;
+    const int S = std::min(std::min(max_s, pow2_floor(256 / tiles)), pow2_floor(nk / 8));
+    if (S < 2) return XDET_OK;
+    return L->enable_ksplit(S, 448 / S);
+  }
   bool fuse_sepconv = true;      // option "sepconv" = "fused" | "split"
   bool subsample_projections = true;
   bool patch_conv3x3 = true;     // option "conv3x3" = "patch" | "gemm"
@@ -530,9 +665,11 @@ struct Plan {
   int add_conv(const std::string& name, int stage, const Buf& in_, ConvLayer* L, const Buf* res, int relu_in, Buf* out) {
     Buf in = in_;
     const int emit = L->precision == PREC_F32 ? 0 : emit_planes_next;
-    const float *bsc = emit ? emit_bn_scale : nullptr, *bsh = emit ? emit_bn_shift : nullptr;
+    const bool folded_bn = emit && !emit_bn_scale.empty();
+    if (folded_bn) XDET_TRY(L->set_planes_bn(emit_bn_scale, emit_bn_shift));
     emit_planes_next = 0;
-    emit_bn_scale = emit_bn_shift = nullptr;
+    emit_bn_scale.clear();
+    emit_bn_shift.clear();
     // split path: big stride-1 contractions take their A operand as f16 planes through the LDS DMA;
     // if the producer did not emit planes, one cheap element-wise pass makes them (ReLU folded in)
     // (a strided conv takes planes too if its producer wrote them: the DMA gathers any pixel per row; it is not worth
@@ -559,19 +696,13 @@ struct Plan {
     L->out_shape(in.H, in.W, &Ho, &Wo, &a, &b);
     XDET_TRY(new_buf(Ho, Wo, L->cout, out));
     XDET_REQUIRE(in.ld == L->ld_in() && out->ld == L->ld_out(), "plan: conv channel strides do not match");
+    if (in.hi) XDET_TRY(maybe_ksplit(L, in.H, in.W, Ho, Wo)); else ksplit_next = false;
     if (emit) {
       XDET_TRY(new_planes(out));
       out->planes_relu = emit == 2;
       out->no_f32 = emit == 3;
       pscales[out->pidx].name = name + " (planes of the output)";
-      const bool folded_bn = bsc != nullptr;
-      pscales[out->pidx].apply.push_back([L, folded_bn](int e) {
-        if (folded_bn && e != 0) {
-          set_last_error("calibrate: a planes copy with a folded BN cannot carry a pre-scale");
-          return (int)XDET_ERR_UNSUPPORTED;
-        }
-        return folded_bn ? (int)XDET_OK : L->set_out_exp(e);
-      });
+      pscales[out->pidx].apply.push_back([L](int e) { return L->set_out_exp(e); });
     }
     if (in.hi && in.pidx >= 0) pscales[in.pidx].apply.push_back([L](int e) { return L->set_in_exp(e); });
     const Buf i = in, o = *out;
@@ -579,11 +710,11 @@ struct Plan {
     const unsigned short* z = zeros;
     if (res) XDET_REQUIRE(res->H == Ho && res->W == Wo && res->ld == o.ld, "plan: residual shape mismatch");
     ops.push_back({name, stage, L->flops(in.H, in.W), [=](int N, hipStream_t s) {
-                     // the planes copy: relu(out * bn_scale + bn_shift) for a folded BN, else (relu?)(out) * 2^-out_exp
-                     const float* ps = bsc ? bsc : (L->out_exp ? L->d_pl_scale : nullptr);
-                     const float* ph = bsc ? bsh : (L->out_exp ? L->d_pl_shift : nullptr);
+                     // the planes copy: relu(out * bn_scale + bn_shift) * 2^-out_exp for a folded BN, else (relu?)(out) * 2^-out_exp
+                     const bool aff = folded_bn || L->out_exp != 0;
                      return L->forward(i.p, N, i.H, i.W, i.ld, o.no_f32 ? nullptr : o.p, o.ld, rp, relu_in, s, i.hi, i.lo,
-                                       z, o.hi, o.lo, (o.planes_relu || bsc) ? 1 : 0, ps, ph);
+                                       z, o.hi, o.lo, (o.planes_relu || folded_bn) ? 1 : 0, aff ? L->d_pl_scale : nullptr,
+                                       aff ? L->d_pl_shift : nullptr);
                    }});
     return XDET_OK;
   }
@@ -814,6 +945,7 @@ struct LightHeadNet : Plan {
   bool large_sep_spectral = false;      // decided at build
   bool rpn_side_stream = true;          // option "rpn_stream" = "side" | "main"
   bool check_range = false;             // option "check_range" = "off" | "on": validate every activation against the f16 range
+  bool latency_ksplit = true;           // option "ksplit" = "on" | "off": fixed split-K for the RPN conv and the narrow head GEMM
   std::vector<std::function<int(int, hipStream_t)>> extra_range_checks;   // tensors that are not plain [N][pixels][ld] (DFT bins)
   bool stem_direct = false;             // block1_conv1 as the dedicated NCHW -> planes kernel
   const float* cur_images = nullptr;
@@ -926,6 +1058,8 @@ struct LightHeadNet : Plan {
     XDET_TRY(L0->init(3, 3, 728, 512, 1, 1, 1, 0, 0, k0->v.data(), nullptr, b0->v.data(), 1));
     Buf hid;
     emit_planes_next = 3;   // only the fused 1x1 heads read it
+    // a single image is 8 x 4 tiles against 207 K steps: fixed split-K (a layer constant: same bits at every batch size)
+    ksplit_next = latency_ksplit;
     XDET_TRY(add_conv("rpn_head/conv2d", ST_RPN, mid_x, L0, nullptr, /*relu_in=*/1, &hid));
     // cls (2A) and box (4A) 1x1 heads share their input: one GEMM over the concatenated filters
     const int co = 6 * A;
@@ -1152,6 +1286,7 @@ struct LightHeadNet : Plan {
     for (int j = 0; j < 4; ++j) bc[nc + j] = b2->v[j];
     ConvLayer* L1 = keep(new ConvLayer());
     XDET_TRY(L1->init(1, 1, 2048, co, 1, 1, 0, 0, 0, kc.data(), nullptr, bc.data(), 0));
+    ksplit_next = latency_ksplit;     // 300 rows x 25 outputs: 3 tiles against 64 K steps
     XDET_TRY(add_conv("final_head/fc_cls+fc_loc", ST_HEAD, fc, L1, nullptr, 0, &cls_reg));
     return XDET_OK;
   }
@@ -1162,6 +1297,8 @@ struct LightHeadNet : Plan {
     XDET_REQUIRE(cfg.num_anchors == 22, "anchor table is the reference's 22-anchor set (1 extra + 7 scales x 3 ratios)");
     max_batch = cfg.max_batch;
     net_precision = g_default_precision;
+    ksplit_design_batch = 1;            // the reference evaluates single images (light_head_rfcn_eval.py:212); only layers a
+    ksplit_all = false;                 // builder marks (ksplit_next) are split
     XDET_TRY(build_body());
     XDET_TRY(build_rpn());
     XDET_TRY(large_sep_spectral ? build_large_sep_spectral() : build_large_sep());
@@ -1257,11 +1394,6 @@ struct LightHeadNet : Plan {
     graphs.clear();
     graph_order.clear();
   }
-  // Choose the activation pre-scale exponents from a calibration batch (Plan::pscales).  Pass by pass: run the forward,
-  // take the largest magnitude of every split-precision operand (as stored, i.e. already scaled), and raise the exponent
-  // of the tensors above kRangeTarget.  A tensor that overflowed (inf / NaN in its hi plane) invalidates everything
-  // computed from it, so a pass stops adjusting at the first such tensor (+8 binades) and the next pass re-measures.
-  // Nets whose activations stay below the target keep every exponent at 0: nothing changes, bit for bit.
   int calibrate(const float* images, int N, hipStream_t s, int* n_scaled) {
     XDET_TRY(check(N));
     XDET_REQUIRE(images != nullptr, "calibrate: images is NULL");
@@ -1270,74 +1402,12 @@ struct LightHeadNet : Plan {
     drop_graphs();                                   // graphs bake kernel arguments (the split passes' multipliers)
     const size_t slots = (size_t)N * (cfg.num_classes - 1) * cfg.nms_topk;
     float *ds = nullptr, *db = nullptr;
-    unsigned* d_max = nullptr;
     XDET_HIP(hipMalloc(reinterpret_cast<void**>(&ds), slots * 4));
     XDET_HIP(hipMalloc(reinterpret_cast<void**>(&db), slots * 16));
-    XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_max), pscales.size() * sizeof(unsigned)));
-    std::vector<unsigned> h_max(pscales.size());
-    int rc = XDET_OK;
-    for (const PlaneScale& p : pscales)
-      if (p.clear && rc == XDET_OK) rc = p.clear(s);
-    const int max_passes = (int)pscales.size() + 4;
-    const bool verbose = getenv("XDET_CALIBRATE_VERBOSE") != nullptr;
-    int pass = 0;
-    for (; pass < max_passes && rc == XDET_OK; ++pass) {
-      if ((rc = hipMemsetAsync(d_max, 0, pscales.size() * sizeof(unsigned), s) == hipSuccess ? XDET_OK : XDET_ERR_HIP) != XDET_OK) break;
-      if ((rc = forward_eager(images, N, nullptr, nullptr, ds, db, s)) != XDET_OK) break;
-      for (size_t i = 0; i < pscales.size() && rc == XDET_OK; ++i) {
-        const PlaneScale& p = pscales[i];
-        rc = p.hi ? launch_absmax_planes(p.hi, p.halves(N), d_max + i, s)
-                  : launch_absmax_f32(p.src, (int64_t)N * (int64_t)p.src_per_image, p.src_relu, d_max + i, s);
-      }
-      if (rc != XDET_OK) break;
-      if (hipMemcpyAsync(h_max.data(), d_max, h_max.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess ||
-          hipStreamSynchronize(s) != hipSuccess) { rc = XDET_ERR_HIP; break; }
-      bool changed = false;
-      for (size_t i = 0; i < pscales.size() && rc == XDET_OK; ++i) {
-        const PlaneScale& p = pscales[i];
-        float m;                                     // magnitude of the operand as the MFMAs would see it now
-        bool broken;
-        if (p.hi) {
-          broken = h_max[i] >= 0x7c00u;
-          m = broken ? 0.f : f16_to_f32((unsigned short)h_max[i]);
-        } else {
-          broken = h_max[i] >= 0x7f800000u;
-          float x;
-          memcpy(&x, &h_max[i], 4);
-          m = broken ? 0.f : ldexpf(x * p.bound, -p.exp);
-          if (!broken && !(m <= 3.0e38f)) broken = true;
-        }
-        if (verbose && (broken || m > kRangeTarget))
-          fprintf(stderr, "xdet calibrate: pass %d  %-70s exp %d  max %s%g\n", pass, p.name.c_str(), p.exp,
-                  broken ? "inf/NaN " : "", (double)m);
-        if (broken) {
-          rc = set_plane_exp((int)i, p.exp + 8);
-          changed = true;
-          break;                                     // downstream tensors were computed from garbage: re-measure
-        }
-        if (m > kRangeTarget) {
-          int e = 0;
-          (void)frexpf(m / kRangeTarget, &e);        // m / target in [2^(e-1), 2^e)
-          rc = set_plane_exp((int)i, p.exp + e);
-          changed = true;
-        }
-      }
-      if (!changed) break;
-    }
+    const int rc = calibrate_planes(N, s, n_scaled, [&](hipStream_t st) { return forward_eager(images, N, nullptr, nullptr, ds, db, st); });
     (void)hipFree(ds);
     (void)hipFree(db);
-    (void)hipFree(d_max);
-    XDET_TRY(rc);
-    if (pass >= max_passes) {
-      set_last_error("calibrate: the activation ranges did not settle (non-finite inputs or weights?)");
-      return XDET_ERR_STATE;
-    }
-    if (n_scaled) {
-      int n = 0;
-      for (const PlaneScale& p : pscales) n += p.exp != 0;
-      *n_scaled = n;
-    }
-    return XDET_OK;
+    return rc;
   }
   int forward_eager(const float* images, int N, const int* shapes, const float* bbox, float* ds, float* db,
                     hipStream_t s) {
@@ -1390,6 +1460,7 @@ struct ResNetTrunk : Plan {
   bool built = false;
   Buf in4, outb;
   double flops = 0;
+  bool ksplit_enabled = true;                      // XDET_RESNET_KSPLIT=0: the round-3 launch plan (A/B measurements)
   typedef std::array<uintptr_t, 3> Key;            // (N, images, out): every pointer a captured graph bakes in
   std::map<Key, hipGraphExec_t> graphs;
   std::vector<Key> graph_order;
@@ -1408,7 +1479,9 @@ struct ResNetTrunk : Plan {
 // convs on the LDS-DMA path)
 __global__ void bn_relu_kernel(const float* __restrict__ in, const float* __restrict__ scale,
                                const float* __restrict__ shift, float* __restrict__ out,
-                               unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, int64_t npix, int ld) {
+                               unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, int64_t npix, int ld,
+                               float mul) {
+  // mul = 2^-e, the planes' activation pre-scale (1 by default): hi + lo = relu(bn(x)) * mul; the f32 copy is unscaled
   typedef _Float16 h4 __attribute__((ext_vector_type(4)));
   const int c4n = ld >> 2;
   const int64_t total = npix * c4n;
@@ -1416,11 +1489,13 @@ __global__ void bn_relu_kernel(const float* __restrict__ in, const float* __rest
     const int c = (int)(i % c4n) * 4;
     float4 v = reinterpret_cast<const float4*>(in)[i];
     const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
-    v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-    v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+    // (a ReLU that keeps NaN, as the conv epilogue's: an overflowed split operand upstream must reach the caller, not turn into 0)
+    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+    v.x = !(v.x <= 0.f) ? v.x : 0.f; v.y = !(v.y <= 0.f) ? v.y : 0.f; v.z = !(v.z <= 0.f) ? v.z : 0.f; v.w = !(v.w <= 0.f) ? v.w : 0.f;
     reinterpret_cast<float4*>(out)[i] = v;
     if (hi) {
       const int64_t pix = i / c4n;
+      v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
       const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y, h2 = (_Float16)v.z, h3 = (_Float16)v.w;
       h4 hv = {h0, h1, h2, h3};
       h4 lv = {(_Float16)(v.x - (float)h0), (_Float16)(v.y - (float)h1), (_Float16)(v.z - (float)h2),
@@ -1443,13 +1518,16 @@ int ResNetTrunk::add_bn_relu(const std::string& bn, const Buf& in, Buf* out) {
   XDET_HIP(hipMemcpy(dsc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
   XDET_HIP(hipMemcpy(dsh, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
   XDET_TRY(new_buf(in.H, in.W, in.C, out));
-  if (g_default_precision != PREC_F32 && in.ld % 32 == 0) XDET_TRY(new_planes(out));
+  if (g_default_precision != PREC_F32 && in.ld % 32 == 0) {
+    XDET_TRY(new_planes(out));
+    pscales[out->pidx].name = bn + " (pre-activation planes)";
+  }
   const Buf i = in, o = *out;
   ops.push_back({bn, 0, 0.0, [=](int N, hipStream_t s) {
                    const int64_t npix = (int64_t)N * i.H * i.W;
                    const int blocks = (int)std::min<int64_t>(cdiv(npix * (i.ld / 4), 256), 256 * 32);
                    hipLaunchKernelGGL(bn_relu_kernel, dim3(blocks), dim3(256), 0, s, i.p, dsc, dsh, o.p, o.hi, o.lo, npix,
-                                      i.ld);
+                                      i.ld, pmul(o.pidx));
                    XDET_LAUNCH_CHECK();
                    return (int)XDET_OK;
                  }});
@@ -1458,6 +1536,9 @@ int ResNetTrunk::add_bn_relu(const std::string& bn, const Buf& in, Buf* out) {
 
 int ResNetTrunk::build() {
   XDET_REQUIRE(!built, "net already built");
+  // stages 3-4 at BASELINE config 2's batch 8 are 57 / 15 M tiles against 72- / 144-step K loops: split-K (option "ksplit")
+  if (g_default_precision != PREC_F32 && ksplit_enabled) { ksplit_design_batch = 8; ksplit_all = true; }
+  net_precision = g_default_precision;
   int ci = 0, bi = 0;
   auto cname = [&]() { std::string n = ci == 0 ? "conv2d" : "conv2d_" + std::to_string(ci); ++ci; return n; };
   auto bname = [&]() { std::string n = bi == 0 ? "batch_normalization" : "batch_normalization_" + std::to_string(bi); ++bi; return n; };
@@ -1514,8 +1595,8 @@ int ResNetTrunk::build() {
         XDET_HIP(hipMemcpy(nsc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
         XDET_HIP(hipMemcpy(nsh, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
         emit_planes_next = 1;
-        emit_bn_scale = nsc;
-        emit_bn_shift = nsh;
+        emit_bn_scale = sc;                         // (host copies: the conv keeps its own device arrays, which carry the
+        emit_bn_shift = sh;                         //  planes' pre-scale; nsc / nsh below stay as they are for the projection)
       }
       XDET_TRY(conv_bn(c3, "", 0.f, 0, y2, 1, 4 * f, 1, 1, 0, &shortcut, 0, &y3));
       if (nsc) {
@@ -1632,6 +1713,18 @@ int xdet_conv_forward_planes(void* layer, const uint16_t* in_hi, const uint16_t*
   XDET_REQUIRE(in_hi && (in_lo || L->precision == PREC_F16), "conv(planes): NULL planes");
   DeviceGuard guard(L->device);
   return L->forward(nullptr, N, H, W, ld_in, out, ld_out, residual, 0, S(stream), in_hi, in_lo, L->d_zeros);
+}
+int xdet_conv_set_ksplit(void* layer, int ksplit, int mode, int max_parallel_tiles) {
+  LayerBase* b = static_cast<LayerBase*>(layer);
+  XDET_REQUIRE(b && b->kind == 1, "not a conv layer");
+  ConvLayer* L = static_cast<ConvLayer*>(b);
+  XDET_REQUIRE(mode >= 0 && mode <= 2 && max_parallel_tiles >= 0, "conv_set_ksplit: mode 0|1|2, max_parallel_tiles >= 0");
+  DeviceGuard guard(L->device);
+  if (ksplit == 0) { L->ksplit = 0; return XDET_OK; }
+  XDET_REQUIRE((L->kh == 1 && L->kw == 1) || (L->kh == 3 && L->kw == 3), "conv_set_ksplit: the split-K kernel runs 1x1 and 3x3 filters");
+  XDET_TRY(L->enable_ksplit(ksplit, max_parallel_tiles));
+  L->ks_mode = mode;
+  return XDET_OK;
 }
 int xdet_conv_out_shape(void* layer, int H, int W, int* Ho, int* Wo) {
   LayerBase* b = static_cast<LayerBase*>(layer);
@@ -1755,6 +1848,12 @@ int xdet_bboxes_eval(const float* cls, int ld_cls, const float* boxes, int N, in
                             nms_thr, nms_topk, det_scores, det_boxes, S(stream));
 }
 
+// A handle is a void*: both plan types start with their Plan base, whose kind tag says what the pointer really is
+// (handing a resnet handle to a light-head entry point used to be undefined behaviour).
+static Plan* plan_of(void* net) { return static_cast<Plan*>(net); }
+#define XDET_NET_KIND(net, kind, what)                                                                     \
+  XDET_REQUIRE((net) != nullptr && plan_of(net)->plan_kind == (kind), what ": not a handle of this net type")
+
 // ---- light-head net ----
 static int set_weight(Plan* p, const char* name, const float* data, int ndim, const int64_t* dims) {
   XDET_REQUIRE(p && name && data && ndim >= 1 && ndim <= 4 && dims, "set_weight: bad arguments");
@@ -1769,6 +1868,7 @@ static int set_weight(Plan* p, const char* name, const float* data, int ndim, co
 int xdet_net_create(void** net, const xdet_lighthead_config* cfg) {
   XDET_REQUIRE(net && cfg, "net/cfg is NULL");
   LightHeadNet* n = new LightHeadNet();
+  n->plan_kind = 0;
   n->cfg = *cfg;
   XDET_HIP(hipGetDevice(&n->device));
   *net = n;
@@ -1795,6 +1895,11 @@ int xdet_net_set_option(void* net, const char* key, const char* value) {
   if (k == "sepconv") {
     XDET_REQUIRE(v == "fused" || v == "split", "sepconv must be fused | split");
     n->fuse_sepconv = v == "fused";
+    return XDET_OK;
+  }
+  if (k == "ksplit") {
+    XDET_REQUIRE(v == "on" || v == "off", "ksplit must be on | off");
+    n->latency_ksplit = v == "on";
     return XDET_OK;
   }
   if (k == "check_range") {
@@ -1907,6 +2012,7 @@ int xdet_net_bboxes_eval(void* net, int N, const int* image_shapes, const float*
 
 int xdet_net_forward(void* net, const float* images, int N, const int* image_shapes, const float* bbox_img,
                      float* det_scores, float* det_boxes, int use_graph, void* stream) {
+  XDET_NET_KIND(net, 0, "net_forward");
   LightHeadNet* n = static_cast<LightHeadNet*>(net);
   XDET_REQUIRE(n && images && det_scores && det_boxes, "forward: NULL argument");
   XDET_TRY(n->check(N));
@@ -1949,21 +2055,23 @@ int xdet_net_forward(void* net, const float* images, int N, const int* image_sha
 }
 
 int xdet_net_calibrate(void* net, const float* images, int N, int* n_scaled, void* stream) {
+  XDET_NET_KIND(net, 0, "net_calibrate");
   LightHeadNet* n = static_cast<LightHeadNet*>(net);
-  XDET_REQUIRE(n, "net is NULL");
   DeviceGuard guard(n->device);
   return n->calibrate(images, N, S(stream), n_scaled);
 }
+// (either net type: the list lives in the common Plan base)
 int xdet_net_plane_scales(void* net, int max_n, int* n_out, int* exps) {
-  LightHeadNet* n = static_cast<LightHeadNet*>(net);
-  XDET_REQUIRE(n && n->built && n_out, "plane_scales: bad arguments");
+  XDET_REQUIRE(net && n_out && (plan_of(net)->plan_kind == 0 || plan_of(net)->plan_kind == 1), "plane_scales: bad arguments");
+  Plan* n = plan_of(net);
   *n_out = (int)n->pscales.size();
   for (int i = 0; exps && i < max_n && i < *n_out; ++i) exps[i] = n->pscales[i].exp;
   return XDET_OK;
 }
 int xdet_net_plane_scale_name(void* net, int idx, char* buf, int buflen) {
-  LightHeadNet* n = static_cast<LightHeadNet*>(net);
-  XDET_REQUIRE(n && n->built && buf && buflen > 0 && idx >= 0 && idx < (int)n->pscales.size(), "plane_scale_name: bad arguments");
+  XDET_REQUIRE(net && (plan_of(net)->plan_kind == 0 || plan_of(net)->plan_kind == 1), "plane_scale_name: bad arguments");
+  Plan* n = plan_of(net);
+  XDET_REQUIRE(buf && buflen > 0 && idx >= 0 && idx < (int)n->pscales.size(), "plane_scale_name: bad arguments");
   snprintf(buf, buflen, "%s", n->pscales[idx].name.c_str());
   return XDET_OK;
 }
@@ -2023,8 +2131,10 @@ int xdet_profile_op_name(void* net, int kind, int op, char* buf, int buflen) {
 int xdet_resnet_create(void** net, int image_size, int max_batch) {
   XDET_REQUIRE(net && image_size >= 64 && max_batch > 0, "resnet_create: bad arguments");
   ResNetTrunk* r = new ResNetTrunk();
+  r->plan_kind = 1;
   r->image_size = image_size;
   r->max_batch = max_batch;
+  if (const char* e = getenv("XDET_RESNET_KSPLIT")) r->ksplit_enabled = strcmp(e, "0") != 0;
   XDET_HIP(hipGetDevice(&r->device));
   *net = r;
   return XDET_OK;
@@ -2038,6 +2148,7 @@ int xdet_resnet_build(void* net) {
   return static_cast<ResNetTrunk*>(net)->build();
 }
 int xdet_resnet_forward(void* net, const float* images, int N, float* out_nhwc, void* stream) {
+  XDET_NET_KIND(net, 1, "resnet_forward");
   ResNetTrunk* r = static_cast<ResNetTrunk*>(net);
   XDET_REQUIRE(r && r->built && images, "resnet_forward: bad arguments");
   XDET_REQUIRE(N > 0 && N <= r->max_batch, "batch must be in 1..max_batch");
@@ -2085,6 +2196,21 @@ int xdet_resnet_forward_graph(void* net, const float* images, int N, float* out_
   }
   XDET_HIP(hipGraphLaunch(it->second, s));
   return XDET_OK;
+}
+// activation pre-scale of the trunk's split-precision operands (as xdet_net_calibrate): pre-activation planes
+// (bn_relu pass / the previous block's epilogue, whose folded BN carries 2^-e), the inner convs' planes, the strided
+// projections' subsample pass
+int xdet_resnet_calibrate(void* net, const float* images, int N, int* n_scaled, void* stream) {
+  XDET_NET_KIND(net, 1, "resnet_calibrate");
+  ResNetTrunk* r = static_cast<ResNetTrunk*>(net);
+  XDET_REQUIRE(r->built && images && N > 0 && N <= r->max_batch, "resnet_calibrate: bad arguments");
+  DeviceGuard guard(r->device);
+  if (n_scaled) *n_scaled = 0;
+  if (r->net_precision == PREC_F32) return XDET_OK;
+  for (auto& g : r->graphs) (void)hipGraphExecDestroy(g.second);      // graphs bake kernel arguments
+  r->graphs.clear();
+  r->graph_order.clear();
+  return r->calibrate_planes(N, S(stream), n_scaled, [&](hipStream_t st) { return xdet_resnet_forward(net, images, N, nullptr, st); });
 }
 int xdet_resnet_out_shape(void* net, int* Ho, int* Wo, int* C) {
   ResNetTrunk* r = static_cast<ResNetTrunk*>(net);

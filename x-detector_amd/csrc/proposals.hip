@@ -209,11 +209,11 @@ constexpr int SORT_MAX = 8192;
 __global__ __launch_bounds__(1024) void prop_sort_kernel(const u64* __restrict__ cand,
                                                          const float* __restrict__ cboxes, int n_anchor, int pre_n,
                                                          const int* __restrict__ counts, float* __restrict__ sboxes,
-                                                         float* __restrict__ sscores) {
+                                                         float* __restrict__ sscores, int sort_max) {
   __shared__ u64 keys[SORT_MAX];
   const int n = blockIdx.x, tid = threadIdx.x;
   const int L = counts[n * 4 + 3];
-  if (L > SORT_MAX || L <= 0) return;
+  if (L > sort_max || L <= 0) return;
   int P = 64;
   while (P < L) P <<= 1;
   const u64* k = cand + (int64_t)n * n_anchor;
@@ -273,11 +273,11 @@ __global__ __launch_bounds__(1024) void prop_sort_kernel(const u64* __restrict__
 }
 
 __global__ __launch_bounds__(256) void prop_rank_kernel(const u64* __restrict__ cand, int n_anchor,
-                                                        const int* __restrict__ counts, int* __restrict__ ranks) {
+                                                        const int* __restrict__ counts, int* __restrict__ ranks, int sort_max) {
   __shared__ u64 tile[RANK_TILE];
   const int n = blockIdx.z;
   const int c = counts[n * 4 + 3];
-  if (c <= SORT_MAX) return;                       // handled by prop_sort_kernel
+  if (c <= sort_max) return;                       // handled by prop_sort_kernel
   const int i0 = blockIdx.x * (256 * RANK_IPT);
   const int jps = ((c + RANK_SPLITS - 1) / RANK_SPLITS + RANK_TILE - 1) / RANK_TILE * RANK_TILE;
   const int j0 = blockIdx.y * jps;
@@ -313,10 +313,10 @@ __global__ __launch_bounds__(256) void prop_rank_kernel(const u64* __restrict__ 
 __global__ void prop_scatter_kernel(const u64* __restrict__ cand, const int* __restrict__ ranks,
                                     const float* __restrict__ cboxes, int n_anchor, int pre_n,
                                     const int* __restrict__ counts, float* __restrict__ sboxes,
-                                    float* __restrict__ sscores) {
+                                    float* __restrict__ sscores, int sort_max) {
   const int n = blockIdx.y;
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (counts[n * 4 + 3] <= SORT_MAX || slot >= counts[n * 4 + 3]) return;
+  if (counts[n * 4 + 3] <= sort_max || slot >= counts[n * 4 + 3]) return;
   const int64_t g = (int64_t)n * n_anchor + slot;
   const int r = ranks[g];
   if (r >= pre_n) return;
@@ -483,14 +483,22 @@ int launch_get_proposals(const float* objectness, const float* boxes, int N, int
   hipLaunchKernelGGL(prop_compact_kernel, dim3(gb, N), dim3(256), 0, s, ws.keys, n_anchor, ws.tbin, ws.cand, ws.ranks,
                      ws.counts);
   XDET_LAUNCH_CHECK();
-  hipLaunchKernelGGL(prop_sort_kernel, dim3(N), dim3(1024), 0, s, ws.cand, ws.cboxes, n_anchor, pre_n, ws.counts,
-                     ws.sboxes, ws.sscores);
-  XDET_LAUNCH_CHECK();
+  // The order of the (distinct) keys, two ways with the same result: a bitonic sort in LDS by ONE workgroup per image
+  // (the cheapest in CU time: what a batch wants, its images sort side by side) or rank counting spread over the chip
+  // (160 workgroups per image: what one or two images want -- the sort is ~70 us on one of 256 CUs, on the critical path
+  // of a single-image forward).  Lists beyond the sort's LDS capacity always take the counting path.
+  static const int small_n = getenv("XDET_PROP_RANK_N") ? atoi(getenv("XDET_PROP_RANK_N")) : 0;     // A/B knob: measured at one image, 1.302 ms against 1.296 with the sort -- the sort is not on the critical path -- so off
+  const int sort_max = N <= small_n ? 0 : SORT_MAX;
+  if (sort_max > 0) {
+    hipLaunchKernelGGL(prop_sort_kernel, dim3(N), dim3(1024), 0, s, ws.cand, ws.cboxes, n_anchor, pre_n, ws.counts,
+                       ws.sboxes, ws.sscores, sort_max);
+    XDET_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(prop_rank_kernel, dim3((unsigned)cdiv(n_anchor, 256 * RANK_IPT), RANK_SPLITS, N), dim3(256), 0, s,
-                     ws.cand, n_anchor, ws.counts, ws.ranks);
+                     ws.cand, n_anchor, ws.counts, ws.ranks, sort_max);
   XDET_LAUNCH_CHECK();
   hipLaunchKernelGGL(prop_scatter_kernel, dim3(gb, N), dim3(256), 0, s, ws.cand, ws.ranks, ws.cboxes, n_anchor, pre_n,
-                     ws.counts, ws.sboxes, ws.sscores);
+                     ws.counts, ws.sboxes, ws.sscores, sort_max);
   XDET_LAUNCH_CHECK();
   {
     XDET_REQUIRE((size_t)post_n * 16 <= 96 * 1024, "get_proposals: rpn_post_nms_top_n too large (max 6144)");

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 4) void psroialign_fwd_kernel(const float* __r
   // and wider gathers did -- VEC = 2 and psroi_grid_bin above.)  Every
   // expression keeps the reference's typing and order: (1.-fx)*(1.-fy)*f00 + (1.-fx)*fy*f10 + fx*(1.-fy)*f01 in
   // double, fx*fy*f11 in float, summed left to right.
-  constexpr int JMAX = 8;
+  constexpr int JMAX = (VEC == 2 && !USE_MAX) ? 6 : 8;   // ('mean' with two channels: 8 hoisted columns spill 2 registers at four waves)
   const int sy = layout == 0 ? W : W * ldc, sx = layout == 0 ? 1 : ldc, sc = layout == 0 ? H * W : 1;
   const float* __restrict__ fimg = feat + (size_t)n * H * W * ldc;       // NCHW: ldc == C
   typedef float vecf __attribute__((ext_vector_type(VEC)));
@@ -260,7 +260,10 @@ __global__ __launch_bounds__(256, 4) void psroialign_fwd_kernel(const float* __r
   // two separate element loops (not one loop with two bodies): the register allocation is then the larger of the two
   // paths, not their union
   // wave-uniform: bins whose pixel grid (n_h + 1) x (n_w + 1) fits the 16 LDS entries of a lane, corners de-duplicated
-  if (VEC == 2 && USE_MAX && dedup && n_h * n_w > 1 && (n_h + 1) * (n_w + 1) <= 16 && n_h <= 5 && n_w <= 5) {   // (max only: the mean form has no registers to spare)
+  // ('mean' takes the two-channel direct path only: with the grid on top its running sums and counts need 16 registers
+  //  more than the four-waves-per-SIMD budget of 128 -- compiled: 16 spilled -- and at three waves the grid gives its gain
+  //  back, as it did for 'max' at 134 registers in round 3)
+  if (VEC == 2 && USE_MAX && dedup && n_h * n_w > 1 && (n_h + 1) * (n_w + 1) <= 16 && n_h <= 5 && n_w <= 5) {
     float2* grid = s_grid + (threadIdx.x >> 6) * (16 * 64) + lane;
     bool declined = false;
     for (int ev = lane; ev * VEC < C; ev += 64) {
@@ -338,9 +341,10 @@ int launch_psroialign(const float* feat, const float* rois, float* pooled, int32
 #define XDET_PSROI_LAUNCH(V, M)                                                                                        \
   hipLaunchKernelGGL((psroialign_fwd_kernel<V, M>), dim3((unsigned)blocks), dim3(256), 0, s, feat, rois, pooled, index, N, C, \
                      H, W, R, gw, gh, layout, cs, out_ld, rois_are_corners, (V) == 2 ? dedup : 0)
-  if (two && use_max) XDET_PSROI_LAUNCH(2, true);       // the net's form ('max', NHWC); 'mean' keeps one channel per lane
-  else if (use_max) XDET_PSROI_LAUNCH(1, true);
-  else XDET_PSROI_LAUNCH(1, false);
+  if (two && use_max) XDET_PSROI_LAUNCH(2, true);       // the net's form ('max', NHWC)
+  else if (two) XDET_PSROI_LAUNCH(2, false);            // 'mean', NHWC: two channels per lane (8-byte corner loads), direct path
+  else if (use_max) XDET_PSROI_LAUNCH(1, true);         // NCHW (the op's public contract): neighbouring channels are H*W
+  else XDET_PSROI_LAUNCH(1, false);                     // floats apart -- one channel per lane, direct gathers
 #undef XDET_PSROI_LAUNCH
   XDET_LAUNCH_CHECK();
   return XDET_OK;

@@ -76,6 +76,7 @@ SIGNATURES = {
     'xdet_conv_create': (c_int, [ctypes.POINTER(c_void_p)] + [c_int] * 9 + [PF, PF, PF, c_int]),
     'xdet_conv_forward': (c_int, [c_void_p, PF, c_int, c_int, c_int, c_int, PF, c_int, PF, c_int, c_void_p]),
     'xdet_conv_out_shape': (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    'xdet_conv_set_ksplit': (c_int, [c_void_p, c_int, c_int, c_int]),
     'xdet_split_f32': (c_int, [PF, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'xdet_conv_forward_planes': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, PF, c_int, PF,
                                          c_void_p]),
@@ -127,6 +128,7 @@ SIGNATURES = {
     'xdet_resnet_build': (c_int, [c_void_p]),
     'xdet_resnet_forward': (c_int, [c_void_p, PF, c_int, PF, c_void_p]),
     'xdet_resnet_forward_graph': (c_int, [c_void_p, PF, c_int, PF, c_void_p]),
+    'xdet_resnet_calibrate': (c_int, [c_void_p, PF, c_int, ctypes.POINTER(c_int), c_void_p]),
     'xdet_resnet_out_shape': (c_int, [c_void_p] + [ctypes.POINTER(c_int)] * 3),
     'xdet_resnet_flops_per_image': (c_int, [c_void_p, ctypes.POINTER(c_double)]),
     'xdet_resnet_destroy': (c_int, [c_void_p]),

@@ -13,6 +13,7 @@ SOURCES = [
     ('conv_mfma.hip', []),
     ('conv_mfma_split.hip', []),
     ('conv_mfma_dma.hip', []),
+    ('conv_mfma_ksplit.hip', []),
     ('elementwise.hip', []),
     ('spectral.hip', []),
     ('sepconv_fused.hip', []),
@@ -48,6 +49,9 @@ def build(force=False, verbose=False):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
+    # (an object compiled by hand -- a resource-usage or -S run with -o <the object> -- is newer than the library too)
+    if not dirty and max(os.path.getmtime(o) for o in objs) > os.path.getmtime(LIB):
+        dirty = True
     if dirty:
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']
         if verbose:

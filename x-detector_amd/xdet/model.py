@@ -21,7 +21,7 @@ class LightHeadDetector(object):
     def __init__(self, weights, image_size=480, max_batch=1, num_classes=21, rpn_pre_nms_top_n=5000,
                  rpn_post_nms_top_n=1000, rpn_nms_thres=0.7, rpn_min_size=None, select_threshold=0.01,
                  nms_threshold=0.3, nms_topk=200, device=None, large_sep='auto', sepconv='fused', rpn_stream='side',
-                 conv3x3='patch', pool='split', check_range=False):
+                 conv3x3='patch', pool='split', check_range=False, ksplit=True):
         """check_range=True: every activation tensor is validated against the f16 range of the split-precision convs
         after each forward (|x| <= 65504, no NaN); a violation raises in detections() / forward().  For validating a
         new checkpoint once: the pass re-reads every activation (~+30 % time)."""
@@ -45,6 +45,7 @@ class LightHeadDetector(object):
         check(lib().xdet_net_set_option(self.handle, b'conv3x3', conv3x3.encode()))
         check(lib().xdet_net_set_option(self.handle, b'pool', pool.encode()))
         check(lib().xdet_net_set_option(self.handle, b'check_range', b'on' if check_range else b'off'))
+        check(lib().xdet_net_set_option(self.handle, b'ksplit', b'on' if ksplit else b'off'))
         check(lib().xdet_net_build(self.handle))
         self.max_batch = max_batch
         self.image_size = image_size

@@ -100,6 +100,11 @@ class Conv2D(object):
                                      _host(sh) if sh is not None else None, 1 if relu else 0))
         self.handle = h
 
+    def set_ksplit(self, ksplit, mode=0, max_parallel_tiles=448):
+        """fixed split of the reduction (xdet_conv_set_ksplit): the planes path then runs on the split-K kernel;
+        mode 0 = by grid size, 1 = ranges in parallel, 2 = one workgroup per tile -- all bit-identical."""
+        check(lib().xdet_conv_set_ksplit(self.handle, int(ksplit), int(mode), int(max_parallel_tiles)))
+
     def __call__(self, x, residual=None, relu_in=False, stream=None, planes=False, staged_tile=False):
         """planes=True (split-precision modes only): split x into f16 hi/lo planes first and run the
         LDS-DMA kernel -- the path every big contraction takes inside a net.  staged_tile=True (with planes; 3x3 VALID

@@ -43,6 +43,26 @@ class ResNet50Trunk(object):
         self.stream.synchronize()
         return to_host(self._out.ptr, (n,) + self.out_shape, np.float32)
 
+    def calibrate(self, images_nchw):
+        """choose the activation pre-scale exponents of the split-precision operands from a calibration batch
+        (xdet_resnet_calibrate); returns {tensor name: exponent} of the tensors that got one."""
+        n = self.set_images(images_nchw)
+        k = ctypes.c_int()
+        check(lib().xdet_resnet_calibrate(self.handle, self._images.ptr, n, ctypes.byref(k), self.stream.handle))
+        return {name: e for name, e in self.plane_scales().items() if e}
+
+    def plane_scales(self):
+        n = ctypes.c_int()
+        check(lib().xdet_net_plane_scales(self.handle, 0, ctypes.byref(n), None))
+        exps = (ctypes.c_int * max(n.value, 1))()
+        check(lib().xdet_net_plane_scales(self.handle, n.value, ctypes.byref(n), exps))
+        out = {}
+        buf = ctypes.create_string_buffer(256)
+        for i in range(n.value):
+            check(lib().xdet_net_plane_scale_name(self.handle, i, buf, 256))
+            out['%d: %s' % (i, buf.value.decode())] = exps[i]
+        return out
+
     def flops_per_image(self):
         f = ctypes.c_double()
         check(lib().xdet_resnet_flops_per_image(self.handle, ctypes.byref(f)))
