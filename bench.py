@@ -94,7 +94,8 @@ def parse():
                     help='after the K timed steps: an UN-timed-for-value leg of back-to-back steps of about this many '
                          'seconds (reported as sustained_images_per_sec), so that a utilisation sampler with a period of '
                          'seconds sees the GPU busy whatever --steps is; 0 = off')
-    ap.add_argument('--no-ksplit', action='store_true', help='RPN conv / narrow head GEMM on the plain kernels (A/B runs)')
+    ap.add_argument('--ksplit', default='on', choices=['on', 'off', 'all'],
+                    help='fixed split-K: narrow head GEMM (on, default), nothing (off), RPN conv as well (all) -- A/B runs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=200, help='images of the bounded CPU-baseline sample (~10-20 s)')
     ap.add_argument('--cpu-batch', type=int, default=8, help='images per call of the C++ CPU baseline')
@@ -374,7 +375,7 @@ def main():
         sb = B // ways                               # images per sub-batch / net instance
         nets = [LightHeadDetector(weights, image_size=S, max_batch=sb, rpn_post_nms_top_n=args.proposals,
                                   rpn_stream='main' if args.serial_rpn else 'side', conv3x3=args.conv3x3,
-                                  pool=args.pool, ksplit=not args.no_ksplit)
+                                  pool=args.pool, ksplit=args.ksplit)
                 for _ in range(ways)]
         net = nets[0]
         kind = 0

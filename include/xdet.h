@@ -223,8 +223,9 @@ int xdet_net_set_weight(void* net, const char* name, const float* data_host, int
  *   "conv3x3" = "patch" | "gemm": block1_conv2 on the staged-tile kernel (default) or the implicit-GEMM kernel.
  *   "pool" = "split" | "whole" | "split_all": the horizontal half of the block2 / block3 max-pools in the producing
  *   block's epilogue (default) or the whole pool as its own kernel.
- *   "ksplit" = "on" | "off": the RPN 3x3 conv and the 2048 -> 25 head GEMM (a single image: 32 / 3 tiles against 207 / 64
- *   K steps) on the fixed split-K kernel (default; results identical at every batch size) or on the plain kernels.
+ *   "ksplit" = "on" | "off" | "all": the 2048 -> 25 head GEMM (a single image: 3 tiles against 64 K steps) on the fixed
+ *   split-K kernel (on, the default; a layer constant: results identical at every batch size), nothing (off), or the RPN
+ *   3x3 conv as well (all: 32 tiles against 207 K steps; faster for one image, 0.9 % slower at bench-size batches).
  *   "check_range" = "off" | "on": after each forward validate everything that is turned into f16 against the f16 range --
  *   every split plane (no inf / NaN in the hi plane; the planes hold x * 2^-e after xdet_net_calibrate), the f32 input
  *   of a register-split conv (|x| <= 65504) and of a fused separable block (relu?(x) * sum|taps| * 2^-e <= 65504) -- and

@@ -8,14 +8,16 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/profiles
 mkdir -p $OUT
 cd $REPO
-B="python bench.py --no-cpu-baseline --steps 20 --warmup 3"
+B="python bench.py --no-cpu-baseline --steps 20 --warmup 3 --sustain-seconds 0"
 $B --ops > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench_ops.txt
 $B --no-parity --ways 1 --batch 128 > $OUT/${TAG}_bench_1way_b128.json 2>/dev/null
 $B --no-parity --batch 128 > $OUT/${TAG}_bench_2x64.json 2>/dev/null
-$B --no-parity --batch 1 --steps 200 --warmup 20 > $OUT/${TAG}_bench_b1.json 2>/dev/null
+$B --no-parity --batch 1 --steps 300 --warmup 30 --sustain-seconds 0 > $OUT/${TAG}_bench_b1.json 2>/dev/null
+$B --no-parity --batch 1 --steps 300 --warmup 30 --sustain-seconds 0 --ksplit all > $OUT/${TAG}_bench_b1_ksplit_all.json 2>/dev/null
 $B --no-parity --batch 8 --ways 1 --steps 100 --warmup 20 > $OUT/${TAG}_bench_b8.json 2>/dev/null
-$B --no-parity --workload resnet50 --batch 8 --steps 100 --warmup 20 > $OUT/${TAG}_bench_resnet50_b8.json 2>/dev/null
-$B --no-parity --workload resnet50 --batch 32 --steps 50 --warmup 10 > $OUT/${TAG}_bench_resnet50_b32.json 2>/dev/null
+$B --no-parity --workload resnet50 --batch 8 --steps 100 --warmup 20 --sustain-seconds 0 --ops > $OUT/${TAG}_bench_resnet50_b8.json 2> $OUT/${TAG}_bench_resnet50_b8_ops.txt
+$B --no-parity --workload resnet50 --batch 8 --resnet-ways 1 --steps 100 --warmup 20 --sustain-seconds 0 > $OUT/${TAG}_bench_resnet50_b8_1way.json 2>/dev/null
+$B --no-parity --workload resnet50 --batch 32 --steps 50 --warmup 10 --sustain-seconds 0 > $OUT/${TAG}_bench_resnet50_b32.json 2>/dev/null
 $B --no-parity --voc-stream > $OUT/${TAG}_bench_voc_stream.json 2>/dev/null
 $B --no-parity --comm > $OUT/${TAG}_bench_comm_world1.json 2>/dev/null
 $B --no-parity --precision f32 --batch 32 --ways 1 > $OUT/${TAG}_bench_f32_b32.json 2>/dev/null

@@ -10,8 +10,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-parity --no-roofline --serial-rpn $*"
-PARGS="--eager --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-roofline --serial-rpn $*"
+ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-parity --no-roofline --sustain-seconds 0 --serial-rpn $*"
+PARGS="--eager --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-roofline --sustain-seconds 0 --serial-rpn $*"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python $REPO/bench.py $ARGS > $OUT/${TAG}_stats.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do

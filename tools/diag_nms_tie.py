@@ -3,7 +3,7 @@
 tests/test_gpu_e2e.py::test_second_weight_set, finds every (image, class) list with an unmatched detection and prints, for
 each such detection, the kept boxes of the OTHER side that overlap it near the NMS threshold, with scores -- the evidence
 behind `assert_match_or_score_tie`'s two admissible causes (a score tie between two mutually suppressing candidates; a
-candidate whose IoU with a kept box sits at the threshold).   python tools/diag_nms_tie.py [--no-ksplit]"""
+candidate whose IoU with a kept box sits at the threshold).   python tools/diag_nms_tie.py [--no-ksplit | --ksplit-all]"""
 import os
 import sys
 
@@ -25,7 +25,7 @@ def main():
     w = W.make_lighthead_weights(777, gains=gains)
     imgs = W.synthetic_images(2, 480, seed=555)
     set_precision('f16x3')
-    det = LightHeadDetector(w, image_size=480, max_batch=2, rpn_post_nms_top_n=300, ksplit='--no-ksplit' not in sys.argv)
+    det = LightHeadDetector(w, image_size=480, max_batch=2, rpn_post_nms_top_n=300, ksplit='off' if '--no-ksplit' in sys.argv else 'all' if '--ksplit-all' in sys.argv else 'on')
     got = det.forward(imgs)
     tr = {}
     ref = O.lighthead_forward(imgs, w, rpn_post_nms_top_n=300, trace=tr)

@@ -8,5 +8,5 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
 cd /tmp
 timeout 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $REPO/gpurun_out/$NAME -- \
-  python $REPO/bench.py --eager --steps 1 --warmup 1 --no-cpu-baseline --no-parity > $REPO/gpurun_out/$NAME.log 2>&1
+  python $REPO/bench.py --eager --steps 1 --warmup 1 --no-cpu-baseline --no-parity --sustain-seconds 0 > $REPO/gpurun_out/$NAME.log 2>&1
 tail -2 $REPO/gpurun_out/$NAME.log | cut -c1-300

@@ -331,7 +331,6 @@ __global__ __launch_bounds__(64) void conv_ksplit_fold_kernel(ConvParams p) {
   // with flat 64-bit addresses the compiler kept all 16 x S of them live and spilled
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.ks_partial + (size_t)tile * S * V * 1024, 0, S * V * 4096, 0x00020000);
   const int vo = tid * 16;
-  typedef unsigned ks_u4 __attribute__((ext_vector_type(4)));
   // two ranges per pass of a real loop (2 x V loads in flight, then their additions in range order): unrolled over all S
   // ranges the compiler put every load up front and spilled; one range per pass is a chain of S memory round trips
   ks_f4 t[V];

@@ -923,7 +923,9 @@ struct Plan {
   }
 };
 
-enum { ST_BODY = 0, ST_RPN = 1, ST_LSEP = 2, ST_HEAD = 3 };
+// ST_EXIT: the exit flow (conv2d_4, blocks 13-14, net/xception_body.py:340-376) -- part of the backbone, its own stage so that
+// the RPN branch, which only needs mid_outputs (:339), can fork in front of it
+enum { ST_BODY = 0, ST_RPN = 1, ST_LSEP = 2, ST_HEAD = 3, ST_EXIT = 4 };
 
 static inline double nsplit_of(const ConvLayer* L) { return L->precision == PREC_F16X3 ? 3.0 : 1.0; }
 
@@ -945,7 +947,8 @@ struct LightHeadNet : Plan {
   bool large_sep_spectral = false;      // decided at build
   bool rpn_side_stream = true;          // option "rpn_stream" = "side" | "main"
   bool check_range = false;             // option "check_range" = "off" | "on": validate every activation against the f16 range
-  bool latency_ksplit = true;           // option "ksplit" = "on" | "off": fixed split-K for the RPN conv and the narrow head GEMM
+  bool latency_ksplit = true;           // option "ksplit" = "on" | "off" | "all": fixed split-K for the narrow head GEMM (on),
+  bool rpn_ksplit = false;              // ... and the RPN conv as well (all)
   std::vector<std::function<int(int, hipStream_t)>> extra_range_checks;   // tensors that are not plain [N][pixels][ld] (DFT bins)
   bool stem_direct = false;             // block1_conv1 as the dedicated NCHW -> planes kernel
   const float* cur_images = nullptr;
@@ -1025,11 +1028,11 @@ struct LightHeadNet : Plan {
       x = c3;
     }
     mid_x = x;   // mid_outputs = ReLU(mid_x); consumers apply the ReLU on load
-    XDET_TRY(conv_bn("conv2d_4", "batch_normalization_4", eps, ST_BODY, x, 1, 1024, 1, 1, 0, nullptr, 0, &r));
+    XDET_TRY(conv_bn("conv2d_4", "batch_normalization_4", eps, ST_EXIT, x, 1, 1024, 1, 1, 0, nullptr, 0, &r));
     Buf a, b2, c3, d4;
-    XDET_TRY(sep_bn("block13_sepconv1", eps, ST_BODY, x, 728, 1, 1, 0, nullptr, &a));
-    XDET_TRY(sep_bn("block13_sepconv2", eps, ST_BODY, a, 1024, 1, 1, 0, &r, &b2));
-    XDET_TRY(sep_bn("block14_sepconv1", eps, ST_BODY, b2, 1536, 0, 2, 1, nullptr, &c3));   // :354-364
+    XDET_TRY(sep_bn("block13_sepconv1", eps, ST_EXIT, x, 728, 1, 1, 0, nullptr, &a));
+    XDET_TRY(sep_bn("block13_sepconv2", eps, ST_EXIT, a, 1024, 1, 1, 0, &r, &b2));
+    XDET_TRY(sep_bn("block14_sepconv1", eps, ST_EXIT, b2, 1536, 0, 2, 1, nullptr, &c3));   // :354-364
     // The large-separable convs run either as direct implicit GEMMs over split planes or in the DFT domain
     // (spectral.hip: ~5x fewer MFMA FLOPs; one GEMM per frequency bin with M = N*fmap rows).  The spectral form
     // wins at every batch size -- at one image the direct (15,1) conv is a 900-row GEMM with K = 30,720 on 32
@@ -1039,7 +1042,7 @@ struct LightHeadNet : Plan {
     large_sep_spectral = g_default_precision != PREC_F32 && spectral_supported(c3.H) && c3.H == c3.W && large_sep_mode != 1;
     if (large_sep_mode == 2) XDET_REQUIRE(large_sep_spectral, "large_sep=spectral needs a split-precision mode and a 16/30/50 feature map");
     emit_planes_next = large_sep_spectral ? 0 : 1;   // the direct (15,1) conv takes planes; the DFT pass reads f32
-    XDET_TRY(sep_bn("block14_sepconv2", eps, ST_BODY, c3, 2048, 0, 2, 1, nullptr, &d4));   // :366-376
+    XDET_TRY(sep_bn("block14_sepconv2", eps, ST_EXIT, c3, 2048, 0, 2, 1, nullptr, &d4));   // :366-376
     out = d4;
     fmap = out.H;
     return XDET_OK;
@@ -1058,8 +1061,10 @@ struct LightHeadNet : Plan {
     XDET_TRY(L0->init(3, 3, 728, 512, 1, 1, 1, 0, 0, k0->v.data(), nullptr, b0->v.data(), 1));
     Buf hid;
     emit_planes_next = 3;   // only the fused 1x1 heads read it
-    // a single image is 8 x 4 tiles against 207 K steps: fixed split-K (a layer constant: same bits at every batch size)
-    ksplit_next = latency_ksplit;
+    // (a single image is 8 x 4 tiles against 207 K steps.  Fixed split-K -- option "ksplit" = "all" -- takes it from 116 to
+    //  37 us, but costs the 256 x 256 tile at bench-size batches: 1.92 -> 2.36 ms per 128 images, -0.9 % end to end.
+    //  With the fork in front of the exit flow the conv is off the critical path of a single image anyway.)
+    ksplit_next = latency_ksplit && rpn_ksplit;
     XDET_TRY(add_conv("rpn_head/conv2d", ST_RPN, mid_x, L0, nullptr, /*relu_in=*/1, &hid));
     // cls (2A) and box (4A) 1x1 heads share their input: one GEMM over the concatenated filters
     const int co = 6 * A;
@@ -1359,6 +1364,14 @@ struct LightHeadNet : Plan {
     XDET_REQUIRE(images != nullptr, "images is NULL");
     cur_images = images;         // the stem op reads the NCHW input directly (graphs are keyed on this pointer)
     if (!stem_direct) XDET_TRY(launch_nchw_to_nhwc4(images, in4.p, N, 3, cfg.image_size, cfg.image_size, 4, s));
+    XDET_TRY(run_stage(ST_BODY, N, s));
+    return run_stage(ST_EXIT, N, s);
+  }
+  int entry_and_middle_flow(const float* images, int N, hipStream_t s) {      // up to mid_outputs
+    XDET_TRY(check(N));
+    XDET_REQUIRE(images != nullptr, "images is NULL");
+    cur_images = images;
+    if (!stem_direct) XDET_TRY(launch_nchw_to_nhwc4(images, in4.p, N, 3, cfg.image_size, cfg.image_size, 4, s));
     return run_stage(ST_BODY, N, s);
   }
   int rpn_decode(int N, hipStream_t s) {
@@ -1411,12 +1424,15 @@ struct LightHeadNet : Plan {
   }
   int forward_eager(const float* images, int N, const int* shapes, const float* bbox, float* ds, float* db,
                     hipStream_t s) {
-    XDET_TRY(xception_body(images, N, s));
-    // fork: the RPN branch (3x3 conv, 1x1 heads, decode, top-k, NMS -- mostly small latency-bound
-    // launches) runs on a side stream under the large-separable convs, which depend only on `out`.
+    XDET_TRY(entry_and_middle_flow(images, N, s));
+    // fork: the RPN branch (3x3 conv, 1x1 heads, decode, top-k, NMS -- a long conv and then small latency-bound
+    // launches) needs mid_outputs only (net/xception_body.py:339,381-400): it runs on a side stream under the exit flow
+    // AND the large-separable convs (round 4; it used to fork behind the exit flow, where a single image's RPN conv --
+    // 207 K steps on 64 workgroups -- was the longer branch and sat on the critical path).
     // While per-op profiling is on, the branch stays on the main stream: an event pair around a launch that
     // shares the chip with the other branch's kernels would time the sharing, not the kernel.
     if (profiling || !rpn_side_stream) {
+      XDET_TRY(run_stage(ST_EXIT, N, s));
       XDET_TRY(run_stage(ST_RPN, N, s));
       XDET_TRY(rpn_decode(N, s));
       XDET_TRY(get_proposals(N, s));
@@ -1433,6 +1449,7 @@ struct LightHeadNet : Plan {
       XDET_TRY(rpn_decode(N, aux));
       XDET_TRY(get_proposals(N, aux));
       XDET_HIP(hipEventRecord(ev_join, aux));
+      XDET_TRY(run_stage(ST_EXIT, N, s));
       XDET_TRY(run_stage(ST_LSEP, N, s));
       XDET_HIP(hipStreamWaitEvent(s, ev_join, 0));   // join before the head consumes the proposals
     }
@@ -1898,8 +1915,9 @@ int xdet_net_set_option(void* net, const char* key, const char* value) {
     return XDET_OK;
   }
   if (k == "ksplit") {
-    XDET_REQUIRE(v == "on" || v == "off", "ksplit must be on | off");
-    n->latency_ksplit = v == "on";
+    XDET_REQUIRE(v == "on" || v == "off" || v == "all", "ksplit must be on | off | all");
+    n->latency_ksplit = v != "off";
+    n->rpn_ksplit = v == "all";
     return XDET_OK;
   }
   if (k == "check_range") {
@@ -2086,9 +2104,9 @@ int xdet_net_graph_count(void* net, int* count) {
 int xdet_net_flops_per_image(void* net, double* backbone, double* rpn, double* large_sep, double* head) {
   LightHeadNet* n = static_cast<LightHeadNet*>(net);
   XDET_REQUIRE(n && n->built, "net not built");
-  double f[4] = {0, 0, 0, 0};
+  double f[5] = {0, 0, 0, 0, 0};
   for (const Op& op : n->ops) f[op.stage] += std::max(op.flops, 0.0);
-  if (backbone) *backbone = f[ST_BODY];
+  if (backbone) *backbone = f[ST_BODY] + f[ST_EXIT];
   if (rpn) *rpn = f[ST_RPN];
   if (large_sep) *large_sep = f[ST_LSEP];
   if (head) *head = f[ST_HEAD];

@@ -45,7 +45,7 @@ class LightHeadDetector(object):
         check(lib().xdet_net_set_option(self.handle, b'conv3x3', conv3x3.encode()))
         check(lib().xdet_net_set_option(self.handle, b'pool', pool.encode()))
         check(lib().xdet_net_set_option(self.handle, b'check_range', b'on' if check_range else b'off'))
-        check(lib().xdet_net_set_option(self.handle, b'ksplit', b'on' if ksplit else b'off'))
+        check(lib().xdet_net_set_option(self.handle, b'ksplit', ksplit.encode() if isinstance(ksplit, str) else (b'on' if ksplit else b'off')))
         check(lib().xdet_net_build(self.handle))
         self.max_batch = max_batch
         self.image_size = image_size
