@@ -67,8 +67,13 @@ __global__ __launch_bounds__(256) void dft_fwd_kernel(const float* __restrict__ 
 #pragma unroll
   for (int i = 0; i < F; ++i) v[i] = ok ? *reinterpret_cast<const float4*>(base + i * step) : make_float4(0.f, 0.f, 0.f, 0.f);
   const int c32n = (2 * ld) >> 5;
+  // gridDim.z workgroups share a line's bins (every bin is computed from the line alone: how the bins are dealt out
+  // changes nothing in the results).  One workgroup per line walks all L/2 bins in ~30 us -- fine when thousands of lines
+  // fill the chip, the critical path of a single image's large-separable branch otherwise (4 x 16 workgroups).
+  const int nbz = (NB + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int b_lo = (int)blockIdx.z * nbz, b_hi = min(NB, b_lo + nbz);
 #pragma unroll 1
-  for (int b = 0; b < NB; ++b) {
+  for (int b = b_lo; b < b_hi; ++b) {
     const float* __restrict__ tr = tab + (size_t)b * 2 * F;
     const float* __restrict__ ti = tr + F;
     float4 re = make_float4(0.f, 0.f, 0.f, 0.f), im = re;
@@ -88,7 +93,9 @@ __global__ __launch_bounds__(256) void dft_fwd_kernel(const float* __restrict__ 
 
 // Y: [L/2 * m_pad][ldn] f32, re at channel c, im at channel C_ld + c.  tab: [L/2][2][F] (inverse coefficients,
 // 1/L and the factor 2 of the conjugate half folded in).  out = relu?(idft * scale + shift), NHWC stride ldo.
-template <int F, int L>
+// ZI: workgroups per line along the output positions (each output is its own sum over the bins: dealing the positions
+// out changes nothing in the results); 2 for the few lines of one or two images, else 1.
+template <int F, int L, int ZI>
 __global__ __launch_bounds__(256) void dft_inv_kernel(const float* __restrict__ Y, int ldn, int C_ld, int M, int m_pad,
                                                       const float* __restrict__ tab, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, int relu, float* __restrict__ out,
@@ -102,18 +109,21 @@ __global__ __launch_bounds__(256) void dft_inv_kernel(const float* __restrict__ 
   const int m = blockIdx.x * 8 + (lane >> 3);
   if (m >= M) return;
   const int n = m / F, o = m - n * F;
-  float4 acc[F];
+  static_assert(F % ZI == 0, "output positions must divide evenly");
+  constexpr int G = F / ZI;                          // output positions of this workgroup: [i0, i0 + G)
+  const int i0 = (int)blockIdx.z * G;
+  float4 acc[G];
 #pragma unroll
-  for (int i = 0; i < F; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < G; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
   for (int b = 0; b < NB; ++b) {
     const float* row = Y + ((size_t)b * m_pad + m) * ldn + c;
     const float4 yr = *reinterpret_cast<const float4*>(row);
     const float4 yi = *reinterpret_cast<const float4*>(row + C_ld);
-    const float* __restrict__ tr = tab + (size_t)b * 2 * F;
+    const float* __restrict__ tr = tab + (size_t)b * 2 * F + i0;
     const float* __restrict__ ti = tr + F;
 #pragma unroll
-    for (int i = 0; i < F; ++i) {
+    for (int i = 0; i < G; ++i) {
       const float cr = tr[i], ci = ti[i];
       acc[i].x = fmaf(yr.x, cr, acc[i].x); acc[i].y = fmaf(yr.y, cr, acc[i].y);
       acc[i].z = fmaf(yr.z, cr, acc[i].z); acc[i].w = fmaf(yr.w, cr, acc[i].w);
@@ -122,10 +132,10 @@ __global__ __launch_bounds__(256) void dft_inv_kernel(const float* __restrict__ 
     }
   }
   const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
-  float* base = out + ((size_t)n * F * F + (axis == 0 ? o : o * F)) * ldo + c;
   const size_t step = (size_t)(axis == 0 ? F : 1) * ldo;
+  float* base = out + ((size_t)n * F * F + (axis == 0 ? o : o * F)) * ldo + c + (size_t)i0 * step;
 #pragma unroll
-  for (int i = 0; i < F; ++i) {
+  for (int i = 0; i < G; ++i) {
     float4 t = make_float4(fmaf(acc[i].x, sc.x, sh.x), fmaf(acc[i].y, sc.y, sh.y), fmaf(acc[i].z, sc.z, sh.z),
                            fmaf(acc[i].w, sc.w, sh.w));
     // NaN-propagating ReLU: fmaxf(NaN, 0) = 0 would turn an overflowed bin (hi = inf in the planes -> NaN out of the
@@ -217,7 +227,10 @@ void spectral_weights(const float* w, int T, int cin, int cout, int cin_ld, int 
 template <int F>
 static int launch_fwd_t(const float* in, int ld, int axis, int N, int m_pad, const float* tab, u16* hi, u16* lo, hipStream_t s) {
   const int M = N * F;
-  dim3 grid((unsigned)cdiv(M, 8), (unsigned)cdiv(ld / 32, 4));
+  // few lines (one or two images): deal the bins of a line to up to 6 workgroups so that the launch covers the chip
+  const int64_t wgs = cdiv(M, 8) * cdiv(ld / 32, 4);
+  const unsigned z = wgs >= 512 ? 1u : wgs >= 256 ? 2u : wgs >= 128 ? 4u : 6u;
+  dim3 grid((unsigned)cdiv(M, 8), (unsigned)cdiv(ld / 32, 4), z);
   hipLaunchKernelGGL((dft_fwd_kernel<F, F + 14>), grid, dim3(256), 0, s, in, ld, axis, M, m_pad, tab, hi, lo);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
@@ -226,9 +239,15 @@ template <int F>
 static int launch_inv_t(const float* Y, int ldn, int C_ld, int N, int m_pad, const float* tab, const float* scale,
                         const float* shift, int relu, float* out, int ldo, int axis, hipStream_t s) {
   const int M = N * F;
-  dim3 grid((unsigned)cdiv(M, 8), (unsigned)cdiv(C_ld / 32, 4));
-  hipLaunchKernelGGL((dft_inv_kernel<F, F + 14>), grid, dim3(256), 0, s, Y, ldn, C_ld, M, m_pad, tab, scale, shift, relu,
-                     out, ldo, axis);
+  if (cdiv(M, 8) * cdiv(C_ld / 32, 4) < 256) {        // few lines: two workgroups per line
+    dim3 grid((unsigned)cdiv(M, 8), (unsigned)cdiv(C_ld / 32, 4), 2);
+    hipLaunchKernelGGL((dft_inv_kernel<F, F + 14, 2>), grid, dim3(256), 0, s, Y, ldn, C_ld, M, m_pad, tab, scale, shift, relu,
+                       out, ldo, axis);
+  } else {
+    dim3 grid((unsigned)cdiv(M, 8), (unsigned)cdiv(C_ld / 32, 4));
+    hipLaunchKernelGGL((dft_inv_kernel<F, F + 14, 1>), grid, dim3(256), 0, s, Y, ldn, C_ld, M, m_pad, tab, scale, shift, relu,
+                       out, ldo, axis);
+  }
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }
