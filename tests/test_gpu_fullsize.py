@@ -159,7 +159,7 @@ def test_more_images_against_the_oracle(oracle, lh_weights, lsep):
     assert ties <= 2 and matched >= total - 4 * ties, (matched, total, ties)
 
 
-@pytest.mark.parametrize('nb', [3, 8, 17, 32])
+@pytest.mark.parametrize('nb', [1, 3, 8, 17, 32])
 def test_batch_invariance_across_batch_sizes(big, lh_weights, nb):
     """every batch size selects its own mix of tile shapes (128x64 ... 256x256) per layer: the first nb
     images computed as a batch of nb equal the same images inside the batch of 64, bit for bit"""
