@@ -13,9 +13,10 @@ from xdet.runtime import DeviceBuffer, Event, Stream, to_device   # noqa: E402
 
 def main():
     use_max = 0 if '--mean' in sys.argv else 1          # --mean: the 'mean' pooling form
+    nchw = '--nchw' in sys.argv                         # --nchw: the op's public layout (one channel per lane)
     n, h, w, r, g, c, ldc = 64, 30, 30, 300, 7, 490, 512
     rng = np.random.default_rng(0)
-    feat = to_device(rng.standard_normal((n, h, w, ldc)).astype(np.float32))
+    feat = to_device(rng.standard_normal((n, c, h, w) if nchw else (n, h, w, ldc)).astype(np.float32))
     pool = DeviceBuffer(n * r * c * 4)
     st = Stream()
     for name, size in [('1 px', 1. / 30), ('0.2', 0.2), ('0.45', 0.45), ('0.7', 0.7), ('full', 1.0), ('mixed', None)]:
@@ -29,7 +30,7 @@ def main():
         samples = float(np.mean((np.floor(np.minimum(hh, 1) * h / g) + 1) * (np.floor(np.minimum(ww, 1) * w / g) + 1)))
 
         def run():
-            check(lib().xdet_psroialign_fwd(feat.ptr, rois.ptr, pool.ptr, None, n, c, h, w, r, g, g, use_max, 1, ldc, c, 0, st.handle))
+            check(lib().xdet_psroialign_fwd(feat.ptr, rois.ptr, pool.ptr, None, n, c, h, w, r, g, g, use_max, 0 if nchw else 1, c if nchw else ldc, c, 0, st.handle))
         run()
         st.synchronize()
         e0, e1 = Event(), Event()

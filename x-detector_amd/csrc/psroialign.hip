@@ -196,7 +196,51 @@ __global__ __launch_bounds__(256, 4) void psroialign_fwd_kernel(const float* __r
         }
       }
     };
-    if (n_w <= JMAX) {
+    if (VEC == 1 && layout == 0 && n_w <= JMAX) {
+      // NCHW, the op's public layout: the two corners of a sample row are NEIGHBOURS in memory (x, x + 1), so one 8-byte
+      // load (dword-aligned is enough for global memory) fetches both -- half the gathers, which are what bounds this
+      // kernel; the last column (x + 1 clamped to W - 1, i.e. the same pixel twice) takes a 4-byte load.  Values, typing
+      // and order of the blend are untouched.
+      const int coff = c_in * sc;
+      int xo0[JMAX];
+      bool pair[JMAX];
+      float fxs[JMAX];
+      double wx0[JMAX];
+#pragma unroll
+      for (int j = 0; j < JMAX; ++j) {
+        if (j < n_w) {
+          const float x = (float)((double)(x0 + step_w * (float)j) + half_w);
+          const int ix = (int)x;
+          const float fx = x - (float)ix;
+          xo0[j] = ix + coff;
+          pair[j] = ix + 1 <= W - 1;
+          fxs[j] = fx;
+          wx0[j] = 1. - fx;
+        }
+      }
+      typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+      for (int i = 0; i < n_h; ++i) {
+        const float y = (float)((double)(y0 + step_h * (float)i) + half_h);
+        const int iy = (int)y;
+        const float fy = y - (float)iy;
+        const int yo0 = iy * sy, yo1 = min(iy + 1, H - 1) * sy;
+        const double wy0 = 1. - fy, wy1 = fy;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+          if (j < n_w) {
+            vecf f00, f10, f01, f11;
+            if (pair[j]) {
+              const f2u a = *reinterpret_cast<const f2u*>(fimg + yo0 + xo0[j]), b = *reinterpret_cast<const f2u*>(fimg + yo1 + xo0[j]);
+              f00[0] = a[0]; f01[0] = a[1]; f10[0] = b[0]; f11[0] = b[1];
+            } else {
+              f00[0] = f01[0] = fimg[yo0 + xo0[j]];
+              f10[0] = f11[0] = fimg[yo1 + xo0[j]];
+            }
+            blend(wx0[j] * wy0, wx0[j] * wy1, (double)fxs[j] * wy0, fxs[j] * fy, f00, f10, f01, f11, n_w * i + j);
+          }
+        }
+      }
+    } else if (n_w <= JMAX) {
       const int coff = c_in * sc;
       int xo0[JMAX], xo1[JMAX];
       float fxs[JMAX];
@@ -320,6 +364,26 @@ __global__ __launch_bounds__(256, 4) void psroialign_fwd_kernel(const float* __r
   }
 }
 
+// [C][HW] -> [HW][C] per image through 32 x 32 LDS tiles (both sides coalesced): the front end of the NCHW form below
+__global__ __launch_bounds__(256) void psroi_nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* src = in + (size_t)n * C * HW;
+  float* dst = out + (size_t)n * HW * C;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, px = p0 + tx;
+    tile[ty + 8 * k][tx] = (c < C && px < HW) ? src[(size_t)c * HW + px] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int px = p0 + ty + 8 * k, c = c0 + tx;
+    if (px < HW && c < C) dst[(size_t)px * C + c] = tile[tx][ty + 8 * k];
+  }
+}
+
 int launch_psroialign(const float* feat, const float* rois, float* pooled, int32_t* index, int N, int C, int H,
                       int W, int R, int gw, int gh, int use_max, int layout, int ldc, int out_ld,
                       int rois_are_corners, hipStream_t s) {
@@ -330,6 +394,26 @@ int launch_psroialign(const float* feat, const float* rois, float* pooled, int32
   XDET_REQUIRE(layout == 0 || layout == 1, "feat_layout must be 0 (NCHW) or 1 (NHWC)");
   XDET_REQUIRE(ldc >= C && out_ld >= C, "channel strides must be >= C");
   if ((int64_t)N * R == 0) return XDET_OK;
+  // NCHW (the reference op's layout, light_head_rfcn_eval.py:85): neighbouring channels are H * W floats apart, so every
+  // lane of a gather touches its own cache line (553 us for 64 x 300 ROIs of the mixed set against 120 us for the NHWC
+  // form).  With enough ROIs it pays to transpose the map once into a stream-ordered scratch allocation and run the NHWC
+  // two-channel kernel on it: same values, same arithmetic.  (XDET_PSROI=direct_nchw, an odd bank, or a failed
+  // allocation -- e.g. inside a stream capture -- keep the direct form.)
+  static const bool direct_nchw = getenv("XDET_PSROI") && !strcmp(getenv("XDET_PSROI"), "direct_nchw");
+  if (layout == 0 && !direct_nchw && (C / (gw * gh)) % 2 == 0 && C % 2 == 0 && (int64_t)R * C >= (int64_t)4 * H * W) {
+    float* scratch = nullptr;
+    const size_t bytes = (size_t)N * H * W * C * sizeof(float);
+    if (hipMallocAsync(reinterpret_cast<void**>(&scratch), bytes, s) == hipSuccess && scratch) {
+      hipLaunchKernelGGL(psroi_nchw_to_nhwc_kernel, dim3((unsigned)cdiv(H * W, 32), (unsigned)cdiv(C, 32), (unsigned)N), dim3(256), 0, s,
+                         feat, scratch, C, H * W);
+      const int rc = launch_psroialign(scratch, rois, pooled, index, N, C, H, W, R, gw, gh, use_max, 1, C, out_ld,
+                                       rois_are_corners, s);
+      (void)hipFreeAsync(scratch, s);
+      XDET_LAUNCH_CHECK();
+      return rc;
+    }
+    (void)hipGetLastError();                             // no scratch: the direct form below
+  }
   const int64_t blocks = cdiv(N, 8) * 8 * cdiv(R, 4);   // image n on XCD n & 7 (see the kernel)
   // two channels per lane (8-byte corner loads) where the layout allows it: NHWC, even bank and channel stride,
   // 8-byte aligned map; XDET_PSROI=element forces the one-channel form (A/B measurements)
