@@ -6,8 +6,9 @@
 One "step" = one pass of the whole hot path (backbone + RPN + proposals + PsRoiAlign + light
 head + per-class NMS) over one batch of B synthetic 480x480 images per GPU, inputs already
 resident in HBM.  The batch runs as --ways concurrent sub-batches (default 2 x 128), each a net
-instance replaying its hipGraph on its own stream, so the partial last round of workgroups of one
-launch is filled by the other stream's kernels.
+instance replaying its hipGraph on its own stream: while one stream is in an HBM-bound launch
+(depthwise, pools, DFT passes) the other's GEMMs have the matrix pipes (measured +3 % over one
+stream of 256; 4 x 64 is slower again: profiles/NOTES_r04.md).
 
 Multi-GPU (--gpus N > 1): one process per GPU.  Started plainly, this script spawns the N ranks
 itself (xdet.launch); started by `python -m torch.distributed.run --nproc-per-node N ...` it IS one
