@@ -624,7 +624,7 @@ def main():
                            # efficiency against its own N=1 run, this is the same curve read off ONE line
                            'weak_scaling_efficiency_vs_rank_median': (round(value / (world * float(np.median(rates))), 4)
                                                                       if rates and all(rates) else None),
-                           'expected_images_per_sec_if_linear': {'1': 3740, '2': 7400, '4': 14800, '8': 29500,
+                           'expected_images_per_sec_if_linear': {'1': 3900, '2': 7700, '4': 15400, '8': 30800,
                                                                  'from': 'DESIGN.md section 6 (per-GPU rate of the default '
                                                                          'configuration x N, all-gather hidden)'},
                            # gathered through ncclAllGather: one record per rank
