@@ -492,3 +492,37 @@ def test_ksplit_fold_in_the_large_tile_kernel_is_the_same_function():
     finally:
         set_precision('f32')
 
+
+
+@pytest.mark.parametrize('shape', [(80, 30, 30, 728, 728, True, False), (70, 31, 29, 512, 1024, False, True),
+                                   (300, 15, 15, 1024, 1536, True, True)])
+def test_large_batch_pointwise_gemm_is_the_same_function(shape):
+    """Pointwise layers at bench-size batches run on 256 x 256 tiles whose epilogue takes the form without per-row
+    predicates (conv_epilogue_full: buffer stores, columns beyond ldo out of range) on every tile but the ragged last one.
+    Same K order and the same epilogue arithmetic: an image's rows are the bits the small-batch kernels (128 x 64 deep ring,
+    128 x 128) give it -- also across the ragged last M tile and the padded last N tile (728 -> 768)."""
+    from xdet.ops import Conv2D
+    from xdet.runtime import DeviceTensor, set_precision
+    N, H, W, cin, cout, with_res, relu = shape
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((N, H, W, cin)).astype(np.float32)
+    k = (rng.standard_normal((1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((N, H, W, cout)).astype(np.float32) if with_res else None
+    set_precision('f16x3')
+    try:
+        conv = Conv2D(k, 1, 'SAME', 1, sc, sh, relu=relu)
+        big = conv(DeviceTensor.from_numpy(x), residual=DeviceTensor.from_numpy(res) if with_res else None, planes=True).numpy()
+        for n0, n in ((0, 1), (N // 2, 3), (N - 2, 2)):
+            small = conv(DeviceTensor.from_numpy(x[n0:n0 + n]),
+                         residual=DeviceTensor.from_numpy(res[n0:n0 + n]) if with_res else None, planes=True).numpy()
+            assert np.array_equal(small, big[n0:n0 + n]), (n0, n)
+    finally:
+        set_precision('f32')
+    ref = x[:2].reshape(-1, cin).astype(np.float64) @ k.reshape(cin, cout).astype(np.float64) * sc + sh
+    if with_res:
+        ref = ref + res[:2].reshape(-1, cout)
+    if relu:
+        ref = np.maximum(ref, 0)
+    assert np.abs(big[:2].reshape(-1, cout) - ref).max() < 3e-5 * max(1.0, np.abs(ref).max())

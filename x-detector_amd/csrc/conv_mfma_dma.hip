@@ -328,7 +328,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
     __builtin_amdgcn_sched_barrier(0);
     mma(a0h, a0l, b0h, b0l);
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();                             // waits vmcnt(0)/lgkmcnt(0) first: DMA(kt+1) + set B landed
+    // explicit: that DMA(kt+1) has landed must not depend on the compiler's own tracking of LDS-DMA writes against later
+    // LDS reads -- it put the vmcnt(0) here by itself in this kernel and left it out of a restructured copy of the loop
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                             // (+ lgkmcnt(0): set B landed) every wave is done with stage kt
     // fragment reads first: the compiler orders LDS reads against the DMA's LDS writes, so reads
     // placed after issue() could not move up between the DMA pieces
     if (STEADY || kt + 1 < nk) load_frags(buf ^ 1, 0, a0h, a0l, b0h, b0l);
@@ -371,7 +374,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
         for (int j = 0; j < TN; ++j) acc[i][j] = tot[i][j] + acc[i][j];
     }
   }
-  conv_epilogue<WM, WN, TM, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wm, wn, m0, n0);
+  // (all rows below M -- every tile but a ragged last one: the form without per-row predicates, conv_epilogue.h)
+  if (m0 + BM <= p.M) conv_epilogue_full<WM, WN, TM, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wm, wn, m0, n0);
+  else conv_epilogue<WM, WN, TM, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wm, wn, m0, n0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -598,7 +603,8 @@ __global__ __launch_bounds__(256) void conv_dma_deep_kernel(ConvParams p_in) {
     ring = ring + PAIR >= NSTAGE ? ring + PAIR - NSTAGE : ring + PAIR;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy tail steps write LDS too
-  conv_epilogue<32, 64, 1, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wave, 0, m0, n0);
+  if (m0 + 128 <= p.M) conv_epilogue_full<32, 64, 1, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wave, 0, m0, n0);
+  else conv_epilogue<32, 64, 1, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wave, 0, m0, n0);
 }
 
 // pointwise layers whose planes and weights stay below 4 GiB (32-bit buffer offsets) take the buffer-load form
