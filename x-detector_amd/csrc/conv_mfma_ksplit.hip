@@ -298,7 +298,8 @@ __global__ __launch_bounds__(256) void conv_dma_ksplit_kernel(ConvParams p) {
               ks_f4{acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
     return;                                                // the fold + epilogue: conv_ksplit_fold_kernel, next launch
   }
-  conv_epilogue<WM, WN, TM, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wm, wn, m0, n0);
+  if (m0 + BM <= p.M) conv_epilogue_full<WM, WN, TM, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wm, wn, m0, n0);
+  else conv_epilogue<WM, WN, TM, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wm, wn, m0, n0);
 }
 
 // Second launch of the parallel mode: ONE WAVE per (tile, wave sub-tile) folds the S slabs in range order -- the thread
@@ -359,7 +360,8 @@ __global__ __launch_bounds__(64) void conv_ksplit_fold_kernel(ConvParams p) {
         const ks_f4 x = t[(i * TN + j) * 4 + q];
         acc[i][j][q * 4] = x.x; acc[i][j][q * 4 + 1] = x.y; acc[i][j][q * 4 + 2] = x.z; acc[i][j][q * 4 + 3] = x.w;
       }
-  conv_epilogue<WM, WN, TM, TN, 1, LDS_BYTES>(p, acc, smem16, 0, lane, wm, wn, m0, n0);
+  if (m0 + BM <= p.M) conv_epilogue_full<WM, WN, TM, TN, 1, LDS_BYTES>(p, acc, smem16, 0, lane, wm, wn, m0, n0);
+  else conv_epilogue<WM, WN, TM, TN, 1, LDS_BYTES>(p, acc, smem16, 0, lane, wm, wn, m0, n0);
 }
 
 template <int BN, int WAVES_M, int WAVES_N>

@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f16_kernel(ConvParams p) {
     __syncthreads();
   }
 
-  conv_epilogue<WM, WN, TM, TN, 4, 2 * STAGE * 2>(p, acc, smem16, wave, lane, wm, wn, m0, n0);
+  if (m0 + BM <= p.M) conv_epilogue_full<WM, WN, TM, TN, 4, 2 * STAGE * 2>(p, acc, smem16, wave, lane, wm, wn, m0, n0);
+  else conv_epilogue<WM, WN, TM, TN, 4, 2 * STAGE * 2>(p, acc, smem16, wave, lane, wm, wn, m0, n0);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool SMALL_CIN, int NSPLIT>
