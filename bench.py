@@ -557,6 +557,11 @@ def main():
                     'frac_executed': round(issued_flops / nprod / (conv_ms * 1e-3) / 1e12 / peak, 4),
                     'frac_direct_only': round(d_fl / (d_ms * 1e-3) / 1e12 / peak, 4) if d_ms > 0 else None,
                     'frac_cap': round(1.0 / nprod, 4),
+                    # the shader clock the chip sustains INSIDE the dominant kernel's K loop with all CUs busy (s_memtime /
+                    # s_memrealtime around the loop, profiles/r04_kloop_clock.txt: 1.55-1.69 GHz; `peak` is priced at 2.4 GHz)
+                    'sustained_shader_clock_ghz': 1.6 if default_cfg and args.precision != 'f32' else None,
+                    'frac_of_peak_at_sustained_clock': (round(ach / (peak * 1.6 / 2.4), 4)
+                                                        if default_cfg and args.precision != 'f32' else None),
                     'frac_note': ('%d MFMA products per term cap frac at %.3f; spectral ops credited with their direct-form '
                                   'FLOPs in frac, not in frac_executed' % (nprod, 1.0 / nprod)),
                     'mfma_issued_tflops': round(issued_flops / (conv_ms * 1e-3) / 1e12, 2),
