@@ -124,6 +124,18 @@ int xdet_conv_set_ksplit(void* layer, int ksplit, int mode, int max_parallel_til
 int xdet_split_f32(const float* in, uint16_t* hi, uint16_t* lo, int64_t n_pix, int ld, int relu, void* stream);
 int xdet_conv_forward_planes(void* layer, const uint16_t* in_hi, const uint16_t* in_lo, int N, int H, int W,
                              int ld_in, float* out, int ld_out, const float* residual, void* stream);
+/* The "x8" form of the planes for a pointwise (1x1, stride 1) layer of mode 1 (csrc/conv_params.h): the two cross terms of the
+ * split-precision product, a_hi*w_lo + a_lo*w_hi (2^-11 of the result), are computed from fp8 (e4m3, OCP) copies of the
+ * operands by one block-scaled MFMA per 32 input channels instead of four f16 MFMAs (the GEMM is 21-26 % faster, one
+ * contraction accurate to ~1e-5 instead of ~5e-7 relative: profiles/NOTES_r04.md).  `lo8` has the size and blocking of a
+ * `lo` plane; per (pixel, 32-channel block) it holds 32 bytes fp8(hi * 2^-x8_exp) followed by 32 bytes
+ * fp8(lo * 2^(11 - x8_exp)).  x8_exp: a power-of-two scale of the tensor such that its largest magnitude * 2^-x8_exp lands in
+ * (128, 256] (values beyond 448 * 2^x8_exp saturate in the fp8 copies only).  Inside a net (option "cross" = "fp8") the
+ * depthwise kernels write this form and the calibration pass chooses the exponents; these two entries expose the kernels for
+ * tests. */
+int xdet_split_f32_x8(const float* in, uint16_t* hi, uint16_t* lo8, int64_t n_pix, int ld, int relu, int x8_exp, void* stream);
+int xdet_conv_forward_planes_x8(void* layer, const uint16_t* in_hi, const uint16_t* in_lo8, int N, int H, int W, int ld_in,
+                                float* out, int ld_out, const float* residual, int x8_exp, void* stream);
 int xdet_layer_destroy(void* layer);
 /* depthwise 3x3 SAME stride 1 (the depthwise half of tf.layers.separable_conv2d,
  * net/xception_body.py:224-231); dw_kernel_host f32 [3,3,C,1]; in/out NHWC with stride ld. */

@@ -50,6 +50,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--only', default='')
     ap.add_argument('--planes', action='store_true', help='A operand pre-split into f16 planes (LDS-DMA kernel)')
+    ap.add_argument('--x8', action='store_true', help='with --planes: the x8 form of the planes (fp8 cross terms; 1x1 stride-1 layers)')
     ap.add_argument('--custom', action='append', default=[],
                     help='extra 1x1 GEMM shape "H,W,cin,cout" (replaces the built-in list); repeatable')
     a = ap.parse_args()
@@ -77,8 +78,12 @@ def main():
             from xdet.runtime import DeviceBuffer
             n = -(-a.batch * H * W // 16) * 16 * x.ld
             hi, lo = DeviceBuffer(n * 2 + 512, zero=True), DeviceBuffer(n * 2 + 512, zero=True)
-            check(lib().xdet_split_f32(x.ptr, hi.ptr, lo.ptr, a.batch * H * W, x.ld, 0, st.handle))
-            check(lib().xdet_conv_forward_planes(L.handle, hi.ptr, lo.ptr, a.batch, H, W, x.ld, y.ptr, y.ld, None, st.handle))
+            if a.x8:
+                check(lib().xdet_split_f32_x8(x.ptr, hi.ptr, lo.ptr, a.batch * H * W, x.ld, 0, -5, st.handle))
+                check(lib().xdet_conv_forward_planes_x8(L.handle, hi.ptr, lo.ptr, a.batch, H, W, x.ld, y.ptr, y.ld, None, -5, st.handle))
+            else:
+                check(lib().xdet_split_f32(x.ptr, hi.ptr, lo.ptr, a.batch * H * W, x.ld, 0, st.handle))
+                check(lib().xdet_conv_forward_planes(L.handle, hi.ptr, lo.ptr, a.batch, H, W, x.ld, y.ptr, y.ld, None, st.handle))
             st.synchronize()
         if a.planes and a.ksplit:
             res = []
@@ -98,7 +103,9 @@ def main():
             continue
         e0.record(st)
         for _ in range(a.iters):
-            if a.planes:
+            if a.planes and a.x8:
+                check(lib().xdet_conv_forward_planes_x8(L.handle, hi.ptr, lo.ptr, a.batch, H, W, x.ld, y.ptr, y.ld, None, -5, st.handle))
+            elif a.planes:
                 check(lib().xdet_conv_forward_planes(L.handle, hi.ptr, lo.ptr, a.batch, H, W, x.ld, y.ptr, y.ld, None, st.handle))
             else:
                 check(lib().xdet_conv_forward(L.handle, x.ptr, a.batch, H, W, x.ld, y.ptr, y.ld, None, 0, st.handle))

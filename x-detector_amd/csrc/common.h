@@ -90,14 +90,15 @@ int launch_stem_conv3x3s2(const float* in_nchw, const float* w27x32, const float
                           unsigned short* hi, unsigned short* lo, int N, int S, hipStream_t s);
 // mul: the planes' activation pre-scale 2^-e (a power of two; 1 = none): hi + lo = x * mul
 int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, int64_t n_pix, int ld, int relu,
-                     hipStream_t s, float mul = 1.f);
+                     hipStream_t s, float mul = 1.f, int x8 = 0, int x8_exp = 0);
 int launch_split_f32_subsample2(const float* in, unsigned short* hi, unsigned short* lo, int N, int H, int W, int ld,
                                 hipStream_t s, const float* scale = nullptr, const float* shift = nullptr, float mul = 1.f);
 // range calibration: largest |hi| of a plane (f16 bits) / largest |x| or max(x, 0) of an f32 tensor (f32 bits), atomicMax'ed into *out
 int launch_absmax_planes(const unsigned short* hi, int64_t n_halves, unsigned* out, hipStream_t s);
 int launch_absmax_f32(const float* x, int64_t n, int relu, unsigned* out, hipStream_t s);
+// x8: the planes in the x8 form (conv_params.h) with the tensor's fp8 exponent x8_exp
 int launch_depthwise3x3_split(const float* in, const float* w9c, unsigned short* hi, unsigned short* lo, int N,
-                              int H, int W, int C, int ld, int dil, int relu_in, hipStream_t s);
+                              int H, int W, int C, int ld, int dil, int relu_in, hipStream_t s, int x8 = 0, int x8_exp = 0);
 
 // ---- spectral large-separable conv: DFT passes around the grouped GEMM (spectral.hip) ----
 bool spectral_supported(int F);

@@ -28,6 +28,8 @@ namespace xdet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int x8frag __attribute__((ext_vector_type(8)));     // 32 fp8 of one row: a lane's operand of the 32x32x64 block-scaled MFMA
+typedef int x8half __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 
 #define XDET_GLDS16(gptr, lptr)                                                                        \
@@ -46,9 +48,16 @@ typedef unsigned short u16;
 // At large batch this kernel walks all ranges in its one K pipeline and folds its accumulators at the range boundaries:
 // the same expression tree, the same bits, without scratch traffic -- on the 256 x 128 tile, whose 64 accumulator registers
 // per wave leave room for the running total.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE, bool PW = false, bool FOLD = false>
+// X8 (pointwise form only): the cross terms a_hi*w_lo + a_lo*w_hi come from fp8 copies of the operands (conv_params.h) through
+// one v_mfma_scale_f32_32x32x64_f8f6f4 per accumulator block and 32-deep K step -- its 64-deep K is [hi8 | lo8] of the
+// activations against [w_lo8 | w_hi8], a lane's scale byte the power-of-two factor of exactly its 32-deep half
+// (tools/ubench/mfma_scale_semantics.hip) -- instead of four f16 MFMAs: 2 + 1 instead of 6 matrix instructions per block and
+// step.  Per accumulator the order is hi*hi (first 16 channels), hi*hi (second 16), cross -- in every tile shape, so results do
+// not depend on the kernel a batch size selects.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE, bool PW = false, bool FOLD = false, bool X8 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(ConvParams p_in) {
   static_assert(NSTAGE == 2, "two LDS stages");
+  static_assert(!X8 || (PW && NSPLIT == 3 && !FOLD), "x8: pointwise f16x3 layers only");
   constexpr int NW = WAVES_M * WAVES_N;          // waves per workgroup (4 or 8)
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -268,17 +277,45 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
     for (int i = 0; i < TM; ++i) {
       const int o = aoff[i] + ((c ^ asw[i]) << 3);
       ah[i] = *reinterpret_cast<const f16x8*>(Ah + o);
-      if (NSPLIT > 1) al[i] = *reinterpret_cast<const f16x8*>(Al + o);
+      if constexpr (NSPLIT > 1 && !X8) al[i] = *reinterpret_cast<const f16x8*>(Al + o);
     }
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
       const int o = boffs[j] + ((c ^ bsw[j]) << 3);
       bh[j] = *reinterpret_cast<const f16x8*>(Bh + o);
-      if (NSPLIT > 1) bl[j] = *reinterpret_cast<const f16x8*>(Bl + o);
+      if constexpr (NSPLIT > 1 && !X8) bl[j] = *reinterpret_cast<const f16x8*>(Bl + o);
     }
   };
+  // x8: this lane's 32 fp8 of a row's 64-byte record -- the hi8 half for lanes 0..31, the lo8 half for lanes 32..63 (the
+  // instruction's K split) -- are its 16-byte chunks 2*fh and 2*fh + 1 (chunk-permuted like every row of the stage)
+  auto load_x8 = [&](int buf, x8frag* a8, x8frag* b8) {
+    const u16* Al = smem16 + buf * STAGE + BM * ROWB;
+    const u16* Bl = Al + BM * ROWB + BN * ROWB;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const x8half q0 = *reinterpret_cast<const x8half*>(Al + aoff[i] + (((2 * fh) ^ asw[i]) << 3));
+      const x8half q1 = *reinterpret_cast<const x8half*>(Al + aoff[i] + (((2 * fh + 1) ^ asw[i]) << 3));
+      a8[i] = x8frag{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+      const x8half q0 = *reinterpret_cast<const x8half*>(Bl + boffs[j] + (((2 * fh) ^ bsw[j]) << 3));
+      const x8half q1 = *reinterpret_cast<const x8half*>(Bl + boffs[j] + (((2 * fh + 1) ^ bsw[j]) << 3));
+      b8[j] = x8frag{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+    }
+  };
+  // E8M0 scale bytes of this lane's 32-deep half: activations hi8 * 2^e / lo8 * 2^(e - 11), weights w_lo8 * 2^-9 / w_hi8 * 2^2
+  const int x8_sa = X8 ? 127 + p.x8_exp - (fh ? 11 : 0) : 0;
+  const int x8_sb = fh ? 127 + 2 : 127 - 9;
+  auto mma_x8 = [&](const x8frag* a8, const x8frag* b8) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], b8[j], acc[i][j], 0, 0, 0, x8_sa, 0, x8_sb);
+  };
   auto mma = [&](const f16x8* ah, const f16x8* al, const f16x8* bh, const f16x8* bl) {
-    if (NSPLIT > 1) {
+    if constexpr (NSPLIT > 1 && !X8) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -297,9 +334,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
   };
 
-  f16x8 a0h[TM], a0l[TM], b0h[TN], b0l[TN];      // set A: half 0 of the current stage
-  f16x8 a1h[TM], a1l[TM], b1h[TN], b1l[TN];      // set B: half 1
+  f16x8 a0h[TM], a0l[X8 ? 1 : TM], b0h[TN], b0l[X8 ? 1 : TN];      // set A: half 0 of the current stage
+  f16x8 a1h[TM], a1l[X8 ? 1 : TM], b1h[TN], b1l[X8 ? 1 : TN];      // set B: half 1
+  x8frag a8[X8 ? TM : 1], b8[X8 ? TN : 1];                         // x8: the cross-term operands of the whole 32-deep step
   issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                               // stage 0 landed
   if (nk > 1) issue(1, 1);
   load_frags(0, 0, a0h, a0l, b0h, b0l);
@@ -325,6 +364,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
       }
     }
     load_frags(buf, 1, a1h, a1l, b1h, b1l);
+    if constexpr (X8) load_x8(buf, a8, b8);
     __builtin_amdgcn_sched_barrier(0);
     mma(a0h, a0l, b0h, b0l);
     __builtin_amdgcn_sched_barrier(0);
@@ -338,10 +378,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
     if (STEADY || kt + 2 < nk) issue(kt + 2, buf);
     if (!STEADY) __builtin_amdgcn_sched_barrier(0);
     mma(a1h, a1l, b1h, b1l);
+    if constexpr (X8) mma_x8(a8, b8);
     if (STEADY) {
       constexpr int NPIECE = (A_IT + B_IT) * (NSPLIT > 1 ? 2 : 1);
-      constexpr int NMMA = TM * JN * (NSPLIT > 1 ? 3 : 1);
-      constexpr int NRD = (TM + JN) * (NSPLIT > 1 ? 2 : 1);
+      constexpr int NMMA = TM * JN * (X8 ? 2 : NSPLIT > 1 ? 3 : 1);
+      constexpr int NRD = (TM + JN) * (NSPLIT > 1 && !X8 ? 2 : 1);
       __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
 #pragma unroll
       for (int k = 0; k < NPIECE; ++k) {
@@ -633,11 +674,15 @@ static int launch_deep(const ConvParams& p, hipStream_t s) {
   return XDET_OK;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE = 2, bool PW = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE = 2, bool PW = false, bool X8 = false>
 static int launch_d(const ConvParams& p, hipStream_t s) {
   if (!PW && pw_eligible(p)) return launch_d<BM, BN, WAVES_M, WAVES_N, NSPLIT, NSTAGE, true>(p, s);
+  if constexpr (PW && !X8 && NSPLIT == 3) {
+    if (p.x8) return launch_d<BM, BN, WAVES_M, WAVES_N, NSPLIT, NSTAGE, true, true>(p, s);
+  }
+  XDET_REQUIRE(X8 || !p.x8, "conv(dma): x8 planes need a pointwise f16x3 layer below 4 GiB");
   constexpr size_t lds = (size_t)NSTAGE * (2 * BM + 2 * BN) * 32 * sizeof(u16);
-  auto kern = conv_dma_f16_kernel<BM, BN, WAVES_M, WAVES_N, NSPLIT, NSTAGE, PW>;
+  auto kern = conv_dma_f16_kernel<BM, BN, WAVES_M, WAVES_N, NSPLIT, NSTAGE, PW, false, X8>;
   static DeviceOnce once;
   XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
   dim3 grid((unsigned)(cdiv(cdiv(p.M, BM), 8) * 8 * (p.Cout_pad / BN)));
@@ -698,7 +743,8 @@ int launch_conv_mfma_dma(const ConvParams& p_in, int n_tile, int nsplit, hipStre
     if (nsplit == 3 && b128 <= 128 && (!p.group_rows || p.group_rows % 128 == 0)) {
       // few workgroups: the deep operand ring (XDET_CONV_SMALL=2stage: the two-stage kernel, for A/B runs)
       static const bool two_stage = getenv("XDET_CONV_SMALL") && !strcmp(getenv("XDET_CONV_SMALL"), "2stage");
-      return two_stage ? launch_d<128, 64, 4, 1, 3>(p, s) : launch_deep<3>(p, s);
+      // (x8 planes: the two-stage kernel -- the deep ring has no x8 form yet)
+      return two_stage || p.x8 ? launch_d<128, 64, 4, 1, 3>(p, s) : launch_deep<3>(p, s);
     }
     return nsplit == 1 ? launch_d<128, 128, 2, 2, 1>(p, s) : launch_d<128, 128, 2, 2, 3>(p, s);
   }

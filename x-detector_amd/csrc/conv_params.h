@@ -43,6 +43,14 @@ struct ConvParams {
   // fixed split of the reduction (conv_mfma_ksplit.hip only): the K steps are cut into `ksplit` equal ranges and the
   // result is the left fold of the per-range sums; ks_partial = scratch slabs [tiles][ksplit][128 x N tile] f32 of
   // the mode that runs the ranges in parallel
+  // "x8" form of a pointwise contraction on the LDS-DMA path (conv_mfma_dma.hip): the two cross terms of the split-precision
+  // product (a_hi*w_lo + a_lo*w_hi, 2^-11 of the result) are computed from fp8 (e4m3) copies of the operands by ONE block-scaled
+  // MFMA per 32 real K instead of four f16 MFMAs.  Then `in_lo` / `wt_lo` hold, per 32-channel block of a row, 32 bytes of
+  // hi8 = fp8(hi * 2^-x8_exp) followed by 32 bytes of lo8 = fp8(lo * 2^(11 - x8_exp)) (weights: fp8(w_lo * 2^9) followed by
+  // fp8(w_hi * 2^-2)) in the place of the 32 f16 `lo` values -- same bytes, same DMA.  x8_exp: the activation tensor's
+  // power-of-two fp8 scale, chosen by the calibration pass so that its largest magnitude lands in (128, 256].
+  int x8 = 0;
+  int x8_exp = 0;
   int skip_dead = 1;   // conv_dma_f16_kernel: waves skip 32-column blocks that are pure padding of the N tile (0: A/B runs)
   int ksplit = 1;
   float* ks_partial = nullptr;

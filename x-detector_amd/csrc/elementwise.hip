@@ -48,11 +48,58 @@ __device__ __forceinline__ int64_t blocked_off(int64_t pix, int c, int c32n) {
 }
 
 
-template <bool SPLIT>
+// four f32 -> four fp8 (e4m3, OCP) in one dword: x * mul, clamped to the format's +-448 first (the conversion does not
+// saturate by itself), round to nearest even
+__device__ __forceinline__ unsigned pack_e4m3x4(float a, float b, float c, float d, float mul) {
+  a = __builtin_amdgcn_fmed3f(a * mul, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b * mul, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c * mul, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d * mul, -448.f, 448.f);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (unsigned)r;
+}
+
+// SPLIT: 0 = f32 out, 1 = f16 hi / lo planes, 2 = the x8 form of the planes (conv_params.h): `hi` as before, and in the place
+// of the 32 f16 `lo` values of a (pixel, 32-channel block) 32 bytes fp8(hi * x8_hi) + 32 bytes fp8(lo * x8_lo)
+template <int SPLIT>
 __device__ __forceinline__ void dw_store_strip(const float4* acc, float* __restrict__ out, unsigned short* __restrict__ hi,
                                                unsigned short* __restrict__ lo, int64_t rowpix, int x0, int W, int ld,
-                                               int c) {
-  if (SPLIT) {
+                                               int c, float x8_hi = 0.f, float x8_lo = 0.f) {
+  if (SPLIT == 2) {
+    uint2 h[4];
+    unsigned h8[4], l8[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 v = acc[k];
+      const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y, h2 = (_Float16)v.z, h3 = (_Float16)v.w;
+      f16x4e hv = {h0, h1, h2, h3};
+      h[k] = *reinterpret_cast<uint2*>(&hv);
+      h8[k] = pack_e4m3x4((float)h0, (float)h1, (float)h2, (float)h3, x8_hi);
+      l8[k] = pack_e4m3x4(v.x - (float)h0, v.y - (float)h1, v.z - (float)h2, v.w - (float)h3, x8_lo);
+    }
+    // lane pairs swap halves as below: the even lane ends up with 8 channels of pixels 0 and 2, the odd lane of 1 and 3
+    const bool odd = threadIdx.x & 1;
+    const int cb = c & ~7, c32n = ld >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const uint2 sh = odd ? h[2 * t] : h[2 * t + 1];
+      const unsigned s8h = odd ? h8[2 * t] : h8[2 * t + 1], s8l = odd ? l8[2 * t] : l8[2 * t + 1];
+      uint2 rh;
+      rh.x = __shfl_xor(sh.x, 1); rh.y = __shfl_xor(sh.y, 1);
+      const unsigned r8h = __shfl_xor(s8h, 1), r8l = __shfl_xor(s8l, 1);
+      const uint2 mh = odd ? h[2 * t + 1] : h[2 * t];
+      const unsigned m8h = odd ? h8[2 * t + 1] : h8[2 * t], m8l = odd ? l8[2 * t + 1] : l8[2 * t];
+      const uint4 oh = odd ? make_uint4(rh.x, rh.y, mh.x, mh.y) : make_uint4(mh.x, mh.y, rh.x, rh.y);
+      const uint2 o8h = odd ? make_uint2(r8h, m8h) : make_uint2(m8h, r8h);
+      const uint2 o8l = odd ? make_uint2(r8l, m8l) : make_uint2(m8l, r8l);
+      const int x = x0 + 2 * t + (odd ? 1 : 0);
+      if (x < W) {
+        *reinterpret_cast<uint4*>(hi + blocked_off(rowpix + x, cb, c32n)) = oh;
+        unsigned char* rec = reinterpret_cast<unsigned char*>(lo + blocked_off(rowpix + x, cb & ~31, c32n));   // the block's 64-byte record
+        *reinterpret_cast<uint2*>(rec + (cb & 31)) = o8h;
+        *reinterpret_cast<uint2*>(rec + 32 + (cb & 31)) = o8l;
+      }
+    }
+  } else if (SPLIT) {
     // lane pairs swap halves: the even lane ends up with all 8 channels of pixels 0 and 2, the odd lane
     // with those of pixels 1 and 3 -> 16-B stores, 128-B runs per 8 lanes (instead of 8-B stores in 64-B runs)
     uint2 h[4], l[4];
@@ -153,7 +200,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const float* __restri
         }
       }
     }
-    dw_store_strip<SPLIT>(acc, out, hi, lo, (int64_t)row * W, x0, W, ld, c);
+    dw_store_strip<SPLIT ? 1 : 0>(acc, out, hi, lo, (int64_t)row * W, x0, W, ld, c);
   }
 }
 
@@ -169,13 +216,13 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------
 constexpr int DT_R = 4, DT_X = 32, DT_P = 40;
 
-template <int DIL, bool SPLIT>
+template <int DIL, int SPLIT>
 __global__ __launch_bounds__(256) void depthwise3x3_tile_kernel(const float* __restrict__ in,
                                                                 const float* __restrict__ w9c, float* __restrict__ out,
                                                                 unsigned short* __restrict__ hi,
                                                                 unsigned short* __restrict__ lo, int N, int H, int W,
                                                                 int ld, int relu_in, int ntiles, int TY, int TX,
-                                                                int tiles_per_block, int n_first) {
+                                                                int tiles_per_block, int n_first, float x8_hi, float x8_lo) {
   // `in` points at image n_first of the tensor and N images are covered (one launch per range of images below 2 GiB:
   // the DMA's buffer offsets are 32-bit); `out` / `hi` / `lo` are the whole tensor's, indexed with n_first + n
   static_assert(DT_X + 2 * DIL <= DT_P, "patch row does not fit the LDS pitch");
@@ -285,12 +332,13 @@ __global__ __launch_bounds__(256) void depthwise3x3_tile_kernel(const float* __r
           acc[k].z = fmaf(v.z, ww.z, acc[k].z); acc[k].w = fmaf(v.w, ww.w, acc[k].w);
         }
       }
-    dw_store_strip<SPLIT>(acc, out, hi, lo, ((int64_t)(n_first + n) * H + y) * W, x0 + strip * 4, W, ld, c);
+    dw_store_strip<SPLIT>(acc, out, hi, lo, ((int64_t)(n_first + n) * H + y) * W, x0 + strip * 4, W, ld, c, x8_hi, x8_lo);
   }
 }
 
 static int launch_dw(const float* in, const float* w9c, float* out, unsigned short* hi, unsigned short* lo, int N,
-                     int H, int W, int C, int ld, int dil, int relu_in, hipStream_t s) {
+                     int H, int W, int C, int ld, int dil, int relu_in, hipStream_t s, int x8 = 0, int x8_exp = 0) {
+  const float x8_hi = std::ldexp(1.f, -x8_exp), x8_lo = std::ldexp(1.f, 11 - x8_exp);
   XDET_REQUIRE(ld % 4 == 0 && ld >= C, "depthwise: channel stride must be a multiple of 4");
   XDET_REQUIRE(dil == 1 || dil == 2, "depthwise: dilation must be 1 or 2");
   if ((int64_t)N * H == 0) return XDET_OK;
@@ -308,9 +356,10 @@ static int launch_dw(const float* in, const float* w9c, float* out, unsigned sho
     const int TY = (int)cdiv(H, DT_R), TX = (int)cdiv(W, DT_X);
     const size_t lds = (size_t)2 * (DT_R + 2 * dil) * DT_P * 32 * sizeof(float);
     if (dil == 2) {
-      static DeviceOnce once_t, once_f;
-      XDET_TRY(ensure_dynamic_lds(once_t, reinterpret_cast<const void*>(depthwise3x3_tile_kernel<2, true>), (int)lds));
-      XDET_TRY(ensure_dynamic_lds(once_f, reinterpret_cast<const void*>(depthwise3x3_tile_kernel<2, false>), (int)lds));
+      static DeviceOnce once_t, once_f, once_x;
+      XDET_TRY(ensure_dynamic_lds(once_t, reinterpret_cast<const void*>(depthwise3x3_tile_kernel<2, 1>), (int)lds));
+      XDET_TRY(ensure_dynamic_lds(once_f, reinterpret_cast<const void*>(depthwise3x3_tile_kernel<2, 0>), (int)lds));
+      XDET_TRY(ensure_dynamic_lds(once_x, reinterpret_cast<const void*>(depthwise3x3_tile_kernel<2, 2>), (int)lds));
     }
     for (int nb = 0; nb < N; nb += n_max) {
       const int n = std::min(n_max, N - nb);
@@ -319,17 +368,22 @@ static int launch_dw(const float* in, const float* w9c, float* out, unsigned sho
       const int blocks = (int)std::min<int64_t>(nt, lds > 80 * 1024 ? 256 : 512);   // workgroups per CU that fit in LDS
       const int tpb = (int)cdiv(nt, blocks);
       const dim3 g((unsigned)cdiv(nt, tpb));
+#define XDET_DW_TILE(D, S) hipLaunchKernelGGL((depthwise3x3_tile_kernel<D, S>), g, dim3(256), lds, s, in_r, w9c, out, hi, lo, n, H, W, ld, relu_in, (int)nt, TY, TX, tpb, nb, x8_hi, x8_lo)
       if (dil == 1) {
-        if (split) hipLaunchKernelGGL((depthwise3x3_tile_kernel<1, true>), g, dim3(256), lds, s, in_r, w9c, out, hi, lo, n, H, W, ld, relu_in, (int)nt, TY, TX, tpb, nb);
-        else hipLaunchKernelGGL((depthwise3x3_tile_kernel<1, false>), g, dim3(256), lds, s, in_r, w9c, out, hi, lo, n, H, W, ld, relu_in, (int)nt, TY, TX, tpb, nb);
+        if (split && x8) XDET_DW_TILE(1, 2);
+        else if (split) XDET_DW_TILE(1, 1);
+        else XDET_DW_TILE(1, 0);
       } else {
-        if (split) hipLaunchKernelGGL((depthwise3x3_tile_kernel<2, true>), g, dim3(256), lds, s, in_r, w9c, out, hi, lo, n, H, W, ld, relu_in, (int)nt, TY, TX, tpb, nb);
-        else hipLaunchKernelGGL((depthwise3x3_tile_kernel<2, false>), g, dim3(256), lds, s, in_r, w9c, out, hi, lo, n, H, W, ld, relu_in, (int)nt, TY, TX, tpb, nb);
+        if (split && x8) XDET_DW_TILE(2, 2);
+        else if (split) XDET_DW_TILE(2, 1);
+        else XDET_DW_TILE(2, 0);
       }
+#undef XDET_DW_TILE
       XDET_LAUNCH_CHECK();
     }
     return XDET_OK;
   }
+  XDET_REQUIRE(!x8, "depthwise: x8 planes need the tile kernel (channel stride a multiple of 32, images below 2 GiB)");
   if (dil == 1 && !split) hipLaunchKernelGGL((depthwise3x3_kernel<1, false>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows, yblocks);
   else if (dil == 1) hipLaunchKernelGGL((depthwise3x3_kernel<1, true>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows, yblocks);
   else if (!split) hipLaunchKernelGGL((depthwise3x3_kernel<2, false>), grid, dim3(256), 0, s, in, w9c, out, hi, lo, H, W, ld, relu_in, nrows, yblocks);
@@ -344,10 +398,10 @@ int launch_depthwise3x3(const float* in, const float* w9c, float* out, int N, in
 }
 
 int launch_depthwise3x3_split(const float* in, const float* w9c, unsigned short* hi, unsigned short* lo, int N,
-                              int H, int W, int C, int ld, int dil, int relu_in, hipStream_t s) {
+                              int H, int W, int C, int ld, int dil, int relu_in, hipStream_t s, int x8, int x8_exp) {
   XDET_REQUIRE(hi && lo, "depthwise(split): NULL planes");
   XDET_REQUIRE(ld % 32 == 0, "depthwise(split): channel stride must be a multiple of 32");
-  return launch_dw(in, w9c, nullptr, hi, lo, N, H, W, C, ld, dil, relu_in, s);
+  return launch_dw(in, w9c, nullptr, hi, lo, N, H, W, C, ld, dil, relu_in, s, x8, x8_exp);
 }
 
 // ---- split-precision planes: x = hi + lo, both f16 (the A operand format of conv_mfma_dma.hip) ----
@@ -369,9 +423,10 @@ __device__ __forceinline__ void split8(const float4 a, const float4 b, f16x8e* h
 }
 
 // mul: a power of two (the tensor's activation pre-scale 2^-e, 1 by default): the planes hold x * mul
+template <bool X8>
 __global__ __launch_bounds__(256) void split_f32_kernel(const float* __restrict__ in, unsigned short* __restrict__ hi,
                                                         unsigned short* __restrict__ lo, int64_t n_pix, int ld,
-                                                        int relu, float mul) {
+                                                        int relu, float mul, float x8_hi, float x8_lo) {
   const int c32n = ld >> 5;
   const int64_t n8 = ((n_pix + 15) >> 4) * c32n * 64;   // 16-B output chunks per plane (64 per 1 KB block)
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
@@ -391,17 +446,29 @@ __global__ __launch_bounds__(256) void split_f32_kernel(const float* __restrict_
     f16x8e h, l;
     split8(a, b, &h, &l);
     *reinterpret_cast<f16x8e*>(hi + i * 8) = h;
-    *reinterpret_cast<f16x8e*>(lo + i * 8) = l;
+    if (X8) {   // 8 channels of the (pixel, block) record: 8 bytes of hi8 at +c, 8 bytes of lo8 at +32 + c
+      const float hf[8] = {(float)h[0], (float)h[1], (float)h[2], (float)h[3], (float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+      const float vf[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      unsigned char* rec = reinterpret_cast<unsigned char*>(lo + (i & ~(int64_t)3) * 8);
+      const int cb = (int)(i & 3) * 8;
+      *reinterpret_cast<uint2*>(rec + cb) = make_uint2(pack_e4m3x4(hf[0], hf[1], hf[2], hf[3], x8_hi), pack_e4m3x4(hf[4], hf[5], hf[6], hf[7], x8_hi));
+      *reinterpret_cast<uint2*>(rec + 32 + cb) =
+          make_uint2(pack_e4m3x4(vf[0] - hf[0], vf[1] - hf[1], vf[2] - hf[2], vf[3] - hf[3], x8_lo),
+                     pack_e4m3x4(vf[4] - hf[4], vf[5] - hf[5], vf[6] - hf[6], vf[7] - hf[7], x8_lo));
+    } else {
+      *reinterpret_cast<f16x8e*>(lo + i * 8) = l;
+    }
   }
 }
 
 int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, int64_t n_pix, int ld, int relu,
-                     hipStream_t s, float mul) {
+                     hipStream_t s, float mul, int x8, int x8_exp) {
   XDET_REQUIRE(ld > 0 && ld % 32 == 0, "split: channel stride must be a multiple of 32");
   if (n_pix == 0) return XDET_OK;
   const int64_t n = cdiv(n_pix, 16) * 16 * ld;
   const int blocks = (int)std::min<int64_t>(cdiv(n / 8, 256), 256 * 32);
-  hipLaunchKernelGGL(split_f32_kernel, dim3(blocks), dim3(256), 0, s, in, hi, lo, n_pix, ld, relu, mul);
+  if (x8) hipLaunchKernelGGL(split_f32_kernel<true>, dim3(blocks), dim3(256), 0, s, in, hi, lo, n_pix, ld, relu, mul, std::ldexp(1.f, -x8_exp), std::ldexp(1.f, 11 - x8_exp));
+  else hipLaunchKernelGGL(split_f32_kernel<false>, dim3(blocks), dim3(256), 0, s, in, hi, lo, n_pix, ld, relu, mul, 0.f, 0.f);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }

@@ -76,6 +76,24 @@ static inline unsigned short f32_to_f16_rne(float f) {
   if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;      // round to nearest even (may carry to inf)
   return (unsigned short)(sign | h);
 }
+// OCP fp8 e4m3 (bias 7, largest 448 = 0x7e, no infinities), round to nearest even, saturating: the format of the x8 cross-term
+// operands (conv_params.h; the device side is v_cvt_pk_fp8_f32 in the producing kernels)
+static inline unsigned char f32_to_e4m3(float f) {
+  const unsigned char sgn = std::signbit(f) ? 0x80 : 0;
+  const float a = std::fabs(f);
+  if (!(a == a)) return 0x7f;
+  if (a >= 448.f) return sgn | 0x7e;
+  if (a < 0.015625f) {                                   // below the smallest normal 2^-6: subnormals are multiples of 2^-9
+    const int q = (int)std::nearbyint(std::ldexp((double)a, 9));
+    return sgn | (unsigned char)q;                       // q = 8 is the encoding of 2^-6 itself
+  }
+  int e;
+  (void)std::frexp(a, &e);                               // a = m * 2^e, m in [0.5, 1)
+  e -= 1;
+  int q = (int)std::nearbyint(std::ldexp((double)a, 3 - e));   // 8 .. 16
+  if (q == 16) { q = 8; ++e; }
+  return sgn | (unsigned char)(((e + 7) << 3) | (q - 8));
+}
 static inline float f16_to_f32(unsigned short h) {
   const unsigned sign = (unsigned)(h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
   float v;
@@ -116,6 +134,7 @@ struct ConvLayer : LayerBase {
   // the same f16 weights K-blocked as [Kp/32][Cout_pad][32] for the LDS-DMA kernel: one K-step of a
   // tile's B operand is then one contiguous run
   unsigned short *d_wt_hi_b = nullptr, *d_wt_lo_b = nullptr;
+  unsigned short* d_wt_x8_b = nullptr;   // x8 form of the K-blocked lo plane (conv_params.h): 32 B fp8(w_lo * 2^9) | 32 B fp8(w_hi * 2^-2) per (K block, row)
   unsigned short* d_zeros = nullptr;   // 256 B of zeros on the layer's device: the source of out-of-image taps
   // Activation pre-scale (split-precision range, Plan::calibrate): the A-operand planes hold x * 2^-in_exp and the
   // epilogue scale carries 2^in_exp (exact: powers of two); a planes copy of the output is written as out * 2^-out_exp
@@ -183,6 +202,7 @@ struct ConvLayer : LayerBase {
     if (d_zeros) (void)hipFree(d_zeros);
     if (d_wt_hi_b) (void)hipFree(d_wt_hi_b);
     if (d_wt_lo_b) (void)hipFree(d_wt_lo_b);
+    if (d_wt_x8_b) (void)hipFree(d_wt_x8_b);
     if (d_wt_hi) (void)hipFree(d_wt_hi);
     if (d_wt_lo) (void)hipFree(d_wt_lo);
     if (d_wt) (void)hipFree(d_wt);
@@ -274,6 +294,17 @@ struct ConvLayer : LayerBase {
           kblock(lo);
           XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_wt_lo_b), blk.size() * 2));
           XDET_HIP(hipMemcpy(d_wt_lo_b, blk.data(), blk.size() * 2, hipMemcpyHostToDevice));
+          if (kh == 1 && kw == 1 && stride == 1 && groups == 1) {   // a pointwise layer may be fed x8 planes
+            unsigned char* b8 = reinterpret_cast<unsigned char*>(blk.data());
+            for (int co = 0; co < cout_pad; ++co)
+              for (int k = 0; k < kp; ++k) {
+                unsigned char* rec = b8 + ((size_t)(k >> 5) * cout_pad + co) * 64;
+                rec[k & 31] = f32_to_e4m3(std::ldexp(f16_to_f32(lo[(size_t)co * kp + k]), 9));
+                rec[32 + (k & 31)] = f32_to_e4m3(std::ldexp(f16_to_f32(hi[(size_t)co * kp + k]), -2));
+              }
+            XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_wt_x8_b), blk.size() * 2));
+            XDET_HIP(hipMemcpy(d_wt_x8_b, blk.data(), blk.size() * 2, hipMemcpyHostToDevice));
+          }
         }
       }
     }
@@ -308,7 +339,7 @@ struct ConvLayer : LayerBase {
               hipStream_t s, const unsigned short* in_hi = nullptr, const unsigned short* in_lo = nullptr,
               const unsigned short* zeros = nullptr, unsigned short* out_hi = nullptr,
               unsigned short* out_lo = nullptr, int planes_relu = 0, const float* pl_scale = nullptr,
-              const float* pl_shift = nullptr, int group_rows = 0) const {
+              const float* pl_shift = nullptr, int group_rows = 0, int x8 = 0, int x8_exp = 0) const {
     XDET_REQUIRE(ldi == ld_in(), "conv: ld_in must be round_up(cin,32) (4 for cin<=4)");
     XDET_REQUIRE(ldo == ld_out(), "conv: ld_out must be round_up(cout,32)");
     ConvParams p;
@@ -334,6 +365,10 @@ struct ConvLayer : LayerBase {
     if (in_hi) {   // A operand already split into f16 planes by its producer: LDS-DMA kernel
       XDET_REQUIRE(!small_cin && relu_in == 0, "conv(dma): needs >= 32 input channels and no ReLU-on-load");
       p.wt_hi = d_wt_hi_b; p.wt_lo = d_wt_lo_b;   // K-blocked copies
+      if (x8) {                                   // `in_lo` holds [hi8 | lo8] records: the cross terms run on the fp8 MFMA
+        XDET_REQUIRE(d_wt_x8_b && precision == PREC_F16X3 && ksplit < 1, "conv: x8 planes need a pointwise f16x3 layer without a split-K");
+        p.wt_lo = d_wt_x8_b; p.x8 = 1; p.x8_exp = x8_exp;
+      }
       if (ksplit >= 1 && groups == 1 && conv_ksplit_supported(kh, kw, (int64_t)N * H * W, ldi, cin_p, cout_pad)) {
         p.ksplit = ksplit; p.ks_partial = d_ks_partial;
         return launch_conv_mfma_ksplit(p, cout_pad % 128 == 0 ? 128 : 64, precision == PREC_F16X3 ? 3 : 1, ks_mode, ks_tiles, s);
@@ -1730,6 +1765,23 @@ int xdet_conv_forward_planes(void* layer, const uint16_t* in_hi, const uint16_t*
   XDET_REQUIRE(in_hi && (in_lo || L->precision == PREC_F16), "conv(planes): NULL planes");
   DeviceGuard guard(L->device);
   return L->forward(nullptr, N, H, W, ld_in, out, ld_out, residual, 0, S(stream), in_hi, in_lo, L->d_zeros);
+}
+int xdet_split_f32_x8(const float* in, uint16_t* hi, uint16_t* lo8, int64_t n_pix, int ld, int relu, int x8_exp, void* stream) {
+  XDET_REQUIRE(in && hi && lo8, "split: NULL argument");
+  XDET_REQUIRE(x8_exp > -100 && x8_exp < 100, "split(x8): exponent out of range");
+  return launch_split_f32(in, hi, lo8, n_pix, ld, relu, S(stream), 1.f, 1, x8_exp);
+}
+int xdet_conv_forward_planes_x8(void* layer, const uint16_t* in_hi, const uint16_t* in_lo8, int N, int H, int W, int ld_in,
+                                float* out, int ld_out, const float* residual, int x8_exp, void* stream) {
+  LayerBase* b = static_cast<LayerBase*>(layer);
+  XDET_REQUIRE(b && b->kind == 1, "not a conv layer");
+  ConvLayer* L = static_cast<ConvLayer*>(b);
+  XDET_REQUIRE(L->dma_capable() && L->d_wt_x8_b, "conv(x8): a pointwise (1x1, stride 1) layer created in the f16x3 mode is needed");
+  XDET_REQUIRE(in_hi && in_lo8, "conv(planes): NULL planes");
+  XDET_REQUIRE(x8_exp > -100 && x8_exp < 100, "conv(x8): exponent out of range");
+  DeviceGuard guard(L->device);
+  return L->forward(nullptr, N, H, W, ld_in, out, ld_out, residual, 0, S(stream), in_hi, in_lo8, L->d_zeros, nullptr, nullptr, 0,
+                    nullptr, nullptr, 0, 1, x8_exp);
 }
 int xdet_conv_set_ksplit(void* layer, int ksplit, int mode, int max_parallel_tiles) {
   LayerBase* b = static_cast<LayerBase*>(layer);

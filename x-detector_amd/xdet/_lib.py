@@ -80,6 +80,9 @@ SIGNATURES = {
     'xdet_split_f32': (c_int, [PF, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'xdet_conv_forward_planes': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, PF, c_int, PF,
                                          c_void_p]),
+    'xdet_split_f32_x8': (c_int, [PF, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    'xdet_conv_forward_planes_x8': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, PF, c_int, PF, c_int,
+                                            c_void_p]),
     'xdet_layer_destroy': (c_int, [c_void_p]),
     'xdet_depthwise_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, PF]),
     'xdet_depthwise_forward': (c_int, [c_void_p, PF, c_int, c_int, c_int, c_int, PF, c_int, c_void_p]),

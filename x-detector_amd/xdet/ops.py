@@ -105,11 +105,13 @@ class Conv2D(object):
         mode 0 = by grid size, 1 = ranges in parallel, 2 = one workgroup per tile -- all bit-identical."""
         check(lib().xdet_conv_set_ksplit(self.handle, int(ksplit), int(mode), int(max_parallel_tiles)))
 
-    def __call__(self, x, residual=None, relu_in=False, stream=None, planes=False, staged_tile=False):
+    def __call__(self, x, residual=None, relu_in=False, stream=None, planes=False, staged_tile=False, x8_exp=None):
         """planes=True (split-precision modes only): split x into f16 hi/lo planes first and run the
         LDS-DMA kernel -- the path every big contraction takes inside a net.  staged_tile=True (with planes; 3x3 VALID
         stride 1 over 32 channels, <= 64 outputs): the kernel that stages the input tile once in LDS
-        (xdet_conv3x3_patch_forward, block1_conv2 inside a net)."""
+        (xdet_conv3x3_patch_forward, block1_conv2 inside a net).  x8_exp (with planes; 1x1 stride-1 layers): the x8 form of
+        the planes -- the cross terms of the split-precision product from fp8 copies (xdet_conv_forward_planes_x8); pass the
+        exponent e with max|x| * 2^-e in (128, 256]."""
         N, H, W, C = x.shape
         assert C == self.cin, (C, self.cin)
         ho, wo = ctypes.c_int(), ctypes.c_int()
@@ -119,6 +121,14 @@ class Conv2D(object):
             n = -(-N * H * W // 16) * 16 * x.ld
             hi, lo = DeviceBuffer(n * 2 + 512, zero=True), DeviceBuffer(n * 2 + 512, zero=True)
             st = stream.handle if stream else None
+            if x8_exp is not None:
+                # the x8 form of the planes (pointwise layers): cross terms from fp8 copies scaled by 2^-x8_exp
+                assert not staged_tile
+                check(lib().xdet_split_f32_x8(x.ptr, hi.ptr, lo.ptr, N * H * W, x.ld, 1 if relu_in else 0, int(x8_exp), st))
+                check(lib().xdet_conv_forward_planes_x8(self.handle, hi.ptr, lo.ptr, N, H, W, x.ld, out.ptr, out.ld,
+                                                        residual.ptr if residual is not None else None, int(x8_exp), st))
+                synchronize(stream)
+                return out
             check(lib().xdet_split_f32(x.ptr, hi.ptr, lo.ptr, N * H * W, x.ld, 1 if relu_in else 0, st))
             if staged_tile:
                 assert residual is None
