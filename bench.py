@@ -97,6 +97,9 @@ def parse():
                          'seconds sees the GPU busy whatever --steps is; 0 = off')
     ap.add_argument('--ksplit', default='on', choices=['on', 'off', 'all'],
                     help='fixed split-K: narrow head GEMM (on, default), nothing (off), RPN conv as well (all) -- A/B runs')
+    ap.add_argument('--cross', default='f16', choices=['f16', 'fp8'],
+                    help="cross terms of the split-precision products of the depthwise -> pointwise layers: f16 (f16x3 everywhere) "
+                         "or fp8 copies of the operands (the x8 form, after the calibration pass)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=200, help='images of the bounded CPU-baseline sample (~10-20 s)')
     ap.add_argument('--cpu-batch', type=int, default=8, help='images per call of the C++ CPU baseline')
@@ -376,7 +379,7 @@ def main():
         sb = B // ways                               # images per sub-batch / net instance
         nets = [LightHeadDetector(weights, image_size=S, max_batch=sb, rpn_post_nms_top_n=args.proposals,
                                   rpn_stream='main' if args.serial_rpn else 'side', conv3x3=args.conv3x3,
-                                  pool=args.pool, ksplit=args.ksplit)
+                                  pool=args.pool, ksplit=args.ksplit, cross=args.cross)
                 for _ in range(ways)]
         net = nets[0]
         kind = 0
@@ -384,6 +387,10 @@ def main():
         flops_img = sum(fl.values())
         imgs = W.synthetic_images(B, S, seed=100 + rank)
         for i, nt in enumerate(nets):
+            if args.cross == 'fp8':
+                # the x8 form is switched on by the calibration pass (it measures the tensors whose fp8 copies it scales):
+                # a seeded batch of the same distribution, not the timed inputs
+                nt.calibrate(W.synthetic_images(min(sb, 8), S, seed=4242))
             nt.set_images(imgs[i * sb:(i + 1) * sb])
         raw = None
         if args.voc_stream:

@@ -280,6 +280,10 @@ int xdet_net_forward(void* net, const float* images_nchw, int N, const int* imag
 int xdet_net_calibrate(void* net, const float* images_nchw, int N, int* n_scaled, void* stream);
 int xdet_net_plane_scales(void* net, int max_n, int* n_out, int* exps);
 int xdet_net_plane_scale_name(void* net, int idx, char* buf, int buflen);
+/* option "cross" = "fp8": how many split-precision tensors are in the x8 form (fp8 copies for the cross terms; see
+ * xdet_conv_forward_planes_x8) -- 0 until xdet_net_calibrate has measured them, then the 28 depthwise -> pointwise edges of
+ * the light-head net (net/xception_body.py:220-234, blocks 5-14). */
+int xdet_net_x8_planes(void* net, int* n_on);
 int xdet_net_graph_count(void* net, int* count);
 /* per-kernel accounting of the last build: total dense FLOPs (2*MAC, unpadded) of one image */
 int xdet_net_flops_per_image(void* net, double* backbone, double* rpn, double* large_sep, double* head);

@@ -518,7 +518,19 @@ struct Plan {
     float bound = 1.f;
     std::vector<std::function<int(int)>> apply;       // re-derive the device parameters that carry 2^-e / 2^e
     std::function<int(hipStream_t)> clear;            // optional: zero the padding a measurement would otherwise scan
+    // x8 form (option "cross" = "fp8"; conv_params.h): planes written by a depthwise tile kernel for ONE pointwise consumer on
+    // the LDS-DMA kernels.  Both ends are fixed at build time (x8_ok); the form is switched on by the calibration pass, which
+    // measures the tensor and chooses x8_exp so that its largest |hi| * 2^-x8_exp lands in (128, 256].
+    bool x8_cand = false, x8_ok = false, x8_on = false;
+    int x8_exp = 0;
+    float last_max = 0.f;                             // largest magnitude of the operand in the last calibration pass
   };
+  bool cross8 = false;                                // option "cross" = "f16" | "fp8"
+  bool plane_x8(int pidx, int* e) const {
+    const bool on = pidx >= 0 && pscales[pidx].x8_ok && pscales[pidx].x8_on;
+    *e = on ? pscales[pidx].x8_exp : 0;
+    return on;
+  }
   std::vector<PlaneScale> pscales;
   std::vector<const float*> f32_split_inputs;          // f32 tensors a register-split conv reads (no pre-scale exists for them)
   // check_range: what an f32 tensor may hold.  Only two kinds of f32 tensors are ever turned into f16 without a planes
@@ -591,6 +603,7 @@ struct Plan {
           m = broken ? 0.f : ldexpf(x * p.bound, -p.exp);
           if (!broken && !(m <= 3.0e38f)) broken = true;
         }
+        pscales[i].last_max = broken ? 0.f : m;
         if (verbose && (broken || m > kRangeTarget))
           fprintf(stderr, "xdet calibrate: pass %d  %-70s exp %d  max %s%g\n", pass, p.name.c_str(), p.exp,
                   broken ? "inf/NaN " : "", (double)m);
@@ -619,6 +632,16 @@ struct Plan {
       for (const PlaneScale& p : pscales) n += p.exp != 0;
       *n_scaled = n;
     }
+    for (PlaneScale& p : pscales)                    // the settled pass measured every tensor as its planes hold it
+      if (p.x8_ok) {
+        int e = 0;
+        if (p.last_max > 0.f) {
+          (void)frexpf(p.last_max / 256.f, &e);      // last_max / 256 in [2^(e-1), 2^e)
+          if (ldexpf(256.f, e - 1) == p.last_max) --e;   // exactly a power of two: (128, 256] includes its upper end
+        }
+        p.x8_exp = e;
+        p.x8_on = true;
+      }
     return XDET_OK;
   }
 
@@ -740,6 +763,17 @@ struct Plan {
       pscales[out->pidx].apply.push_back([L](int e) { return L->set_out_exp(e); });
     }
     if (in.hi && in.pidx >= 0) pscales[in.pidx].apply.push_back([L](int e) { return L->set_in_exp(e); });
+    if (in.hi && in.pidx >= 0 && pscales[in.pidx].x8_cand) {
+      // the consumer end of an x8 plane: a pointwise f16x3 layer on the buffer-load form of the LDS-DMA kernels, no split-K
+      const size_t a_bytes = ((size_t)cdiv((int64_t)max_batch * in.H * in.W, 16) * (size_t)(in.ld >> 5)) << 10;
+      const size_t b_bytes = (size_t)(L->kp / 32) * L->cout_pad * 64;
+      pscales[in.pidx].x8_ok = L->d_wt_x8_b && L->precision == PREC_F16X3 && L->ksplit < 1 && L->groups == 1 && relu_in == 0 &&
+                               L->cin_p == L->kp && a_bytes < ((size_t)1 << 32) && b_bytes < ((size_t)1 << 32);
+      pscales[in.pidx].x8_cand = false;              // (one consumer: a second reader of these planes would have to agree)
+    } else if (in.hi && in.pidx >= 0 && pscales[in.pidx].x8_ok) {
+      pscales[in.pidx].x8_ok = false;                // a second consumer: keep the f16 form
+    }
+    const int x8_pidx = in.hi ? in.pidx : -1;
     const Buf i = in, o = *out;
     const float* rp = res ? res->p : nullptr;
     const unsigned short* z = zeros;
@@ -747,9 +781,11 @@ struct Plan {
     ops.push_back({name, stage, L->flops(in.H, in.W), [=](int N, hipStream_t s) {
                      // the planes copy: relu(out * bn_scale + bn_shift) * 2^-out_exp for a folded BN, else (relu?)(out) * 2^-out_exp
                      const bool aff = folded_bn || L->out_exp != 0;
+                     int x8_exp = 0;
+                     const int x8 = plane_x8(x8_pidx, &x8_exp) ? 1 : 0;
                      return L->forward(i.p, N, i.H, i.W, i.ld, o.no_f32 ? nullptr : o.p, o.ld, rp, relu_in, s, i.hi, i.lo,
                                        z, o.hi, o.lo, (o.planes_relu || folded_bn) ? 1 : 0, aff ? L->d_pl_scale : nullptr,
-                                       aff ? L->d_pl_shift : nullptr);
+                                       aff ? L->d_pl_shift : nullptr, 0, x8, x8_exp);
                    }});
     return XDET_OK;
   }
@@ -763,10 +799,14 @@ struct Plan {
       XDET_TRY(new_planes(out));
       pscales[out->pidx].name = name;
       pscales[out->pidx].apply.push_back([L](int e) { return L->set_out_exp(e); });
+      // (the depthwise TILE kernel writes the x8 form: images below 2 GiB)
+      pscales[out->pidx].x8_cand = cross8 && (int64_t)in.H * in.W * in.ld * 4 < ((int64_t)1 << 31);
       const Buf i = in, o = *out;
       ops.push_back({name, stage, 0.0, [=](int N, hipStream_t s) {
+                       int x8_exp = 0;
+                       const int x8 = plane_x8(o.pidx, &x8_exp) ? 1 : 0;
                        return launch_depthwise3x3_split(i.p, L->d_w, o.hi, o.lo, N, i.H, i.W, i.C, i.ld, L->dil,
-                                                        relu_in, s);
+                                                        relu_in, s, x8, x8_exp);
                      }});
       return XDET_OK;
     }
@@ -1972,6 +2012,11 @@ int xdet_net_set_option(void* net, const char* key, const char* value) {
     n->rpn_ksplit = v == "all";
     return XDET_OK;
   }
+  if (k == "cross") {
+    XDET_REQUIRE(v == "f16" || v == "fp8", "cross must be f16 | fp8");
+    n->cross8 = v == "fp8";
+    return XDET_OK;
+  }
   if (k == "check_range") {
     XDET_REQUIRE(v == "on" || v == "off", "check_range must be on | off");
     n->check_range = v == "on";
@@ -2136,6 +2181,13 @@ int xdet_net_plane_scales(void* net, int max_n, int* n_out, int* exps) {
   Plan* n = plan_of(net);
   *n_out = (int)n->pscales.size();
   for (int i = 0; exps && i < max_n && i < *n_out; ++i) exps[i] = n->pscales[i].exp;
+  return XDET_OK;
+}
+int xdet_net_x8_planes(void* net, int* n_on) {
+  XDET_REQUIRE(net && n_on && (plan_of(net)->plan_kind == 0 || plan_of(net)->plan_kind == 1), "x8_planes: bad arguments");
+  int n = 0;
+  for (const auto& p : plan_of(net)->pscales) n += p.x8_ok && p.x8_on;
+  *n_on = n;
   return XDET_OK;
 }
 int xdet_net_plane_scale_name(void* net, int idx, char* buf, int buflen) {

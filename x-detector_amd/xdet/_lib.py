@@ -118,6 +118,7 @@ SIGNATURES = {
     'xdet_net_forward': (c_int, [c_void_p, PF, c_int, PI, PF, PF, PF, c_int, c_void_p]),
     'xdet_net_calibrate': (c_int, [c_void_p, PF, c_int, ctypes.POINTER(c_int), c_void_p]),
     'xdet_net_plane_scales': (c_int, [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    'xdet_net_x8_planes': (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     'xdet_net_plane_scale_name': (c_int, [c_void_p, c_int, ctypes.c_char_p, c_int]),
     'xdet_net_graph_count': (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     'xdet_net_flops_per_image': (c_int, [c_void_p] + [ctypes.POINTER(c_double)] * 4),

@@ -21,10 +21,13 @@ class LightHeadDetector(object):
     def __init__(self, weights, image_size=480, max_batch=1, num_classes=21, rpn_pre_nms_top_n=5000,
                  rpn_post_nms_top_n=1000, rpn_nms_thres=0.7, rpn_min_size=None, select_threshold=0.01,
                  nms_threshold=0.3, nms_topk=200, device=None, large_sep='auto', sepconv='fused', rpn_stream='side',
-                 conv3x3='patch', pool='split', check_range=False, ksplit=True):
+                 conv3x3='patch', pool='split', check_range=False, ksplit=True, cross='f16'):
         """check_range=True: every activation tensor is validated against the f16 range of the split-precision convs
         after each forward (|x| <= 65504, no NaN); a violation raises in detections() / forward().  For validating a
-        new checkpoint once: the pass re-reads every activation (~+30 % time)."""
+        new checkpoint once: the pass re-reads every activation (~+30 % time).
+        cross='fp8': the cross terms of the split-precision products of the depthwise -> pointwise layers (28 of the 46
+        contractions, the dominant ones) are computed from fp8 copies of the operands (the "x8" form, include/xdet.h) -- once
+        calibrate() has measured the tensors; until then, and with 'f16', everything is f16x3."""
         if device is not None:
             check(lib().xdet_set_device(int(device)))
         self.cfg = LightHeadConfig(image_size=image_size, max_batch=max_batch, num_classes=num_classes,
@@ -46,6 +49,7 @@ class LightHeadDetector(object):
         check(lib().xdet_net_set_option(self.handle, b'pool', pool.encode()))
         check(lib().xdet_net_set_option(self.handle, b'check_range', b'on' if check_range else b'off'))
         check(lib().xdet_net_set_option(self.handle, b'ksplit', ksplit.encode() if isinstance(ksplit, str) else (b'on' if ksplit else b'off')))
+        check(lib().xdet_net_set_option(self.handle, b'cross', cross.encode()))
         check(lib().xdet_net_build(self.handle))
         self.max_batch = max_batch
         self.image_size = image_size
@@ -124,6 +128,12 @@ class LightHeadDetector(object):
         k = ctypes.c_int()
         check(lib().xdet_net_calibrate(self.handle, self._images.ptr, n, ctypes.byref(k), self.stream.handle))
         return {name: e for name, e in self.plane_scales().items() if e}
+
+    def x8_planes(self):
+        """tensors in the x8 form (cross='fp8', after calibrate()): xdet_net_x8_planes"""
+        n = ctypes.c_int()
+        check(lib().xdet_net_x8_planes(self.handle, ctypes.byref(n)))
+        return n.value
 
     def plane_scales(self):
         cnt = ctypes.c_int()
