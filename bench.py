@@ -609,6 +609,7 @@ def main():
                        if args.workload == 'lighthead' else 'ResNet-50 v2 trunk only (BASELINE config 2), 480x480',
                        'batch_per_gpu': B, 'global_batch': B * world, 'image_size': S,
                        'concurrent_sub_batches': ways,
+                       'cross_terms': args.cross if args.workload == 'lighthead' else 'f16',
                        'input': ('uint8 VOC-shape stream + F1 pre-processing kernel in the step' if args.voc_stream
                                  else 'whitened f32 [B,3,%d,%d] resident in HBM' % (S, S)),
                        'parallelism': 'image-sharded dp%d%s' % (world, ', RCCL all-gather of detections per step '
