@@ -637,8 +637,9 @@ def bboxes_eval(cls_logits, boxes, image_shape=(480, 480), bbox_img=(0., 0., 1.,
         b = bboxes_clip(bbox_img, b)                                    # bboxes_clip
         keep = _center_filter_mask(b, min_size)                         # filter_boxes (dict branch -> keep_top_k=100)
         s, b = _pad_rows(s[keep], 100), _pad_rows(b[keep], 100)
-        v = np.array([bbox_img[0], bbox_img[1], bbox_img[0], bbox_img[1]], F32)   # bboxes_resize :423-447
-        sc = np.array([bbox_img[2] - bbox_img[0], bbox_img[3] - bbox_img[1]] * 2, F32)
+        ref = np.asarray(bbox_img, F32)     # a float32 tensor in the reference: the extent below is a float32 difference
+        v = np.array([ref[0], ref[1], ref[0], ref[1]], F32)                        # bboxes_resize :423-447
+        sc = np.array([ref[2] - ref[0], ref[3] - ref[1]] * 2, F32)                 # (found by tests/test_oracle_discrete.py)
         b = ((b - v) / sc).astype(F32)
         k = min(s.shape[0], nms_topk * 2)                               # bboxes_sort dict branch :348-355
         s, idx = top_k(s, k)

@@ -65,6 +65,33 @@ def test_proposals_and_head(run):
         assert np.abs(det.flat('head_boxes', (n, 300, 4)) - tr['head_boxes']).max() < TOL
 
 
+def test_predictions_dict(run, oracle):
+    """`predictions` of the EstimatorSpec (light_head_rfcn_eval.py:409-433): classes = argmax and probabilities = max
+    of the softmax'd head scores, bboxes_predict = the decoded head boxes, per ROI -- against the oracle's `cls` /
+    `head_boxes`, ROI by ROI (paired through the proposal boxes)."""
+    det, got, ref, tr, _ = run
+    n = 2
+    pred = det.predictions(n)
+    assert pred['classes'].shape == (n, 300) and pred['probabilities'].shape == (n, 300)
+    assert pred['bboxes_predict'].shape == (n, 300, 4)
+    props = det.flat('proposals', (n, 300, 4))
+    prob = oracle.softmax(tr['cls'].reshape(-1, 21)).reshape(n, 300, 21)
+    for i in range(n):
+        # two proposals whose scores tie within float noise may swap places: pair every GPU ROI with the oracle ROI that
+        # has the same box (duplicates of the upsample tail carry identical results, any of them will do)
+        d = np.abs(props[i][:, None, :] - tr['proposals'][i][None, :, :]).max(-1)
+        j = d.argmin(1)
+        assert d[np.arange(300), j].max() < 1e-5
+        assert np.abs(pred['probabilities'][i] - prob[i, j].max(-1)).max() < TOL
+        assert np.abs(pred['bboxes_predict'][i] - tr['head_boxes'][i, j]).max() < TOL
+        # the arg-max may differ only where the two best classes of a ROI tie within the tolerance
+        diff = pred['classes'][i] != prob[i, j].argmax(-1)
+        if diff.any():
+            top2 = np.sort(prob[i, j], -1)[..., -2:]
+            assert np.all((top2[..., 1] - top2[..., 0])[diff] < TOL), 'arg-max class differs without a tie'
+    assert (pred['classes'] > 0).sum() > 0     # some ROI is not background
+
+
 def match_detections(got, ref, tol=TOL):
     """set matching per class: every oracle detection needs a distinct GPU detection whose score
     and box agree within tol (two detections whose scores differ by float noise may legitimately
@@ -94,7 +121,13 @@ def iou(a, b):
     return ih * iw / ua if ua > 0 else 0.0
 
 
-def assert_match_or_score_tie(got, ref, nms_thr=0.3, tol=TOL, tie=2e-5):
+# The matcher below is FROZEN (round 5): it knows two causes of a differing class list, both discrete decisions of the
+# greedy per-class NMS that float noise can flip, and no third one is to be added -- a new kind of difference is a bug
+# in the kernel that produced it.
+THRESHOLD_TIE_BAND = 5e-4   # |IoU - nms_thr| of an admissible threshold tie (the seed-777 pair: 0.3000 +- 0.0003, tools/diag_nms_tie.py)
+
+
+def assert_match_or_score_tie(got, ref, nms_thr=0.3, tol=TOL, tie=2e-5, allow_threshold_tie=False, stats=None):
     """Every oracle detection must be matched by a distinct GPU detection within `tol` and vice versa -- EXCEPT in a
     class list where the greedy per-class NMS met a score tie: two overlapping candidates (IoU > nms_thr) whose scores
     differ by less than the float noise of the scores (`tie`; the feature maps agree to ~1e-5) may be visited in
@@ -124,19 +157,24 @@ def assert_match_or_score_tie(got, ref, nms_thr=0.3, tol=TOL, tie=2e-5):
             continue
         seeds = [(j, k) for j in un for k in ex if abs(float(rs[j]) - float(gs[k])) < tie and iou(rb[j], gb[k]) > nms_thr]
         if not seeds:
-            # the other discrete decision of the greedy NMS: a candidate whose IoU with a higher-scoring KEPT box is at the
-            # threshold is suppressed on one side and kept on the other.  The kept box itself is only pinned to the parity
-            # tolerance (two near-duplicate ROIs whose scores tie may stand in for each other: boxes 1e-3 apart move an IoU by
-            # ~2e-3), hence the slack.  Accepted only if such a suppressor is actually found on the OTHER side for every
-            # differing detection, for at most two detections of the class, and (callers) at most one class list per test.
-            def suppressible(score, box, kept_s, kept_b, slack=2e-3):
-                return any(float(ks) > score - tie and iou(box, kb) > nms_thr - slack for ks, kb in zip(kept_s, kept_b))
+            # the other discrete decision of the greedy NMS: a candidate whose IoU with a higher-scoring KEPT box is AT the
+            # threshold is suppressed on one side and kept on the other.  Off unless the caller asks for it (only the run
+            # whose head GEMM sums in split-K order does: test_second_weight_set); accepted only if, for every differing
+            # detection, the other side keeps a higher-scoring box whose IoU with it lies within THRESHOLD_TIE_BAND of the
+            # threshold, and for at most two detections of the class.
+            assert allow_threshold_tie, ('class %d: %d oracle-only / %d gpu-only detections and no score tie explains them'
+                                         % (c, len(un), len(ex)))
+
+            def at_threshold(score, box, kept_s, kept_b):
+                return any(float(ks) > score - tie and abs(iou(box, kb) - nms_thr) <= THRESHOLD_TIE_BAND for ks, kb in zip(kept_s, kept_b))
             assert len(un) + len(ex) <= 2, (c, len(un), len(ex))
             for j in un:
-                assert suppressible(float(rs[j]), rb[j], gs[:kg], gb[:kg]), ('class %d: oracle-only detection, no NMS threshold tie' % c, float(rs[j]), rb[j].tolist())
+                assert at_threshold(float(rs[j]), rb[j], gs[:kg], gb[:kg]), ('class %d: oracle-only detection, no NMS threshold tie' % c, float(rs[j]), rb[j].tolist())
             for k in ex:
-                assert suppressible(float(gs[k]), gb[k], rs[:kr], rb[:kr]), ('class %d: gpu-only detection, no NMS threshold tie' % c, float(gs[k]), gb[k].tolist())
+                assert at_threshold(float(gs[k]), gb[k], rs[:kr], rb[:kr]), ('class %d: gpu-only detection, no NMS threshold tie' % c, float(gs[k]), gb[k].tolist())
             ties += 1
+            if stats is not None:
+                stats.setdefault('threshold_ties', []).append(c)
             continue
         assert len(un) + len(ex) <= 8, (c, len(un), len(ex))
         for j in un:
@@ -144,6 +182,8 @@ def assert_match_or_score_tie(got, ref, nms_thr=0.3, tol=TOL, tie=2e-5):
         for k in ex:
             assert any(iou(gb[k], rb[j]) > nms_thr for j in un), (c, 'gpu-only detection not explained', float(gs[k]))
         ties += 1
+        if stats is not None:
+            stats.setdefault('score_ties', []).append(c)
     return total, matched, ties
 
 
@@ -278,8 +318,8 @@ def test_net_misuse_is_reported_not_executed(lh_weights):
     assert len(got) == 1 and len(got[0]) == 20
 
 
-@pytest.mark.parametrize('lsep', ['direct', 'spectral'])
-def test_second_weight_set(lsep, oracle):
+@pytest.mark.parametrize('lsep,ksplit', [('direct', 'off'), ('spectral', 'off'), ('direct', 'on'), ('spectral', 'on')])
+def test_second_weight_set(lsep, ksplit, oracle):
     """The 1e-3 claim on an independent synthetic model: other seed (777, its own BN calibration), other gains on the
     score layers than the committed recipe (SYNTH_GAINS), other images -- so that the claim does not rest on one
     hand-picked score spread.  Feature maps within 1e-4 of their scale, proposals equal as sets, detections matched
@@ -293,7 +333,7 @@ def test_second_weight_set(lsep, oracle):
     imgs = W.synthetic_images(2, 480, seed=555)
     set_precision('f16x3')
     try:
-        det = LightHeadDetector(w, image_size=480, max_batch=2, rpn_post_nms_top_n=300, large_sep=lsep)
+        det = LightHeadDetector(w, image_size=480, max_batch=2, rpn_post_nms_top_n=300, large_sep=lsep, ksplit=ksplit)
     finally:
         set_precision('f32')
     got = det.forward(imgs)
@@ -306,14 +346,20 @@ def test_second_weight_set(lsep, oracle):
         b = tr['proposals'][i][np.lexsort(tr['proposals'][i].T)]
         assert np.abs(a - b).max() < TOL
     total = matched = ties = 0
+    stats = {}
     for i in range(2):
-        t, m, k = assert_match_or_score_tie(got[i], ref[i])
+        # ksplit='off' (the head GEMM sums K in one left-to-right pass, as the oracle's reference order does): the strict
+        # round-3 gate -- a differing list needs a found score-tie pair, at most one list.  ksplit='on' (default; the
+        # narrow head GEMM sums four K ranges and folds them): ONE pair of boxes of image 0 whose IoU is 0.3000 +- 0.0003
+        # (tools/diag_nms_tie.py prints it) falls on the other side of the per-class NMS threshold in the two classes
+        # where both boxes pass the score threshold: two lists, one cause, admitted by the exact-pair rule only.
+        t, m, k = assert_match_or_score_tie(got[i], ref[i], allow_threshold_tie=(ksplit == 'on'), stats=stats)
         total, matched, ties = total + t, matched + m, ties + k
-    print('seed 777 [%s]: oracle detections %d matched %d, lists explained by a score tie %d' % (lsep, total, matched, ties))
-    # (round 4: the split-K summation order of the RPN conv / head GEMM moved the float noise: ONE pair of boxes of image 0
-    #  whose IoU is 0.3000 +- 0.0003 -- tools/diag_nms_tie.py prints it -- now falls on the other side of the per-class NMS
-    #  threshold in the two classes where both boxes pass the score threshold: two lists, one cause)
-    assert total > 500 and ties <= 2
+    print('seed 777 [%s, ksplit %s]: oracle detections %d matched %d, lists explained by a score tie %s, by a threshold tie %s'
+          % (lsep, ksplit, total, matched, stats.get('score_ties', []), stats.get('threshold_ties', [])))
+    assert total > 500
+    assert len(stats.get('score_ties', [])) <= 1
+    assert len(stats.get('threshold_ties', [])) <= (2 if ksplit == 'on' else 0)
 
 
 def test_cross_fp8_is_opt_in_bounded_and_batch_invariant(oracle, lh_weights):

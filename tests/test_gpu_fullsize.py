@@ -150,13 +150,14 @@ def test_more_images_against_the_oracle(oracle, lh_weights, lsep):
     got = det.forward(imgs, use_graph=True)
     ref = oracle.lighthead_forward(imgs, lh_weights, rpn_post_nms_top_n=300)
     total = matched = ties = 0
+    stats = {}
     for i in range(6):
-        t, m, k = assert_match_or_score_tie(got[i], ref[i])
+        t, m, k = assert_match_or_score_tie(got[i], ref[i], stats=stats)       # score ties only (threshold ties: not admitted)
         total, matched, ties = total + t, matched + m, ties + k
-    print('6 images, seed 20260928 [%s]: oracle %d matched %d, class lists explained by an NMS score tie: %d'
-          % (lsep, total, matched, ties))
+    print('6 images, seed 20260928 [%s]: oracle %d matched %d, class lists explained by an NMS score tie: %s'
+          % (lsep, total, matched, stats.get('score_ties', [])))
     assert total > 1000
-    assert ties <= 2 and matched >= total - 4 * ties, (matched, total, ties)
+    assert ties <= 1 and matched >= total - 4 * ties, (matched, total, ties)
 
 
 @pytest.mark.parametrize('nb', [1, 3, 8, 17, 32])
@@ -246,3 +247,100 @@ def test_the_configuration_the_driver_benches(oracle, lh_weights):
           % (total, matched, extra))
     assert total > 50 and matched == total and extra == 0, (total, matched, extra)
     comm.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5's shape (800 x 800 -> 50 x 50 map, 55,000 anchors) at a bench-like batch, through the same
+# size-independent properties (the 1e-3 comparison with the oracle at this shape is tests/test_gpu_e2e.py::
+# test_other_baseline_configs, one image; here the batch is what is under test)
+# ---------------------------------------------------------------------------------------------------------------------
+B8 = 32
+
+
+@pytest.fixture(scope='module')
+def big800(lh_weights):
+    from xdet import weights as W
+    from xdet.model import LightHeadDetector
+    from xdet.runtime import set_precision
+    imgs = W.synthetic_images(B8, 800, seed=800800)
+    set_precision('f16x3')
+    try:
+        det = LightHeadDetector(lh_weights, image_size=800, max_batch=B8, rpn_post_nms_top_n=300)
+    finally:
+        set_precision('f32')
+    det.set_images(imgs)
+    det.forward_device(B8, use_graph=True)
+    s, b = det.detections(B8)
+    return det, imgs, s.copy(), b.copy()
+
+
+def test_800_output_invariants(big800):
+    _, _, s, b = big800
+    assert s.shape == (B8, 20, 200) and b.shape == (B8, 20, 200, 4)
+    assert np.isfinite(s).all() and np.isfinite(b).all()
+    k = (s > 0).sum(-1)
+    assert k.sum() > 1000, int(k.sum())
+    worst = 0.0
+    for i in range(B8):
+        for c in range(20):
+            n = int(k[i, c])
+            assert np.all(s[i, c, n:] == 0) and np.all(b[i, c, n:] == 0)
+            if n == 0:
+                continue
+            sc, bx = s[i, c, :n], b[i, c, :n]
+            assert np.all(sc > 0.01) and np.all(sc <= 1.0)
+            assert np.all(np.diff(sc) <= 0)
+            assert bx.min() >= 0.0 and bx.max() <= 1.0
+            assert np.all(bx[:, 2] >= bx[:, 0]) and np.all(bx[:, 3] >= bx[:, 1])
+            if n > 1:
+                m = iou_matrix(bx.astype(np.float64))
+                np.fill_diagonal(m, 0)
+                worst = max(worst, float(m.max()))
+    assert worst <= 0.3 + 1e-6, worst
+
+
+def test_800_replay_eager_and_batch_invariance(big800, lh_weights):
+    """graph replay == eager; an image's detections do not depend on the batch it arrives in (32 -> 1 and 5), its
+    position, or the tile shapes / launch splits the batch size selects (the 397^2 x 128 tensor of 32 images is cut into
+    image ranges below 2 GiB by two kernels) -- bit for bit"""
+    from xdet.model import LightHeadDetector
+    from xdet.runtime import set_precision
+    det, imgs, s, b = big800
+    det.forward_device(B8, use_graph=True)
+    s2, b2 = det.detections(B8)
+    det.forward_device(B8, use_graph=False)
+    s3, b3 = det.detections(B8)
+    assert np.array_equal(s, s2) and np.array_equal(b, b2)
+    assert np.array_equal(s, s3) and np.array_equal(b, b3)
+    set_precision('f16x3')
+    try:
+        # the arithmetic form of the large-separable convs is a property of the net: the same form as the big one
+        small = LightHeadDetector(lh_weights, image_size=800, max_batch=5, rpn_post_nms_top_n=300, large_sep='spectral')
+    finally:
+        set_precision('f32')
+    for pos in (0, 13, B8 - 1):
+        got = small.forward(imgs[pos:pos + 1])
+        for c in range(20):
+            assert np.array_equal(got[0][c + 1][0], s[pos, c]), (pos, c)
+            assert np.array_equal(got[0][c + 1][1], b[pos, c]), (pos, c)
+    got = small.forward(imgs[20:25])
+    for i in range(5):
+        for c in range(20):
+            assert np.array_equal(got[i][c + 1][0], s[20 + i, c]) and np.array_equal(got[i][c + 1][1], b[20 + i, c])
+    perm = np.roll(np.arange(B8), 3)
+    det.set_images(imgs[perm])
+    det.forward_device(B8, use_graph=True)
+    s4, b4 = det.detections(B8)
+    assert np.array_equal(s4, s[perm]) and np.array_equal(b4, b[perm])
+    det.set_images(imgs)
+
+
+def test_800_sampled_image_against_the_oracle(big800, oracle, lh_weights):
+    """one image of the 800 x 800 batch through the CPU oracle: every detection within 1e-3"""
+    _, imgs, s, b = big800
+    pos = 13
+    ref = oracle.lighthead_forward(imgs[pos:pos + 1], lh_weights, rpn_post_nms_top_n=300)
+    got = {c + 1: (s[pos, c], b[pos, c]) for c in range(20)}
+    total, matched, ties = assert_match_or_score_tie(got, ref[0])
+    print('800 x 800 batch of %d, image %d: oracle %d matched %d (lists explained by a score tie: %d)' % (B8, pos, total, matched, ties))
+    assert total > 20 and ties <= 1

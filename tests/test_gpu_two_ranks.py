@@ -75,44 +75,53 @@ def _env(fake):
     return env
 
 
-def test_two_ranks_gather_their_shards_in_rank_major_order(fake_rccl, tmp_path):
+# world 8 = the node the SCALE run uses: eight oversubscribed ranks on the box's one GPU ("make N = 8
+# boring before hardware shows up") -- id-file rendezvous with eight ranks, rank-major gather order, the launcher's
+# NUMA / visibility handling when local_rank exceeds what the box has
+WORLDS = [2, 8]
+
+
+@pytest.mark.parametrize('world', WORLDS)
+def test_ranks_gather_their_shards_in_rank_major_order(fake_rccl, tmp_path, world):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER % {'pkg': os.path.join(ROOT, 'x-detector_amd'), 'out': str(tmp_path)})
     code = ('import sys; sys.path.insert(0, %r); from xdet.launch import launch_ranks; '
-            'sys.exit(launch_ranks([sys.executable, %r], 2, timeout=600))' % (os.path.join(ROOT, 'x-detector_amd'), str(script)))
+            'sys.exit(launch_ranks([sys.executable, %r], %d, timeout=900))' % (os.path.join(ROOT, 'x-detector_amd'), str(script), world))
     p = subprocess.run([sys.executable, '-c', code], env=_env(fake_rccl), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       timeout=900)
+                       timeout=1200)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
-    res = [json.load(open(tmp_path / ('rank_%d.json' % r))) for r in range(2)]
+    res = [json.load(open(tmp_path / ('rank_%d.json' % r))) for r in range(world)]
     for r in res:
         assert r['ok'], r                                    # every rank holds the whole global batch, in global order
-        assert r['max'] == 2.5                               # max over ranks
-        assert r['ranks'] == [0, 1] and r['blobs'] == [[0], [1]]
-        assert r['rates'] == [100.0, 101.0]
-        assert r['pci'][0] == r['pci'][1] and r['pids'][0] != r['pids'][1]      # two processes, one physical GPU
+        assert r['max'] == 1.5 + world - 1                   # max over ranks
+        assert r['ranks'] == list(range(world)) and r['blobs'] == [[k] for k in range(world)]
+        assert r['rates'] == [100.0 + k for k in range(world)]
+        assert len(set(r['pci'])) == 1 and len(set(r['pids'])) == world         # `world` processes, one physical GPU
         assert r['n_det'] > 100
 
 
-def test_bench_with_two_ranks(fake_rccl):
-    """`python bench.py --gpus 2`: the script spawns its two ranks itself; rank 0 prints ONE JSON line whose value is the
-    images of BOTH ranks over the max-over-ranks time."""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-                        '--batch', '16', '--no-cpu-baseline', '--no-parity', '--no-roofline'], env=_env(fake_rccl),
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+@pytest.mark.parametrize('world,batch', [(2, 16), (8, 4)])
+def test_bench_with_ranks(fake_rccl, world, batch):
+    """`python bench.py --gpus N`: the script spawns its ranks itself; rank 0 prints ONE JSON line whose value is the
+    images of ALL ranks over the max-over-ranks time."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps', '3', '--warmup', '1',
+                        '--batch', str(batch), '--no-cpu-baseline', '--no-parity', '--no-roofline'], env=_env(fake_rccl),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 32 and d['scaling'] == 'weak'
+    G = world * batch
+    assert d['n_gpus'] == world and d['config']['global_batch'] == G and d['scaling'] == 'weak'
     c = d['comm']
-    assert c['world'] == 2 and c['ranks_seen'] == [0, 1] and c['distinct_gpus'] == 1      # honest: one physical GPU here
-    assert c['gathered_shape'] == [32, 20, 200, 5] and c['gathered_images_with_detections'] == 32
-    assert len(c['per_rank_images_per_sec']) == 2 and min(c['per_rank_images_per_sec']) > 0
+    assert c['world'] == world and c['ranks_seen'] == list(range(world)) and c['distinct_gpus'] == 1   # honest: one physical GPU here
+    assert c['gathered_shape'] == [G, 20, 200, 5] and c['gathered_images_with_detections'] == G
+    assert len(c['per_rank_images_per_sec']) == world and min(c['per_rank_images_per_sec']) > 0
     assert c['library_overridden'] is True and 'fake_rccl' in c['library']     # the line says what carried the collectives
-    assert 0.3 < c['weak_scaling_efficiency_vs_rank_median'] <= 1.001
+    assert 0.1 < c['weak_scaling_efficiency_vs_rank_median'] <= 1.001
     # value = all ranks' images / the slowest rank's time: never above the sum of the per-rank rates
     assert d['value'] <= sum(c['per_rank_images_per_sec']) * 1.001
-    assert abs(d['value'] - 2 * 16 * 3 / (d['ms_per_step'] * 3e-3)) < 1e-2 * d['value']
+    assert abs(d['value'] - G * 3 / (d['ms_per_step'] * 3e-3)) < 1e-2 * d['value']
 
 
 def test_a_dead_peer_is_a_timeout_not_a_hang(fake_rccl, tmp_path):
@@ -209,22 +218,24 @@ def test_a_stand_in_for_rccl_must_be_asked_for_twice(fake_rccl):
     assert p.returncode == 9 and b'XDET_ALLOW_RCCL_OVERRIDE' in p.stdout, (p.returncode, p.stdout, p.stderr[-2000:])
 
 
-def test_dry_run_with_two_ranks(fake_rccl):
+@pytest.mark.parametrize('world', WORLDS)
+def test_dry_run_with_ranks(fake_rccl, world):
     """`bench.py --gpus N --dry-run`: rendezvous + one all-gather of the device records + exit, in seconds -- what an
     8-GPU node is asked first, before the long run."""
     t0 = time.time()
-    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], env=_env(fake_rccl),
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--dry-run'], env=_env(fake_rccl),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.strip().startswith('{')]
     assert len(lines) == 1, p.stdout.decode()[-2000:]
     d = json.loads(lines[0])
-    assert d['dry_run'] is True and d['n_gpus'] == 2 and d['comm']['ranks_seen'] == [0, 1]
+    assert d['dry_run'] is True and d['n_gpus'] == world and d['comm']['ranks_seen'] == list(range(world))
     assert d['comm']['distinct_gpus'] == 1 and d['comm']['library_overridden'] is True
     assert 'fake_rccl' in d['comm']['library'] and time.time() - t0 < 300
 
 
-def test_bench_under_torch_distributed_run(fake_rccl):
+@pytest.mark.parametrize('world,batch', [(2, 16), (8, 4)])
+def test_bench_under_torch_distributed_run(fake_rccl, world, batch):
     """the driver's SCALE command line, verbatim, at N = 2: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- torch only launches; every rank is
     bench.py, which imports no torch and finds its peers through the id file named after MASTER_PORT + the agent's pid."""
@@ -234,13 +245,13 @@ def test_bench_under_torch_distributed_run(fake_rccl):
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-                        '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3',
-                        '--warmup', '1', '--batch', '16', '--no-cpu-baseline', '--no-parity', '--no-roofline'],
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps', '3',
+                        '--warmup', '1', '--batch', str(batch), '--no-cpu-baseline', '--no-parity', '--no-roofline'],
                        env=_env(fake_rccl), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.strip().startswith('{')]
     assert len(lines) == 1, p.stdout.decode()[-2000:]
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['comm']['world'] == 2 and d['comm']['ranks_seen'] == [0, 1]
-    assert d['comm']['gathered_shape'] == [32, 20, 200, 5] and d['value'] > 0
+    assert d['n_gpus'] == world and d['comm']['world'] == world and d['comm']['ranks_seen'] == list(range(world))
+    assert d['comm']['gathered_shape'] == [world * batch, 20, 200, 5] and d['value'] > 0

@@ -1088,8 +1088,11 @@ struct LightHeadNet : Plan {
     for (const Blk& b : blks) {
       XDET_TRY(conv_bn(b.res, b.bn, eps, ST_BODY, x, 1, b.c, 2, 1, 0, nullptr, 0, &r));
       Buf a, p;
-      XDET_TRY(sep_bn(b.s1, eps, ST_BODY, x, b.c, b.first_relu, 1, 0, nullptr, &a));
-      XDET_TRY(sep_bn(b.s2, eps, ST_BODY, a, b.c, 1, 1, 0, nullptr, &p, &r));
+      // relu -> sepconv2 (net/xception_body.py:271-277) is the ONLY consumer of sepconv1's BN output: the ReLU is taken
+      // in sepconv1's epilogue (one v_max per element on its way out) instead of on sepconv2's 3 x 3 window reads (72 of
+      // the stencil's 192 VALU instructions per chunk when the block runs as the fused kernel) -- the same values
+      XDET_TRY(sep_bn(b.s1, eps, ST_BODY, x, b.c, b.first_relu, 1, /*relu_out=*/1, nullptr, &a));
+      XDET_TRY(sep_bn(b.s2, eps, ST_BODY, a, b.c, /*pre_relu=*/0, 1, 0, nullptr, &p, &r));
       x = p;
     }
     for (int blk = 5; blk <= 12; ++blk) {

@@ -21,7 +21,21 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Bottleneck probes for tools/ubench/sepconv_probe.hip ONLY (the product is compiled with level 0 = everything on):
+//   1 = patch DMA + barriers only, 2 = + stencil / A tile, 3 = + MFMAs (no epilogue stores), 4 = everything but the DMA
+#ifndef SF_PROBE_LEVEL
+#define SF_PROBE_LEVEL 0
+#endif
+#ifndef SF_NSLOT
+#define SF_NSLOT 3
+#endif
+
 namespace xdet {
+
+constexpr bool SF_DO_DMA = SF_PROBE_LEVEL != 4;
+constexpr bool SF_DO_STENCIL = SF_PROBE_LEVEL != 1;
+constexpr bool SF_DO_MFMA = SF_PROBE_LEVEL == 0 || SF_PROBE_LEVEL >= 3;
+constexpr bool SF_DO_STORE = SF_PROBE_LEVEL == 0 || SF_PROBE_LEVEL == 4;
 
 typedef float sf_f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 sf_f16x8 __attribute__((ext_vector_type(8)));
@@ -468,6 +482,367 @@ __global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Producer / consumer form (round 5).  The kernel above runs DMA wait -> stencil -> split -> A tile -> barrier -> MFMA
+// back to back on the same four waves; two workgroups per CU were meant to cover each other's phases and measured
+// 5,500 clocks per 32-channel chunk and CU against ~2,100 of VALU issue and 1,536 of MFMA issue (the 119^2 layers:
+// 2.2-3.2 TB/s with the matrix pipe 24-35 % busy -- bound by neither).  Here the phases are different WAVES of one
+// 512-thread workgroup, one of each on every SIMD:
+//   waves 0-3 (producers): patch DMA three steps deep, 3x3 stencil, hi/lo split, A tile of step s into s_a[s & 1]
+//   waves 4-7 (consumers): the MFMAs of step s-1 out of s_a[(s-1) & 1] against weights that were requested one
+//                          half-step earlier, and the tile's epilogue (folded BN / ReLU / h-pool) after its last chunk
+// with ONE s_barrier per step (a step = one 32-channel chunk of one tile): a SIMD's VALU (producer) and its matrix
+// pipe (consumer) work on adjacent steps at the same time.  Step order, FMA order, product order and K order are those
+// of the kernel above: bit-identical (tests/test_gpu_layers.py runs both forms against the two-kernel path).
+template <bool SPLIT3, bool RELU_IN, bool HPOOL, int WAVES_N>
+__global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
+  constexpr int TM = WAVES_N;
+  constexpr int BN = 64 * WAVES_N;
+  constexpr int NSLOT = SF_NSLOT;
+  __shared__ __attribute__((aligned(16))) float s_patch[NSLOT][SF_PATCH_F];
+  __shared__ __attribute__((aligned(16))) u16 s_a[2][2 * 128 * 32];     // two A tiles (hi rows, then lo rows: 16 KB each)
+  __shared__ __attribute__((aligned(16))) float s_w[9 * SF_KMAX];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // tile schedule: the XCD bands of the kernel above, one workgroup per CU
+  const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, G = gridDim.x >> 3;
+  const int per_xcd = (p.ntiles + 7) >> 3;
+  const int t_begin = xcd * per_xcd + wg;
+  const int t_end = min(p.ntiles, (xcd + 1) * per_xcd);
+  if (t_begin >= t_end) return;
+  const int KC = p.ld >> 5;
+  const int my_tiles = (t_end - t_begin + G - 1) / G;
+  const int total = my_tiles * KC;                 // steps of this workgroup
+
+  for (int i = tid; i < 9 * p.ld; i += 512) {
+    const int t = i / p.ld;
+    s_w[t * SF_KMAX + (i - t * p.ld)] = p.w9c[i];
+  }
+
+  struct Coord { int nt, ty, tx, n; };
+  auto decode = [&](int q) {
+    Coord c;
+    c.nt = q % p.NT; q /= p.NT;
+    c.ty = q % p.TY; q /= p.TY;
+    c.tx = q % p.TX;
+    c.n = q / p.TX;
+    return c;
+  };
+
+  if (wave < 4) {
+    // =================================================== producers ===================================================
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.ld * 4), 0x00020000);
+    const int px8 = lane >> 3;
+    const int lane_off = (px8 * p.ld + (lane & 7) * 4) * 4;                            // bytes
+    // The byte offsets of this wave's six pieces (chunk 0) are computed once per TILE (a lane that must read padding
+    // gets an out-of-range offset: zero fill); a step's request is then six `s_mov m0` + `buffer_load ... lds` with
+    // the chunk's 128 bytes in the scalar offset -- a single wave issues one instruction every ~4-5 clocks, and the
+    // per-step address arithmetic (~140 SALU) used to be a third of the producer's step.
+    unsigned pvoff[SF_NJ];
+    auto tile_offsets = [&](const Coord& c, bool live) {
+      const int y0 = c.ty * SF_R, x0 = HPOOL ? c.tx * SF_XP - p.pool_pad_l : c.tx * SF_X;
+      const int tile_base = (((c.n * p.H + y0) * p.W + x0) * p.ld) * 4;                 // bytes, < 2^31 (host check)
+#pragma unroll
+      for (int jj = 0; jj < SF_NJ; ++jj) {
+        const int i = wave + 4 * jj;
+        const int rr = i >> 2, seg = i & 3;                                            // wave-uniform
+        const bool rok = live && (unsigned)(y0 + rr - 1) < (unsigned)p.H;
+        const bool ok = rok && (unsigned)(x0 + seg * 8 - 1 + px8) < (unsigned)p.W;
+        const int soff = tile_base + ((rr - 1) * p.W + seg * 8 - 1) * p.ld * 4;
+        pvoff[jj] = ok ? (unsigned)(soff + lane_off) : 0xffffffffu;
+      }
+    };
+    auto issue = [&](int chunk, int slot) {
+#pragma unroll
+      for (int jj = 0; jj < SF_NJ; ++jj) {
+        const int i = wave + 4 * jj;
+        const int rr = i >> 2, seg = i & 3;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrc, (__attribute__((address_space(3))) void*)(&s_patch[slot][rr * SF_ROW_F + seg * SF_PIECE_F]), 16, pvoff[jj],
+            chunk * 128, 0, 0);
+      }
+    };
+    // cursor of the NEXT patch to request (NSLOT - 1 steps ahead of the stencil)
+    int it = t_begin, ichunk = 0, islot = 0;
+    tile_offsets(decode(it), SF_DO_DMA);
+    auto issue_next = [&]() {
+      issue(ichunk, islot);
+      islot = islot == NSLOT - 1 ? 0 : islot + 1;
+      if (++ichunk == KC) {
+        ichunk = 0;
+        it += G;
+        tile_offsets(decode(min(it, p.ntiles - 1)), it < t_end && SF_DO_DMA);
+      }
+    };
+#pragma unroll
+    for (int k = 0; k < NSLOT - 1; ++k) issue_next();
+
+    const int c4 = lane & 7, strip = lane >> 3;     // wave = tile row, 4 pixels x 4 channels per lane
+    const int pxb = strip * 4;
+    // A tile layout of this kernel: the 32 rows of a tile row sit at slot (r & 16) | ((r & 3) << 2) | ((r >> 2) & 3) -- the
+    // four strips a ds_write_b64 half-wave holds (rows 4 apart) land in four CONSECUTIVE 64-byte slots, all 64 banks
+    // once (rows in pixel order put them 256 B apart: 4-way conflicts, a quarter of the step's LDS cycles) -- and the
+    // 16-byte chunks of a row are permuted by (r & 3), which keeps the fragment reads (16 lanes = 16 consecutive rows)
+    // conflict-free as well.  Row k of a strip: + 256 k bytes, chunk ((c4 >> 1) ^ k).
+    unsigned wa_k[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      wa_k[k] = sf_lds_addr(&s_a[0][0]) +
+                (unsigned)((wave * 32 + (strip & 4) * 4 + k * 4 + (strip & 3)) * 32 + (((c4 >> 1) ^ k) << 3) + (c4 & 1) * 4) * 2u;
+    const unsigned t_rel = (unsigned)((wave * SF_ROW_F + pxb * 32 + (pxb >> 3) * 32 + c4 * 4) * 4);
+    const unsigned hi_rel = 512u + ((pxb & 7) == 4 ? 128u : 0u);
+    const unsigned patch0 = sf_lds_addr(&s_patch[0][0]);
+    const unsigned w_base = sf_lds_addr(s_w) + (unsigned)(c4 * 4 * 4);
+
+    int rslot = 0, abuf = 0, pchunk = 0;
+    for (int s = 0; s < total; ++s) {
+      // patch(s) has landed (the six pieces of patch(s+1) may still be in flight), the A tile written in the last
+      // step is complete, and after the barrier the consumers are done with s_a[abuf] (they read it in step s-1)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(SF_NJ * (NSLOT - 2)) : "memory");
+      issue_next();
+      __builtin_amdgcn_sched_barrier(0);
+      if (!SF_DO_STENCIL) continue;
+      const unsigned t_addr = patch0 + (unsigned)rslot * (unsigned)(SF_PATCH_F * 4) + t_rel;
+      const unsigned t_hi = t_addr + hi_rel;
+      const unsigned w_addr = w_base + (unsigned)(pchunk * 32 * 4);
+      const unsigned wa_off = (unsigned)abuf * 16384u;
+      sf_f32x4 a[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] = (sf_f32x4){0.f, 0.f, 0.f, 0.f};
+      // the reads of a patch row (six pixels, three taps) are issued one row ahead of the row being filtered and
+      // consumed behind counted lgkmcnt waits (LDS returns in order; the counter has four bits: <= 15 in flight)
+      sf_f32x4 col[3][6], ww[3][3];
+      auto read_row = [&](auto KY) {
+        constexpr int ky = decltype(KY)::value;
+        const unsigned ra = t_addr + ky * (SF_ROW_F * 4), rb = t_hi + ky * (SF_ROW_F * 4);
+        col[ky][0] = sf_ds_read_f4<0>(ra);   col[ky][1] = sf_ds_read_f4<128>(ra); col[ky][2] = sf_ds_read_f4<256>(ra);
+        col[ky][3] = sf_ds_read_f4<384>(ra); col[ky][4] = sf_ds_read_f4<0>(rb);   col[ky][5] = sf_ds_read_f4<128>(rb);
+        ww[ky][0] = sf_ds_read_f4<(ky * 3 + 0) * SF_KMAX * 4>(w_addr);
+        ww[ky][1] = sf_ds_read_f4<(ky * 3 + 1) * SF_KMAX * 4>(w_addr);
+        ww[ky][2] = sf_ds_read_f4<(ky * 3 + 2) * SF_KMAX * 4>(w_addr);
+      };
+      auto fma_row = [&](auto KY, auto PENDING) {
+        constexpr int ky = decltype(KY)::value;
+        constexpr int pending = decltype(PENDING)::value;    // reads issued after this row's
+        asm volatile("s_waitcnt lgkmcnt(%9)"
+                     : "+v"(col[ky][0]), "+v"(col[ky][1]), "+v"(col[ky][2]), "+v"(col[ky][3]), "+v"(col[ky][4]), "+v"(col[ky][5]),
+                       "+v"(ww[ky][0]), "+v"(ww[ky][1]), "+v"(ww[ky][2])
+                     : "n"(pending)
+                     : "memory");
+        if (RELU_IN) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            col[ky][k].x = sf_relu(col[ky][k].x); col[ky][k].y = sf_relu(col[ky][k].y);
+            col[ky][k].z = sf_relu(col[ky][k].z); col[ky][k].w = sf_relu(col[ky][k].w);
+          }
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            a[k].x = fmaf(col[ky][k + kx].x, ww[ky][kx].x, a[k].x); a[k].y = fmaf(col[ky][k + kx].y, ww[ky][kx].y, a[k].y);
+            a[k].z = fmaf(col[ky][k + kx].z, ww[ky][kx].z, a[k].z); a[k].w = fmaf(col[ky][k + kx].w, ww[ky][kx].w, a[k].w);
+          }
+      };
+      read_row(std::integral_constant<int, 0>{});
+      read_row(std::integral_constant<int, 1>{});
+      fma_row(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
+      read_row(std::integral_constant<int, 2>{});
+      fma_row(std::integral_constant<int, 1>{}, std::integral_constant<int, 9>{});
+      fma_row(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const _Float16 h0 = (_Float16)a[k].x, h1 = (_Float16)a[k].y, h2 = (_Float16)a[k].z, h3 = (_Float16)a[k].w;
+        sf_f16x4 hv = {h0, h1, h2, h3};
+        sf_write_row<SPLIT3>(wa_k[k] + wa_off, 0, hv, a[k]);
+      }
+      rslot = rslot == NSLOT - 1 ? 0 : rslot + 1;
+      abuf ^= 1;
+      pchunk = pchunk + 1 == KC ? 0 : pchunk + 1;
+    }
+    // publishes the last A tile; nothing of this wave is in flight when it ends
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    return;
+  }
+
+  // ===================================================== consumers =====================================================
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.out, 0, (int)(unsigned)std::min<size_t>((size_t)p.N * p.H * (HPOOL ? p.Wo : p.W) * p.ldo * 4, 0xffffffffull),
+      0x00020000);
+  const int cw = wave - 4;
+  const int frow = lane & 31, fh = lane >> 5;
+  const int wm = cw / WAVES_N, wn = cw % WAVES_N;
+  unsigned a_rd[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int slot = wm * TM * 32 + ((frow & 16) | ((frow & 3) << 2) | ((frow >> 2) & 3));
+    a_rd[ks] = sf_lds_addr(&s_a[0][0]) + (unsigned)(slot * 32 + (((ks * 2 + fh) ^ (frow & 3)) << 3)) * 2u;
+  }
+  sf_f32x16 acc[TM][2];
+  sf_f16x8 bh[2][2], bl[2][2];
+  auto load_b_half = [&](int ks, int chunk, int n0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const size_t o = ((size_t)chunk * p.Cout_pad + (n0 + wn * 64 + j * 32 + frow)) * 32 + (ks * 2 + fh) * 8;
+      bh[ks][j] = *reinterpret_cast<const sf_f16x8*>(p.wt_hi + o);
+      if (SPLIT3) bl[ks][j] = *reinterpret_cast<const sf_f16x8*>(p.wt_lo + o);
+    }
+  };
+  int ct = t_begin, cchunk = 0;
+  Coord cur = decode(ct);
+  load_b_half(0, 0, cur.nt * BN);
+  load_b_half(1, 0, cur.nt * BN);
+  float esc[2], esh[2];
+  for (int s = 0; s <= total; ++s) {
+    // the A tile of step s-1 is complete; LDS reads of the previous step have returned (they fed its MFMAs)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (s == 0 || !SF_DO_MFMA) continue;
+    const int n0 = cur.nt * BN;
+    if (cchunk == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        esc[j] = p.scale[n0 + wn * 64 + j * 32 + frow];
+        esh[j] = p.shift[n0 + wn * 64 + j * 32 + frow];
+      }
+    }
+    // the step after this one: its weights are requested as soon as a half's registers are free
+    const bool last = cchunk + 1 == KC;
+    const int nchunk = last ? 0 : cchunk + 1;
+    const Coord nxt = decode(min(last ? ct + G : ct, p.ntiles - 1));
+    const int nn0 = nxt.nt * BN;
+    const unsigned aoff = (unsigned)((s - 1) & 1) * 16384u;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      sf_f16x8 ah[TM], al[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = sf_ds_read_b128<0>(a_rd[ks] + aoff + i * 2048);
+        if (SPLIT3) al[i] = sf_ds_read_b128<128 * 64>(a_rd[ks] + aoff + i * 2048);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; i += 2) {
+        if (SPLIT3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i]), "+v"(ah[i + 1]), "+v"(al[i]), "+v"(al[i + 1])::"memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i]), "+v"(ah[i + 1])::"memory");
+      }
+      // products in the conv kernel's order (lo*hi, hi*lo, hi*hi)
+      if (SPLIT3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[ks][j], acc[i][j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[ks][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_b_half(ks, nchunk, nn0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    cchunk = nchunk;
+    if (!last) continue;
+    if (!SF_DO_STORE) {   // probe: keep the accumulators alive without the epilogue's stores
+      float z = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) z += acc[i][j][r];
+      if (z == 1234.5f) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, z), orsrc, 0u, 0u, 0);
+      ct += G;
+      cur = nxt;
+      continue;
+    }
+
+    // ---- epilogue of the tile (as in the kernel above) ----
+    const int y0 = cur.ty * SF_R, x0 = HPOOL ? cur.tx * SF_XP - p.pool_pad_l : cur.tx * SF_X;
+    if (HPOOL) {
+      const int klim = min(SF_XP / 2, p.Wo - cur.tx * (SF_XP / 2)) - 8 * fh;
+      const bool edge = x0 < 0 || x0 + 32 > p.W;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int y = y0 + wm * TM + i;
+        if (y >= p.H) continue;
+        const unsigned row_off = (unsigned)((((size_t)cur.n * p.H + y) * p.Wo + cur.tx * (SF_XP / 2)) * p.ldo * 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int co = n0 + wn * 64 + j * 32 + frow;
+          const unsigned lane_off = co < p.ldo ? (unsigned)((8 * fh * p.ldo + co) * 4) : 0xffffffffu;
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            v[r] = fmaf(acc[i][j][r], esc[j], esh[j]);
+            if (p.relu_out) v[r] = fmaxf(v[r], 0.f);
+          }
+          if (edge) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int col = x0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+              if ((unsigned)col >= (unsigned)p.W) v[r] = -INFINITY;
+            }
+          }
+          float X[8], Y[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            X[r] = v[r];
+            Y[r] = v[r + 8];
+            sf_permlane32_swap(X[r], Y[r]);
+          }
+          auto colv = [&](int q) { return (q & 4) ? Y[(q & 3) + 4 * (q >> 3)] : X[(q & 3) + 4 * (q >> 3)]; };
+          float c16a = X[0], col16 = X[0];
+          sf_permlane32_swap(c16a, col16);
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            const float c2 = kk < 7 ? colv(2 * kk + 2) : col16;
+            const float m = fmaxf(fmaxf(colv(2 * kk), colv(2 * kk + 1)), c2);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), orsrc, kk < klim ? lane_off : 0xffffffffu,
+                                                  row_off + kk * p.ldo * 4, 0);
+          }
+        }
+      }
+    } else {
+      const int lim = min(SF_X, p.W - x0) - 4 * fh;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int y = y0 + wm * TM + i;
+        if (y >= p.H) continue;
+        const unsigned row_off = (unsigned)((((size_t)cur.n * p.H + y) * p.W + x0) * p.ldo * 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int co = n0 + wn * 64 + j * 32 + frow;
+          const unsigned lane_off = co < p.ldo ? (unsigned)((4 * fh * p.ldo + co) * 4) : 0xffffffffu;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2);
+            float v = fmaf(acc[i][j][r], esc[j], esh[j]);
+            if (p.relu_out) v = fmaxf(v, 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, c < lim ? lane_off : 0xffffffffu, row_off + c * p.ldo * 4, 0);
+          }
+        }
+      }
+    }
+    ct += G;
+    cur = nxt;
+  }
+}
+
 bool sepconv_fused_supported(int cin_ld, int cout_pad, int dil) {
   // 128 outputs: one 128-wide pass; multiples of 256 (block4_sepconv1: 728 -> 768): 256-wide passes over the same patch
   return dil == 1 && cin_ld % 32 == 0 && cin_ld <= SF_KMAX && (cout_pad == 128 || (cout_pad % 256 == 0 && cout_pad <= 1024));
@@ -500,13 +875,20 @@ int launch_sepconv_fused(const float* in, const float* w9c, const unsigned short
     const int64_t nt = (int64_t)n * p.TY * p.TX * p.NT;
     p.ntiles = (int)nt;
     p.tiles_per_block = 0;
-    // two workgroups per CU (LDS); a multiple of 8 so that every XCD gets the same number
-    const dim3 g((unsigned)std::min<int64_t>(512, cdiv(nt, 8) * 8));
-    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, g, dim3(256), 0, s, p); };
+    // producer / consumer form: one 512-thread workgroup per CU; XDET_SEPCONV_SERIAL=1: the four-wave form above, two
+    // workgroups per CU (LDS) -- for A/B runs; a multiple of 8 so that every XCD gets the same number
+    static const bool serial = getenv("XDET_SEPCONV_SERIAL") != nullptr;
+    const dim3 g((unsigned)std::min<int64_t>(serial ? 512 : 256, cdiv(nt, 8) * 8));
+    auto go = [&](auto kern, int threads) { hipLaunchKernelGGL(kern, g, dim3(threads), 0, s, p); };
     auto pick = [&](auto split3, auto relu, auto pool) {
       constexpr bool S3 = decltype(split3)::value, RL = decltype(relu)::value, PL = decltype(pool)::value;
-      if (wide) go(sepconv_fused_kernel<S3, RL, PL, 4>);
-      else go(sepconv_fused_kernel<S3, RL, PL, 2>);
+      if (serial) {
+        if (wide) go(sepconv_fused_kernel<S3, RL, PL, 4>, 256);
+        else go(sepconv_fused_kernel<S3, RL, PL, 2>, 256);
+      } else {
+        if (wide) go(sepconv_pc_kernel<S3, RL, PL, 4>, 512);
+        else go(sepconv_pc_kernel<S3, RL, PL, 2>, 512);
+      }
     };
     auto pick2 = [&](auto split3, auto relu) {
       if (hpool) pick(split3, relu, std::true_type{});
