@@ -35,7 +35,15 @@ namespace xdet {
 constexpr bool SF_DO_DMA = SF_PROBE_LEVEL != 4;
 constexpr bool SF_DO_STENCIL = SF_PROBE_LEVEL != 1;
 constexpr bool SF_DO_MFMA = SF_PROBE_LEVEL == 0 || SF_PROBE_LEVEL >= 3;
-constexpr bool SF_DO_STORE = SF_PROBE_LEVEL == 0 || SF_PROBE_LEVEL == 4;
+constexpr bool SF_DO_STORE = SF_PROBE_LEVEL == 0 || SF_PROBE_LEVEL == 4 || SF_PROBE_LEVEL == 9;
+#if SF_PROBE_LEVEL == 9
+#define SF_STAMP(slot)                                                                         \
+  do {                                                                                         \
+    if (blockIdx.x == 8 && lane == 0 && s < 64) p.dbg[(wave * 64 + s) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define SF_STAMP(slot) do {} while (0)
+#endif
 
 typedef float sf_f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 sf_f16x8 __attribute__((ext_vector_type(8)));
@@ -53,6 +61,7 @@ constexpr int SF_PIECE_F = 8 * 32 + 32;             // floats per piece incl. pa
 constexpr int SF_ROW_F = (SF_P / 8) * SF_PIECE_F;   // floats per patch row (4608 B)
 constexpr int SF_PATCH_F = SF_ROWS * SF_ROW_F;      // floats per patch buffer (27 KB)
 constexpr int SF_KMAX = 256;                        // input channels (dw taps live in LDS)
+constexpr int SF_COUT_MAX = 1024;                   // output channels (sepconv_fused_supported)
 constexpr int SF_NJ = SF_ROWS * (SF_P / 8) / 4;     // DMA pieces per wave per chunk (6)
 
 struct SepFusedParams {
@@ -68,6 +77,9 @@ struct SepFusedParams {
   // HPOOL: the epilogue writes the 3-column / stride-2 maximum of each output row (the horizontal half of the
   // max_pooling2d(3, 2, 'same') that follows the block, net/xception_body.py:281-286): out is [N][H][Wo][ldo]
   int Wo, pool_pad_l;
+#if SF_PROBE_LEVEL == 9
+  unsigned long long* dbg;   // timeline probe: [wave][step][8] s_memtime stamps of workgroup 8
+#endif
 };
 
 // LDS accesses issued while the patch prefetch (an LDS-writing DMA) is in flight.  The compiler cannot tell
@@ -82,6 +94,7 @@ __device__ __forceinline__ void sf_ds_write_b64(unsigned addr, uint2 v) {
   asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
 typedef float sf_f32x4 __attribute__((ext_vector_type(4)));
+typedef float sf_f32x2 __attribute__((ext_vector_type(2)));
 template <int OFF>
 __device__ __forceinline__ sf_f32x4 sf_ds_read_f4(unsigned addr) {
   sf_f32x4 r;
@@ -121,11 +134,34 @@ __device__ __forceinline__ void sf_write_row(unsigned wa0, int r, sf_f16x4 hv, s
   }
 }
 
+// hi = f16(a), lo = f16(a - float(hi)) of four values, as two packed pairs each.  v_fma_mixlo/hi_f16 take the f16 hi half
+// straight as an fma operand and round the f32 difference (exact: it has at most 13 significant bits) to f16 into one
+// half of the destination: one instruction per value where convert-back + subtract + convert were two -- the same bits.
+__device__ __forceinline__ void sf_split4(sf_f32x4 a, uint2* h, uint2* l) {
+  // ONE asm block: inline asm is opaque to the hazard recogniser, and gfx950 wants a wait state between a half-register
+  // write (v_fma_mixlo / mixhi) and a VALU that reads the register -- the order below keeps another instruction between
+  // the two halves of each lo word, the trailing s_nop covers whatever the compiler places behind the block
+  unsigned h0, h1, l0, l1;
+  asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+      "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
+      "v_fma_mixlo_f16 %2, %4, 1.0, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %3, %6, 1.0, -%1 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %2, %5, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %3, %7, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "s_nop 0"
+      : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1)
+      : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w));
+  *h = make_uint2(h0, h1);
+  *l = make_uint2(l0, l1);
+}
+
 // v_permlane32_swap_b32 a, b: the upper 32 lanes of a and the lower 32 lanes of b change places, i.e. afterwards
 // a = {a.lower, b.lower} and b = {a.upper, b.upper}.  (Inline asm: with the clang builtin, hipcc 7.2 dropped the second
 // result of all but the first swap of an unrolled sequence and used the first result in its place.)
+// (The s_nop: a VALU result read by the swap in the next issue slot is a hazard the compiler cannot see through the
+//  asm -- round 5 found window maxima built from a stale register once the BN multiply sat directly in front.)
 __device__ __forceinline__ void sf_permlane32_swap(float& a, float& b) {
-  asm("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
 // WAVES_N = 2: the four waves as 2 x 2 over a 128 x 128 tile (64 x 64 each), a 256-channel layer as two passes.
@@ -502,6 +538,7 @@ __global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
   __shared__ __attribute__((aligned(16))) float s_patch[NSLOT][SF_PATCH_F];
   __shared__ __attribute__((aligned(16))) u16 s_a[2][2 * 128 * 32];     // two A tiles (hi rows, then lo rows: 16 KB each)
   __shared__ __attribute__((aligned(16))) float s_w[9 * SF_KMAX];
+  __shared__ float s_bn[2][SF_COUT_MAX];          // folded-BN scale / shift of every output channel (epilogue)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -519,6 +556,10 @@ __global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
   for (int i = tid; i < 9 * p.ld; i += 512) {
     const int t = i / p.ld;
     s_w[t * SF_KMAX + (i - t * p.ld)] = p.w9c[i];
+  }
+  for (int i = tid; i < p.Cout_pad; i += 512) {
+    s_bn[0][i] = p.scale[i];
+    s_bn[1][i] = p.shift[i];
   }
 
   struct Coord { int nt, ty, tx, n; };
@@ -601,8 +642,13 @@ __global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
     for (int s = 0; s < total; ++s) {
       // patch(s) has landed (the six pieces of patch(s+1) may still be in flight), the A tile written in the last
       // step is complete, and after the barrier the consumers are done with s_a[abuf] (they read it in step s-1)
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(SF_NJ * (NSLOT - 2)) : "memory");
+      SF_STAMP(0);                                   // arrival at the barrier (previous step's work done)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SF_NJ * (NSLOT - 2)) : "memory");
+      SF_STAMP(1);                                   // own DMA pieces of this step's patch have landed
+      asm volatile("s_barrier" ::: "memory");
+      SF_STAMP(2);                                   // released
       issue_next();
+      SF_STAMP(4);                                   // next patch requested
       __builtin_amdgcn_sched_barrier(0);
       if (!SF_DO_STENCIL) continue;
       const unsigned t_addr = patch0 + (unsigned)rslot * (unsigned)(SF_PATCH_F * 4) + t_rel;
@@ -639,26 +685,38 @@ __global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
             col[ky][k].z = sf_relu(col[ky][k].z); col[ky][k].w = sf_relu(col[ky][k].w);
           }
         }
+        // v_pk_fma_f32 on explicit channel pairs (left to the vectoriser, the ReLU-free instance came out as 144 scalar FMAs)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            a[k].x = fmaf(col[ky][k + kx].x, ww[ky][kx].x, a[k].x); a[k].y = fmaf(col[ky][k + kx].y, ww[ky][kx].y, a[k].y);
-            a[k].z = fmaf(col[ky][k + kx].z, ww[ky][kx].z, a[k].z); a[k].w = fmaf(col[ky][k + kx].w, ww[ky][kx].w, a[k].w);
+            const sf_f32x2 c_lo = __builtin_shufflevector(col[ky][k + kx], col[ky][k + kx], 0, 1);
+            const sf_f32x2 c_hi = __builtin_shufflevector(col[ky][k + kx], col[ky][k + kx], 2, 3);
+            const sf_f32x2 w_lo = __builtin_shufflevector(ww[ky][kx], ww[ky][kx], 0, 1);
+            const sf_f32x2 w_hi = __builtin_shufflevector(ww[ky][kx], ww[ky][kx], 2, 3);
+            sf_f32x2 a_lo = __builtin_shufflevector(a[k], a[k], 0, 1), a_hi = __builtin_shufflevector(a[k], a[k], 2, 3);
+            a_lo = __builtin_elementwise_fma(c_lo, w_lo, a_lo);
+            a_hi = __builtin_elementwise_fma(c_hi, w_hi, a_hi);
+            a[k] = __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3);
           }
       };
       read_row(std::integral_constant<int, 0>{});
       read_row(std::integral_constant<int, 1>{});
       fma_row(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
+      SF_STAMP(5);
       read_row(std::integral_constant<int, 2>{});
       fma_row(std::integral_constant<int, 1>{}, std::integral_constant<int, 9>{});
+      SF_STAMP(6);
       fma_row(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+      SF_STAMP(7);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const _Float16 h0 = (_Float16)a[k].x, h1 = (_Float16)a[k].y, h2 = (_Float16)a[k].z, h3 = (_Float16)a[k].w;
-        sf_f16x4 hv = {h0, h1, h2, h3};
-        sf_write_row<SPLIT3>(wa_k[k] + wa_off, 0, hv, a[k]);
+        uint2 h, l;
+        sf_split4(a[k], &h, &l);
+        sf_ds_write_b64<0>(wa_k[k] + wa_off, h);
+        if (SPLIT3) sf_ds_write_b64<8192>(wa_k[k] + wa_off, l);
       }
+      SF_STAMP(3);                                   // stencil + A-tile writes issued
       rslot = rslot == NSLOT - 1 ? 0 : rslot + 1;
       abuf ^= 1;
       pchunk = pchunk + 1 == KC ? 0 : pchunk + 1;
@@ -682,14 +740,35 @@ __global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
     a_rd[ks] = sf_lds_addr(&s_a[0][0]) + (unsigned)(slot * 32 + (((ks * 2 + fh) ^ (frow & 3)) << 3)) * 2u;
   }
   sf_f32x16 acc[TM][2];
+  // Pointwise weights: L2 -> registers, one 16-deep half at a time, requested as soon as the half's registers are free
+  // (right behind its MFMAs) for the NEXT step -- half a step + the barrier ahead of their use.  Loads and waits are
+  // inline asm: left to the compiler, the first MFMA of a step sat behind `s_waitcnt vmcnt(0)` (loop-carried loads
+  // next to the epilogue's conditional stores), i.e. behind the half requested a few instructions before the barrier,
+  // and every step paid an L2 round trip.  vmcnt retires in order: with NB loads per half, `vmcnt(NB)` in front of a
+  // half's MFMAs leaves exactly the other half's loads in flight (a tile's last step also waits for its stores).
+  constexpr int NB = SPLIT3 ? 4 : 2;
   sf_f16x8 bh[2][2], bl[2][2];
-  auto load_b_half = [&](int ks, int chunk, int n0) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const size_t o = ((size_t)chunk * p.Cout_pad + (n0 + wn * 64 + j * 32 + frow)) * 32 + (ks * 2 + fh) * 8;
-      bh[ks][j] = *reinterpret_cast<const sf_f16x8*>(p.wt_hi + o);
-      if (SPLIT3) bl[ks][j] = *reinterpret_cast<const sf_f16x8*>(p.wt_lo + o);
+  const unsigned bvoff = (unsigned)(((wn * 64 + frow) * 32 + fh * 8) * 2);                // bytes; j: + 2048, ks: + 32
+#define SF_LOAD_B(dst, base, imm) \
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(bvoff), "s"(base), "n"(imm) : "memory")
+  auto load_b_half = [&](int ks, int chunk, int n0) {       // ks is a literal at every call site: one arm survives
+    const size_t row0 = ((size_t)chunk * p.Cout_pad + n0) * 32;                          // wave-uniform
+    const u16* bhp = p.wt_hi + row0;
+    const u16* blp = p.wt_lo + row0;
+    if (ks == 0) {
+      SF_LOAD_B(bh[0][0], bhp, 0);
+      SF_LOAD_B(bh[0][1], bhp, 2048);
+      if (SPLIT3) { SF_LOAD_B(bl[0][0], blp, 0); SF_LOAD_B(bl[0][1], blp, 2048); }
+    } else {
+      SF_LOAD_B(bh[1][0], bhp, 32);
+      SF_LOAD_B(bh[1][1], bhp, 32 + 2048);
+      if (SPLIT3) { SF_LOAD_B(bl[1][0], blp, 32); SF_LOAD_B(bl[1][1], blp, 32 + 2048); }
     }
+  };
+#undef SF_LOAD_B
+  auto wait_b_half = [&](int ks) {
+    if (SPLIT3) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(bh[ks][0]), "+v"(bh[ks][1]), "+v"(bl[ks][0]), "+v"(bl[ks][1]) : "n"(NB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(bh[ks][0]), "+v"(bh[ks][1]) : "n"(NB) : "memory");
   };
   int ct = t_begin, cchunk = 0;
   Coord cur = decode(ct);
@@ -698,7 +777,9 @@ __global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
   float esc[2], esh[2];
   for (int s = 0; s <= total; ++s) {
     // the A tile of step s-1 is complete; LDS reads of the previous step have returned (they fed its MFMAs)
+    SF_STAMP(0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    SF_STAMP(1);
     if (s == 0 || !SF_DO_MFMA) continue;
     const int n0 = cur.nt * BN;
     if (cchunk == 0) {
@@ -708,20 +789,15 @@ __global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        esc[j] = p.scale[n0 + wn * 64 + j * 32 + frow];
-        esh[j] = p.shift[n0 + wn * 64 + j * 32 + frow];
-      }
     }
     // the step after this one: its weights are requested as soon as a half's registers are free
     const bool last = cchunk + 1 == KC;
     const int nchunk = last ? 0 : cchunk + 1;
-    const Coord nxt = decode(min(last ? ct + G : ct, p.ntiles - 1));
+    Coord nxt = cur;
+    if (last) nxt = decode(min(ct + G, p.ntiles - 1));     // (three divisions: once per tile, not per step)
     const int nn0 = nxt.nt * BN;
     const unsigned aoff = (unsigned)((s - 1) & 1) * 16384u;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    auto half = [&](const int ks) {
       sf_f16x8 ah[TM], al[TM];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -733,6 +809,7 @@ __global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
         if (SPLIT3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i]), "+v"(ah[i + 1]), "+v"(al[i]), "+v"(al[i + 1])::"memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i]), "+v"(ah[i + 1])::"memory");
       }
+      wait_b_half(ks);
       // products in the conv kernel's order (lo*hi, hi*lo, hi*hi)
       if (SPLIT3) {
 #pragma unroll
@@ -754,7 +831,11 @@ __global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
       __builtin_amdgcn_sched_barrier(0);
       load_b_half(ks, nchunk, nn0);
       __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    half(0);
+    SF_STAMP(2);
+    half(1);
+    SF_STAMP(3);
     cchunk = nchunk;
     if (!last) continue;
     if (!SF_DO_STORE) {   // probe: keep the accumulators alive without the epilogue's stores
@@ -771,11 +852,30 @@ __global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
       continue;
     }
 
-    // ---- epilogue of the tile (as in the kernel above) ----
+    // ---- epilogue of the tile (as in the kernel above; scale / shift from LDS: a global load here would sit in the
+    //      same in-order vmcnt queue as the weight requests of the next step) ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      esc[j] = s_bn[0][n0 + wn * 64 + j * 32 + frow];
+      esh[j] = s_bn[1][n0 + wn * 64 + j * 32 + frow];
+    }
+    // Instruction diet (the epilogue runs on the wave that owns the matrix pipe, with the producers parked at the
+    // barrier): an interior tile's store predicate depends on the register index and the lane half only -- windows /
+    // columns of the upper half that fall outside the tile are the same two in every interior tile -- so the per-store
+    // select is hoisted into two offsets; edge tiles keep the per-element form.
     const int y0 = cur.ty * SF_R, x0 = HPOOL ? cur.tx * SF_XP - p.pool_pad_l : cur.tx * SF_X;
+    unsigned lane_off_j[2], tail_off_j[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int co = n0 + wn * 64 + j * 32 + frow;
+      lane_off_j[j] = co < p.ldo ? (unsigned)(((HPOOL ? 8 : 4) * fh * p.ldo + co) * 4) : 0xffffffffu;
+      tail_off_j[j] = fh ? 0xffffffffu : lane_off_j[j];       // upper half: windows 6, 7 / columns 30, 31 do not exist
+    }
     if (HPOOL) {
-      const int klim = min(SF_XP / 2, p.Wo - cur.tx * (SF_XP / 2)) - 8 * fh;
+      const int nwin = min(SF_XP / 2, p.Wo - cur.tx * (SF_XP / 2));          // wave-uniform
+      const int klim = nwin - 8 * fh;
       const bool edge = x0 < 0 || x0 + 32 > p.W;
+      const bool interior = nwin == SF_XP / 2;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int y = y0 + wm * TM + i;
@@ -783,13 +883,12 @@ __global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
         const unsigned row_off = (unsigned)((((size_t)cur.n * p.H + y) * p.Wo + cur.tx * (SF_XP / 2)) * p.ldo * 4);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int co = n0 + wn * 64 + j * 32 + frow;
-          const unsigned lane_off = co < p.ldo ? (unsigned)((8 * fh * p.ldo + co) * 4) : 0xffffffffu;
           float v[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            v[r] = fmaf(acc[i][j][r], esc[j], esh[j]);
-            if (p.relu_out) v[r] = fmaxf(v[r], 0.f);
+          for (int r = 0; r < 16; ++r) v[r] = fmaf(acc[i][j][r], esc[j], esh[j]);
+          if (p.relu_out) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = sf_relu(v[r]);   // one v_max (fmaxf: + a canonicalising one)
           }
           if (edge) {
 #pragma unroll
@@ -808,17 +907,29 @@ __global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
           auto colv = [&](int q) { return (q & 4) ? Y[(q & 3) + 4 * (q >> 3)] : X[(q & 3) + 4 * (q >> 3)]; };
           float c16a = X[0], col16 = X[0];
           sf_permlane32_swap(c16a, col16);
+          float m[8];
 #pragma unroll
           for (int kk = 0; kk < 8; ++kk) {
             const float c2 = kk < 7 ? colv(2 * kk + 2) : col16;
-            const float m = fmaxf(fmaxf(colv(2 * kk), colv(2 * kk + 1)), c2);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), orsrc, kk < klim ? lane_off : 0xffffffffu,
-                                                  row_off + kk * p.ldo * 4, 0);
+            m[kk] = fmaxf(fmaxf(colv(2 * kk), colv(2 * kk + 1)), c2);
+          }
+          if (interior) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m[kk]), orsrc, kk < 6 ? lane_off_j[j] : tail_off_j[j],
+                                                    row_off + kk * p.ldo * 4, 0);
+          } else {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m[kk]), orsrc, kk < klim ? lane_off_j[j] : 0xffffffffu,
+                                                    row_off + kk * p.ldo * 4, 0);
           }
         }
       }
     } else {
-      const int lim = min(SF_X, p.W - x0) - 4 * fh;
+      const int ncol = min(SF_X, p.W - x0);                                  // wave-uniform
+      const int lim = ncol - 4 * fh;
+      const bool interior = ncol == SF_X;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int y = y0 + wm * TM + i;
@@ -826,14 +937,27 @@ __global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
         const unsigned row_off = (unsigned)((((size_t)cur.n * p.H + y) * p.W + x0) * p.ldo * 4);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int co = n0 + wn * 64 + j * 32 + frow;
-          const unsigned lane_off = co < p.ldo ? (unsigned)((4 * fh * p.ldo + co) * 4) : 0xffffffffu;
+          float v[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int c = (r & 3) + 8 * (r >> 2);
-            float v = fmaf(acc[i][j][r], esc[j], esh[j]);
-            if (p.relu_out) v = fmaxf(v, 0.f);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, c < lim ? lane_off : 0xffffffffu, row_off + c * p.ldo * 4, 0);
+          for (int r = 0; r < 16; ++r) v[r] = fmaf(acc[i][j][r], esc[j], esh[j]);
+          if (p.relu_out) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = sf_relu(v[r]);   // one v_max (fmaxf: + a canonicalising one)
+          }
+          if (interior) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int c = (r & 3) + 8 * (r >> 2);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), orsrc, c < 26 ? lane_off_j[j] : tail_off_j[j],
+                                                    row_off + c * p.ldo * 4, 0);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int c = (r & 3) + 8 * (r >> 2);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), orsrc, c < lim ? lane_off_j[j] : 0xffffffffu,
+                                                    row_off + c * p.ldo * 4, 0);
+            }
           }
         }
       }
@@ -842,6 +966,10 @@ __global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
     cur = nxt;
   }
 }
+
+#if SF_PROBE_LEVEL == 9
+unsigned long long* g_probe_dbg = nullptr;
+#endif
 
 bool sepconv_fused_supported(int cin_ld, int cout_pad, int dil) {
   // 128 outputs: one 128-wide pass; multiples of 256 (block4_sepconv1: 728 -> 768): 256-wide passes over the same patch
@@ -871,6 +999,9 @@ int launch_sepconv_fused(const float* in, const float* w9c, const unsigned short
     static const bool two_pass = getenv("XDET_SEPCONV_TWO_PASS") != nullptr;
     const bool wide = cout_pad % 256 == 0 && !two_pass;
     p.Wo = (W + 1) / 2; p.pool_pad_l = hpool ? pool_pad_l : 0;
+#if SF_PROBE_LEVEL == 9
+    p.dbg = g_probe_dbg;
+#endif
     p.TY = (int)cdiv(H, SF_R); p.TX = hpool ? (int)cdiv(p.Wo, SF_XP / 2) : (int)cdiv(W, SF_X); p.NT = wide ? cout_pad / 256 : cout_pad / 128;
     const int64_t nt = (int64_t)n * p.TY * p.TX * p.NT;
     p.ntiles = (int)nt;
