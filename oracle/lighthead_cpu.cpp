@@ -301,7 +301,32 @@ struct Net {
     convs[name].run(d, y, res, false);
   }
 
+  // Batches with at least one image per two threads run IMAGE-parallel: every thread takes whole images through the
+  // whole graph (the `omp parallel for`s inside are then nested regions and run on the calling thread), so nothing is
+  // synchronised per layer and nothing serial (tensor allocation, the ReLU copies) is left between parallel regions --
+  // the layer-parallel form below was fastest at 16 threads and slower beyond on a 2 x 64-core host.
+  // Smaller batches keep the layer-parallel form.
   void forward(const float* images_nchw, int N, float* det_scores, float* det_boxes) {
+    const int nt = omp_get_max_threads();
+    if (N >= 2 && 2 * N >= nt && !omp_in_parallel()) {
+      std::string first_error;
+#pragma omp parallel for schedule(dynamic, 1)
+      for (int n = 0; n < N; ++n) {
+        try {
+          forward_batch(images_nchw + (size_t)n * 3 * S * S, 1, det_scores + (size_t)n * (num_classes - 1) * nms_topk,
+                        det_boxes + (size_t)n * (num_classes - 1) * nms_topk * 4);
+        } catch (const std::exception& e) {
+#pragma omp critical
+          if (first_error.empty()) first_error = e.what();
+        }
+      }
+      if (!first_error.empty()) throw std::runtime_error(first_error);
+      return;
+    }
+    forward_batch(images_nchw, N, det_scores, det_boxes);
+  }
+
+  void forward_batch(const float* images_nchw, int N, float* det_scores, float* det_boxes) {
     T4 x;
     x.alloc(N, S, S, 3);
     for (int n = 0; n < N; ++n)

@@ -408,7 +408,8 @@ def build_cpp_baseline(force=False):
 
 
 _cpp = None
-FAST_PATH_DESCRIPTION = 'C++17 + OpenMP restatement of the reference graph (oracle/lighthead_cpu.cpp, fp32, AVX-512/AVX2)'
+FAST_PATH_DESCRIPTION = ('C++17 + OpenMP restatement of the reference graph (oracle/lighthead_cpu.cpp, fp32, AVX-512/AVX2; '
+                         'image-parallel: one image per thread at a time)')
 
 
 class CppForward(object):
@@ -436,18 +437,23 @@ class CppForward(object):
         _cpp.lhcpu_set_threads(int(n))
         self.threads = int(_cpp.lhcpu_threads())
 
-    def tune_threads(self, image, candidates=(16, 32, 64, 128, 256)):
-        """pick the OpenMP thread count that runs one forward fastest on THIS box (a CPU baseline should be the
-        box's best, not whatever omp_get_max_threads() reports inside a container); returns {threads: seconds}"""
+    def tune_threads(self, images, candidates=None):
+        """pick the OpenMP thread count that runs one call fastest on THIS box; returns {threads: seconds}.  The
+        baseline runs image-parallel when a call brings at least one image per two threads (lighthead_cpu.cpp), so the
+        candidates are the box's hardware threads and half of them (the physical cores of an SMT-2 host) plus, for small
+        batches (layer-parallel form), the counts that used to win there."""
         import time
         hw = os.cpu_count() or 1
+        n = int(np.asarray(images).shape[0])
+        if candidates is None:
+            candidates = (hw, max(hw // 2, 1)) if 2 * n >= hw // 2 else (16, 32, 64, hw)
         seen = {}
-        for n in sorted(set(min(c, hw) for c in candidates)):
-            self.set_threads(n)
-            self(image)
+        for c in sorted(set(max(1, min(int(c), hw)) for c in candidates)):
+            self.set_threads(c)
+            self(images)
             t = time.time()
-            self(image)
-            seen[n] = time.time() - t
+            self(images)
+            seen[c] = time.time() - t
         self.set_threads(min(seen, key=seen.get))
         return seen
 

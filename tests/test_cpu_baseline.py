@@ -28,3 +28,24 @@ def test_cpp_baseline_matches_the_numpy_oracle(oracle, lh_weights):
     # the bench entry point caches the packed weights
     again = oracle.lighthead_forward_fast(img, lh_weights, rpn_post_nms_top_n=300)
     assert np.array_equal(again[0][1][0], got[0][1][0])
+
+
+def test_image_parallel_form_equals_layer_parallel_form(oracle, lh_weights):
+    """a call with at least one image per two threads runs image-parallel (every thread takes whole images through the
+    graph); smaller calls run layer-parallel.  Same arithmetic per image, so the same bits -- and the thread sweep picks
+    one of its candidates."""
+    from xdet import weights as W
+    imgs = W.synthetic_images(2, 256, seed=12)
+    fwd = oracle.CppForward(lh_weights, 256, 100)
+    fwd.set_threads(2)
+    a = fwd(imgs)                       # 2 images, 2 threads: image-parallel
+    fwd.set_threads(8)
+    b = fwd(imgs)                       # 2 images, 8 threads: layer-parallel
+    n_det = 0
+    for i in range(2):
+        for c in range(1, 21):
+            assert np.array_equal(a[i][c][0], b[i][c][0]) and np.array_equal(a[i][c][1], b[i][c][1]), (i, c)
+            n_det += int((a[i][c][0] > 0).sum())
+    assert n_det > 20
+    seen = fwd.tune_threads(imgs, candidates=(1, 2))
+    assert set(seen) == {1, 2} and fwd.threads in seen

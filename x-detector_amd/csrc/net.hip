@@ -147,14 +147,24 @@ struct ConvLayer : LayerBase {
   int ks_mode = 0;                     // 0 = by grid size, 1 = parallel ranges, 2 = one workgroup per tile (tests)
   int64_t ks_tiles = 0;                // tiles the scratch below was sized for
   float* d_ks_partial = nullptr;
-  int enable_ksplit(int S, int64_t max_parallel_tiles) {
+  bool ks_owns_scratch = false;        // false: the slab belongs to the plan (one per stream, shared by its layers)
+  size_t ks_scratch_bytes(int S, int64_t tiles) const {
+    return S > 1 ? (size_t)std::max<int64_t>(tiles, 1) * S * 128 * (cout_pad % 128 == 0 ? 128 : 64) * sizeof(float) : 0;
+  }
+  // shared == nullptr: the layer allocates its own slab (stand-alone layers behind xdet_conv_set_ksplit); inside a plan the
+  // ops of one stream run one after the other, so all its split-K layers borrow ONE slab sized for the largest of them
+  int enable_ksplit(int S, int64_t max_parallel_tiles, float* shared = nullptr) {
     XDET_REQUIRE(S >= 1 && S <= 16 && dma_capable() && groups == 1, "ksplit: 1..16 ranges, a split-precision non-grouped layer");
-    if (d_ks_partial) (void)hipFree(d_ks_partial);
+    if (d_ks_partial && ks_owns_scratch) (void)hipFree(d_ks_partial);
     d_ks_partial = nullptr;
+    ks_owns_scratch = false;
     ks_tiles = std::max<int64_t>(max_parallel_tiles, 1);
     if (S > 1) {
-      const size_t slab = (size_t)128 * (cout_pad % 128 == 0 ? 128 : 64) * sizeof(float);
-      XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_ks_partial), (size_t)ks_tiles * S * slab));
+      if (shared) d_ks_partial = shared;
+      else {
+        XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_ks_partial), ks_scratch_bytes(S, ks_tiles)));
+        ks_owns_scratch = true;
+      }
     }
     ksplit = S;
     return XDET_OK;
@@ -196,7 +206,7 @@ struct ConvLayer : LayerBase {
   }
 
   ~ConvLayer() override {
-    if (d_ks_partial) (void)hipFree(d_ks_partial);
+    if (d_ks_partial && ks_owns_scratch) (void)hipFree(d_ks_partial);
     if (d_pl_scale) (void)hipFree(d_pl_scale);
     if (d_pl_shift) (void)hipFree(d_pl_shift);
     if (d_zeros) (void)hipFree(d_zeros);
@@ -369,7 +379,11 @@ struct ConvLayer : LayerBase {
         XDET_REQUIRE(d_wt_x8_b && precision == PREC_F16X3 && ksplit < 1, "conv: x8 planes need a pointwise f16x3 layer without a split-K");
         p.wt_lo = d_wt_x8_b; p.x8 = 1; p.x8_exp = x8_exp;
       }
-      if (ksplit >= 1 && groups == 1 && conv_ksplit_supported(kh, kw, (int64_t)N * H * W, ldi, cin_p, cout_pad)) {
+      if (ksplit >= 1 && groups == 1) {
+        // a split-K layer's summation tree is part of its definition: a batch whose planes leave the kernel's 4 GiB
+        // addressing is an error, not a silent change of kernel family (results must not depend on the batch)
+        XDET_REQUIRE(conv_ksplit_supported(kh, kw, (int64_t)N * H * W, ldi, cin_p, cout_pad),
+                     "conv(ksplit): this batch's planes exceed the split-K kernel's 4 GiB addressing; run it in smaller batches");
         p.ksplit = ksplit; p.ks_partial = d_ks_partial;
         return launch_conv_mfma_ksplit(p, cout_pad % 128 == 0 ? 128 : 64, precision == PREC_F16X3 ? 3 : 1, ks_mode, ks_tiles, s);
       }
@@ -713,7 +727,25 @@ struct Plan {
     if (tiles > max_tiles || nk < 16) return XDET_OK;
     const int S = std::min(std::min(max_s, pow2_floor(256 / tiles)), pow2_floor(nk / 8));
     if (S < 2) return XDET_OK;
-    return L->enable_ksplit(S, 448 / S);
+    // scratch: borrowed from the plan -- bound in finish_ksplit() once every layer's need is known
+    XDET_TRY(L->enable_ksplit(1, 448 / S));
+    L->ksplit = S;
+    ks_layers.push_back({L, ks_on_aux_stream});
+    return XDET_OK;
+  }
+  struct KsLayer { ConvLayer* L; bool aux; };
+  std::vector<KsLayer> ks_layers;
+  bool ks_on_aux_stream = false;       // builders set this around layers that run on the side stream (the RPN branch)
+  float* ks_slab[2] = {nullptr, nullptr};
+  // one slab per stream (main / side), sized for the largest split-K layer on it (a slab per layer was
+  // 0.5-0.8 GB per ResNet trunk)
+  int finish_ksplit() {
+    size_t need[2] = {0, 0};
+    for (const KsLayer& k : ks_layers) need[k.aux] = std::max(need[k.aux], k.L->ks_scratch_bytes(k.L->ksplit, k.L->ks_tiles));
+    for (int a = 0; a < 2; ++a)
+      if (need[a] && !ks_slab[a]) XDET_TRY(alloc_bytes(need[a], reinterpret_cast<void**>(&ks_slab[a]), false));
+    for (const KsLayer& k : ks_layers) k.L->d_ks_partial = ks_slab[k.aux];
+    return XDET_OK;
   }
   bool fuse_sepconv = true;      // option "sepconv" = "fused" | "split"
   bool subsample_projections = true;
@@ -1143,7 +1175,9 @@ struct LightHeadNet : Plan {
     //  37 us, but costs the 256 x 256 tile at bench-size batches: 1.92 -> 2.36 ms per 128 images, -0.9 % end to end.
     //  With the fork in front of the exit flow the conv is off the critical path of a single image anyway.)
     ksplit_next = latency_ksplit && rpn_ksplit;
+    ks_on_aux_stream = rpn_side_stream;     // the RPN branch runs beside the exit flow: its own scratch slab
     XDET_TRY(add_conv("rpn_head/conv2d", ST_RPN, mid_x, L0, nullptr, /*relu_in=*/1, &hid));
+    ks_on_aux_stream = false;
     // cls (2A) and box (4A) 1x1 heads share their input: one GEMM over the concatenated filters
     const int co = 6 * A;
     std::vector<float> kc((size_t)512 * co), bc(co);
@@ -1386,6 +1420,7 @@ struct LightHeadNet : Plan {
     XDET_TRY(build_rpn());
     XDET_TRY(large_sep_spectral ? build_large_sep_spectral() : build_large_sep());
     XDET_TRY(build_head());
+    XDET_TRY(finish_ksplit());
     const int B = max_batch, A = cfg.num_anchors, R = cfg.rpn_post_nms_top_n;
     n_anchor = fmap * fmap * A;
     // A5: AnchorCreator.get_layer_anchors (anchor_manipulator.py:698-757), layer_step 16, offset .5
@@ -1709,6 +1744,7 @@ int ResNetTrunk::build() {
   XDET_TRY(add_bn_relu(bname(), x, &outb));
   for (const Op& op : ops) flops += std::max(op.flops, 0.0);
   w.clear();
+  XDET_TRY(finish_ksplit());
   built = true;
   return XDET_OK;
 }
@@ -1987,9 +2023,11 @@ int xdet_net_create(void** net, const xdet_lighthead_config* cfg) {
   return XDET_OK;
 }
 int xdet_net_set_weight(void* net, const char* name, const float* data, int ndim, const int64_t* dims) {
+  XDET_NET_KIND(net, 0, "net_set_weight");
   return set_weight(static_cast<LightHeadNet*>(net), name, data, ndim, dims);
 }
 int xdet_net_set_option(void* net, const char* key, const char* value) {
+  XDET_NET_KIND(net, 0, "net_set_option");
   LightHeadNet* n = static_cast<LightHeadNet*>(net);
   XDET_REQUIRE(n && key && value, "set_option: NULL argument");
   XDET_REQUIRE(!n->built, "set_option: the net is already built");
@@ -2040,18 +2078,21 @@ int xdet_net_set_option(void* net, const char* key, const char* value) {
   return XDET_ERR_INVALID_ARG;
 }
 int xdet_net_build(void* net) {
+  XDET_NET_KIND(net, 0, "net_build");
   XDET_REQUIRE(net, "net is NULL");
   DeviceGuard guard(static_cast<LightHeadNet*>(net)->device);
   return static_cast<LightHeadNet*>(net)->build();
 }
 int xdet_net_destroy(void* net) {
   if (!net) return XDET_OK;
+  XDET_NET_KIND(net, 0, "net_destroy");
   DeviceGuard guard(static_cast<LightHeadNet*>(net)->device);
   delete static_cast<LightHeadNet*>(net);
   return XDET_OK;
 }
 
 int xdet_net_buffer(void* net, const char* name, void** dptr, int64_t dims[4], int* ld) {
+  XDET_NET_KIND(net, 0, "net_buffer");
   LightHeadNet* n = static_cast<LightHeadNet*>(net);
   XDET_REQUIRE(n && n->built && name && dptr && dims && ld, "net_buffer: bad arguments");
   const std::string s(name);
@@ -2080,6 +2121,7 @@ int xdet_net_buffer(void* net, const char* name, void** dptr, int64_t dims[4], i
 }
 
 int xdet_net_xception_body(void* net, const float* images, int N, void* stream) {
+  XDET_NET_KIND(net, 0, "net_xception_body");
   LightHeadNet* n = static_cast<LightHeadNet*>(net);
   XDET_REQUIRE(n, "net is NULL");
   DeviceGuard guard(n->device);
@@ -2088,6 +2130,7 @@ int xdet_net_xception_body(void* net, const float* images, int N, void* stream) 
   return launch_relu_copy(n->mid_x.p, n->mid_relu, (int64_t)N * n->mid_x.per_image(), S(stream));
 }
 int xdet_net_get_rpn(void* net, int N, void* stream) {
+  XDET_NET_KIND(net, 0, "net_get_rpn");
   LightHeadNet* n = static_cast<LightHeadNet*>(net);
   XDET_REQUIRE(n, "net is NULL");
   DeviceGuard guard(n->device);
@@ -2095,6 +2138,7 @@ int xdet_net_get_rpn(void* net, int N, void* stream) {
   return n->run_stage(ST_RPN, N, S(stream));
 }
 int xdet_net_large_sep(void* net, int N, void* stream) {
+  XDET_NET_KIND(net, 0, "net_large_sep");
   LightHeadNet* n = static_cast<LightHeadNet*>(net);
   XDET_REQUIRE(n, "net is NULL");
   DeviceGuard guard(n->device);
@@ -2102,27 +2146,32 @@ int xdet_net_large_sep(void* net, int N, void* stream) {
   return n->run_stage(ST_LSEP, N, S(stream));
 }
 int xdet_net_rpn_decode(void* net, int N, void* stream) {
+  XDET_NET_KIND(net, 0, "net_rpn_decode");
   XDET_REQUIRE(net, "net is NULL");
   DeviceGuard guard(static_cast<LightHeadNet*>(net)->device);
   return static_cast<LightHeadNet*>(net)->rpn_decode(N, S(stream));
 }
 int xdet_net_get_proposals(void* net, int N, void* stream) {
+  XDET_NET_KIND(net, 0, "net_get_proposals");
   XDET_REQUIRE(net, "net is NULL");
   DeviceGuard guard(static_cast<LightHeadNet*>(net)->device);
   return static_cast<LightHeadNet*>(net)->get_proposals(N, S(stream));
 }
 int xdet_net_get_head(void* net, int N, void* stream) {
+  XDET_NET_KIND(net, 0, "net_get_head");
   XDET_REQUIRE(net, "net is NULL");
   DeviceGuard guard(static_cast<LightHeadNet*>(net)->device);
   return static_cast<LightHeadNet*>(net)->get_head(N, S(stream));
 }
 int xdet_net_head_decode(void* net, int N, void* stream) {
+  XDET_NET_KIND(net, 0, "net_head_decode");
   XDET_REQUIRE(net, "net is NULL");
   DeviceGuard guard(static_cast<LightHeadNet*>(net)->device);
   return static_cast<LightHeadNet*>(net)->head_decode(N, S(stream));
 }
 int xdet_net_bboxes_eval(void* net, int N, const int* image_shapes, const float* bbox_img, float* det_scores,
                          float* det_boxes, void* stream) {
+  XDET_NET_KIND(net, 0, "net_bboxes_eval");
   XDET_REQUIRE(net && det_scores && det_boxes, "bboxes_eval: NULL argument");
   DeviceGuard guard(static_cast<LightHeadNet*>(net)->device);
   return static_cast<LightHeadNet*>(net)->bboxes_eval(N, image_shapes, bbox_img, det_scores, det_boxes, S(stream));
@@ -2202,6 +2251,7 @@ int xdet_net_plane_scale_name(void* net, int idx, char* buf, int buflen) {
 }
 
 int xdet_net_graph_count(void* net, int* count) {
+  XDET_NET_KIND(net, 0, "net_graph_count");
   LightHeadNet* n = static_cast<LightHeadNet*>(net);
   XDET_REQUIRE(n && count, "graph_count: NULL argument");
   *count = (int)n->graphs.size();
@@ -2209,6 +2259,7 @@ int xdet_net_graph_count(void* net, int* count) {
 }
 
 int xdet_net_flops_per_image(void* net, double* backbone, double* rpn, double* large_sep, double* head) {
+  XDET_NET_KIND(net, 0, "net_flops_per_image");
   LightHeadNet* n = static_cast<LightHeadNet*>(net);
   XDET_REQUIRE(n && n->built, "net not built");
   double f[5] = {0, 0, 0, 0, 0};
@@ -2265,9 +2316,11 @@ int xdet_resnet_create(void** net, int image_size, int max_batch) {
   return XDET_OK;
 }
 int xdet_resnet_set_weight(void* net, const char* name, const float* data, int ndim, const int64_t* dims) {
+  XDET_NET_KIND(net, 1, "resnet_set_weight");
   return set_weight(static_cast<ResNetTrunk*>(net), name, data, ndim, dims);
 }
 int xdet_resnet_build(void* net) {
+  XDET_NET_KIND(net, 1, "resnet_build");
   XDET_REQUIRE(net, "net is NULL");
   DeviceGuard guard(static_cast<ResNetTrunk*>(net)->device);
   return static_cast<ResNetTrunk*>(net)->build();
@@ -2286,6 +2339,7 @@ int xdet_resnet_forward(void* net, const float* images, int N, float* out_nhwc, 
   return XDET_OK;
 }
 int xdet_resnet_forward_graph(void* net, const float* images, int N, float* out_nhwc, void* stream) {
+  XDET_NET_KIND(net, 1, "resnet_forward_graph");
   ResNetTrunk* r = static_cast<ResNetTrunk*>(net);
   XDET_REQUIRE(r && r->built && images, "resnet_forward: bad arguments");
   XDET_REQUIRE(N > 0 && N <= r->max_batch, "batch must be in 1..max_batch");
@@ -2338,12 +2392,14 @@ int xdet_resnet_calibrate(void* net, const float* images, int N, int* n_scaled, 
   return r->calibrate_planes(N, S(stream), n_scaled, [&](hipStream_t st) { return xdet_resnet_forward(net, images, N, nullptr, st); });
 }
 int xdet_resnet_out_shape(void* net, int* Ho, int* Wo, int* C) {
+  XDET_NET_KIND(net, 1, "resnet_out_shape");
   ResNetTrunk* r = static_cast<ResNetTrunk*>(net);
   XDET_REQUIRE(r && r->built, "resnet not built");
   *Ho = r->outb.H; *Wo = r->outb.W; *C = r->outb.C;
   return XDET_OK;
 }
 int xdet_resnet_flops_per_image(void* net, double* flops) {
+  XDET_NET_KIND(net, 1, "resnet_flops_per_image");
   ResNetTrunk* r = static_cast<ResNetTrunk*>(net);
   XDET_REQUIRE(r && r->built && flops, "resnet not built");
   *flops = r->flops;
@@ -2351,6 +2407,7 @@ int xdet_resnet_flops_per_image(void* net, double* flops) {
 }
 int xdet_resnet_destroy(void* net) {
   if (!net) return XDET_OK;
+  XDET_NET_KIND(net, 1, "resnet_destroy");
   DeviceGuard guard(static_cast<ResNetTrunk*>(net)->device);
   delete static_cast<ResNetTrunk*>(net);
   return XDET_OK;

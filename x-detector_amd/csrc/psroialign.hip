@@ -397,19 +397,24 @@ int launch_psroialign(const float* feat, const float* rois, float* pooled, int32
   // NCHW (the reference op's layout, light_head_rfcn_eval.py:85): neighbouring channels are H * W floats apart, so every
   // lane of a gather touches its own cache line (553 us for 64 x 300 ROIs of the mixed set against 120 us for the NHWC
   // form).  With enough ROIs it pays to transpose the map once into a stream-ordered scratch allocation and run the NHWC
-  // two-channel kernel on it: same values, same arithmetic.  (XDET_PSROI=direct_nchw, an odd bank, or a failed
-  // allocation -- e.g. inside a stream capture -- keep the direct form.)
+  // two-channel kernel on it: same values, same arithmetic.  (XDET_PSROI=direct_nchw, an odd bank, a stream that is being
+  // captured -- an allocation there would become a graph node, and a failed runtime call would invalidate the capture --
+  // or a failed allocation keep the direct form.)
   static const bool direct_nchw = getenv("XDET_PSROI") && !strcmp(getenv("XDET_PSROI"), "direct_nchw");
-  if (layout == 0 && !direct_nchw && (C / (gw * gh)) % 2 == 0 && C % 2 == 0 && (int64_t)R * C >= (int64_t)4 * H * W) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
+  if (layout == 0 && !direct_nchw && cap == hipStreamCaptureStatusNone && (C / (gw * gh)) % 2 == 0 && C % 2 == 0 &&
+      (int64_t)R * C >= (int64_t)4 * H * W) {
     float* scratch = nullptr;
     const size_t bytes = (size_t)N * H * W * C * sizeof(float);
     if (hipMallocAsync(reinterpret_cast<void**>(&scratch), bytes, s) == hipSuccess && scratch) {
       hipLaunchKernelGGL(psroi_nchw_to_nhwc_kernel, dim3((unsigned)cdiv(H * W, 32), (unsigned)cdiv(C, 32), (unsigned)N), dim3(256), 0, s,
                          feat, scratch, C, H * W);
-      const int rc = launch_psroialign(scratch, rois, pooled, index, N, C, H, W, R, gw, gh, use_max, 1, C, out_ld,
-                                       rois_are_corners, s);
+      const hipError_t te = hipGetLastError();           // the transpose's own launch error, before anything else is issued
+      int rc = te == hipSuccess ? XDET_OK : hip_fail(te, "psroi_nchw_to_nhwc_kernel launch", __FILE__, __LINE__);
+      if (rc == XDET_OK)
+        rc = launch_psroialign(scratch, rois, pooled, index, N, C, H, W, R, gw, gh, use_max, 1, C, out_ld, rois_are_corners, s);
       (void)hipFreeAsync(scratch, s);
-      XDET_LAUNCH_CHECK();
       return rc;
     }
     (void)hipGetLastError();                             // no scratch: the direct form below

@@ -100,9 +100,11 @@ class Conv2D(object):
                                      _host(sh) if sh is not None else None, 1 if relu else 0))
         self.handle = h
 
-    def set_ksplit(self, ksplit, mode=0, max_parallel_tiles=448):
+    def set_ksplit(self, ksplit, mode=0, max_parallel_tiles=None):
         """fixed split of the reduction (xdet_conv_set_ksplit): the planes path then runs on the split-K kernel;
         mode 0 = by grid size, 1 = ranges in parallel, 2 = one workgroup per tile -- all bit-identical."""
+        if max_parallel_tiles is None:       # the parallel form is chosen for grids up to 448 (tile, range) workgroups
+            max_parallel_tiles = 448 // max(int(ksplit), 1)
         check(lib().xdet_conv_set_ksplit(self.handle, int(ksplit), int(mode), int(max_parallel_tiles)))
 
     def __call__(self, x, residual=None, relu_in=False, stream=None, planes=False, staged_tile=False, x8_exp=None):
