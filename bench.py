@@ -106,6 +106,11 @@ def parse():
                     help='images per call of the C++ CPU baseline (0 = one per hardware thread, at most 256: the baseline '
                          'runs image-parallel, oracle/lighthead_cpu.cpp)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='time budget of the CPU-baseline sample')
+    ap.add_argument('--stagger', type=float, default=0.0,
+                    help='EXPERIMENT (profiles/NOTES_r05.md): phase-shift the second sub-batch stream by this fraction of a '
+                         'step (it first runs a forward over that fraction of its images, inside the timed region), so that '
+                         'its bandwidth-bound entry flow meets the first stream\'s GEMM-bound middle flow; compare '
+                         'median_ms_per_step')
     ap.add_argument('--ops', action='store_true', help='also print the per-op table to stderr')
     ap.add_argument('--no-parity', action='store_true', help='skip the live f16x3-vs-f32 GPU cross-check')
     ap.add_argument('--no-roofline', action='store_true', help='skip the instrumented eager repeat')
@@ -485,6 +490,8 @@ def main():
     t0 = time.perf_counter()
     evs[0].record(net.stream)
     for k in range(K):
+        if k == 0 and args.stagger > 0 and args.workload == 'lighthead' and len(nets) > 1:
+            nets[1].forward_device(max(1, int(sb * args.stagger)), use_graph=False)
         step()
         evs[k + 1].record(net.stream)
     sync_all()

@@ -14,6 +14,9 @@ $B --no-parity --ways 1 --batch 128 > $OUT/${TAG}_bench_1way_b128.json 2>/dev/nu
 $B --no-parity --batch 128 > $OUT/${TAG}_bench_2x64.json 2>/dev/null
 $B --no-parity --batch 1 --steps 300 --warmup 30 --sustain-seconds 0 > $OUT/${TAG}_bench_b1.json 2>/dev/null
 $B --no-parity --batch 1 --steps 300 --warmup 30 --sustain-seconds 0 --ksplit all > $OUT/${TAG}_bench_b1_ksplit_all.json 2>/dev/null
+# the reference's own operating point (light_head_rfcn_eval.py:109-111,212): rpn_post_nms_top_n = 1000, one image at a time
+$B --no-parity --proposals 1000 --batch 1 --steps 300 --warmup 30 > $OUT/${TAG}_bench_R1000_b1.json 2>/dev/null
+$B --no-parity --proposals 1000 > $OUT/${TAG}_bench_R1000.json 2>/dev/null
 $B --no-parity --batch 8 --ways 1 --steps 100 --warmup 20 > $OUT/${TAG}_bench_b8.json 2>/dev/null
 $B --no-parity --workload resnet50 --batch 8 --steps 100 --warmup 20 --sustain-seconds 0 --ops > $OUT/${TAG}_bench_resnet50_b8.json 2> $OUT/${TAG}_bench_resnet50_b8_ops.txt
 $B --no-parity --workload resnet50 --batch 8 --resnet-ways 1 --steps 100 --warmup 20 --sustain-seconds 0 > $OUT/${TAG}_bench_resnet50_b8_1way.json 2>/dev/null

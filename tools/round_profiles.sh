@@ -16,6 +16,9 @@ python bench.py --no-cpu-baseline --no-parity --comm --voc-stream > $O/profiles/
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_b1 -- python $GRAFT_REPO_ROOT/bench.py --batch 1 --serial-rpn --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-parity --sustain-seconds 0 > $O/${TAG}_b1.log 2>&1)
 cp "$(find $O/${TAG}_b1 -name '*kernel_stats.csv' | head -1)" $O/profiles/${TAG}_batch1_kernel_stats.csv
 python tools/trace_step.py $O/${TAG}_b1 2 > $O/profiles/${TAG}_batch1_step_dispatches.txt
+# the reference's operating point: 1000 proposals, one stream of 128 images -- kernel stats (the head and PsRoiAlign grow 3.3x)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_R1000 -- python $GRAFT_REPO_ROOT/bench.py --proposals 1000 --ways 1 --batch 128 --serial-rpn --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-parity --sustain-seconds 0 > $O/${TAG}_R1000.log 2>&1)
+cp "$(find $O/${TAG}_R1000 -name '*kernel_stats.csv' | head -1)" $O/profiles/${TAG}_R1000_kernel_stats.csv
 # BASELINE config 2 and config 5's shape: stats + PMC summaries, as the default configuration's
 bash tools/collect_profile.sh ${TAG}_resnet_b8 --workload resnet50 --batch 8 --resnet-ways 1 > /dev/null 2>&1
 (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_rn -- python $GRAFT_REPO_ROOT/bench.py --workload resnet50 --batch 8 --resnet-ways 1 --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --sustain-seconds 0 > $O/${TAG}_rn.log 2>&1)

@@ -54,9 +54,18 @@ typedef unsigned short u16;
 // (tools/ubench/mfma_scale_semantics.hip) -- instead of four f16 MFMAs: 2 + 1 instead of 6 matrix instructions per block and
 // step.  Per accumulator the order is hi*hi (first 16 channels), hi*hi (second 16), cross -- in every tile shape, so results do
 // not depend on the kernel a batch size selects.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE, bool PW = false, bool FOLD = false, bool X8 = false>
+// GBUF (round 5; multi-tap layers whose planes and weights stay below 4 GiB -- the RPN 3x3 conv, the direct large-separable
+// convs): the generic form's DMA sources as raw buffer loads too.  A tap's window position still has to be computed per
+// lane and K step (the blocked plane layout is not linear in the pixel), but as ONE 32-bit offset -- out-of-image taps are
+// an out-of-range offset (zero fill) instead of a select between a 64-bit address and the zero page, the channel block and
+// the weights' K block ride in the scalar offset, and (cc, ky, kx) advance incrementally instead of by division: ~22 VALU
+// + ~25 SALU per K step next to the 48 MFMAs where the pointer form spends ~55 + ~70.  Same bytes into the same LDS
+// places: bit-identical.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE, bool PW = false, bool FOLD = false, bool X8 = false,
+          bool GBUF = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(ConvParams p_in) {
   static_assert(NSTAGE == 2, "two LDS stages");
+  static_assert(!(GBUF && PW), "GBUF is the buffer form of the NON-pointwise layers");
   static_assert(!X8 || (PW && NSPLIT == 3 && !FOLD), "x8: pointwise f16x3 layers only");
   constexpr int NW = WAVES_M * WAVES_N;          // waves per workgroup (4 or 8)
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -141,6 +150,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
   // byte offsets of this wave's pieces
   __amdgpu_buffer_rsrc_t r_ah, r_al, r_bh, r_bl;
   unsigned a_vo[A_IT], b_vo[B_IT];
+  int g_cc = 0, g_ky = 0, g_kx = 0, g_tap = 0;   // GBUF: (channel block, tap) of the NEXT issue() -- calls come with kt = 0, 1, 2, ...
+  if (GBUF) {
+    const unsigned a_bytes = (unsigned)(((size_t)(((size_t)p.N * p.H * p.W + 15) >> 4) * c32n) << 10);
+    const unsigned b_bytes = (unsigned)((size_t)nk * p.Cout_pad * 64);
+    r_ah = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.in_hi), 0, (int)a_bytes, 0x00020000);
+    r_al = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(NSPLIT > 1 ? p.in_lo : p.in_hi), 0, (int)a_bytes, 0x00020000);
+    r_bh = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.wt_hi), 0, (int)b_bytes, 0x00020000);
+    r_bl = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(NSPLIT > 1 ? p.wt_lo : p.wt_hi), 0, (int)b_bytes, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < B_IT; ++q) b_vo[q] = (unsigned)(boff[q] * 2);
+  }
   if (PW) {
     const unsigned a_bytes = (unsigned)(((size_t)((p.M + 15) >> 4) * c32n) << 10);
     const unsigned b_bytes = (unsigned)((size_t)nk * p.Cout_pad * 64);
@@ -181,6 +201,36 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
         if (NSPLIT > 1)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(r_bl, (__attribute__((address_space(3))) void*)(Bl + (wave * B_IT + q) * 16 * ROWB),
                                                    16, (int)b_vo[q], (int)b_so, 0, 0);
+      }
+    } else if (GBUF) {
+      // (same K order as the pointer form below: channel block outer, tap inner)
+      const int dy = g_ky * p.dil, dx = g_kx * p.dil;
+      const unsigned a_so = (unsigned)g_cc << 10;
+      const unsigned b_so = (unsigned)(g_tap * (p.Cin_p >> 5) + g_cc) * (unsigned)p.Cout_pad * 64u;
+#pragma unroll
+      for (int q = 0; q < A_IT; ++q) {
+        const int iy = iy0[q] + dy, ix = ix0[q] + dx;
+        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const unsigned pix = (unsigned)(pbase[q] + iy * p.W + ix);
+        const unsigned vo = ok ? (((pix >> 4) * c32n) << 10) + (((pix & 15) << 5) + (unsigned)achunk[q]) * 2u : 0xffffffffu;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_ah, (__attribute__((address_space(3))) void*)(Ah + (wave * A_IT + q) * 16 * ROWB),
+                                                 16, (int)vo, (int)a_so, 0, 0);
+        if (NSPLIT > 1)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_al, (__attribute__((address_space(3))) void*)(Al + (wave * A_IT + q) * 16 * ROWB),
+                                                   16, (int)vo, (int)a_so, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < B_IT; ++q) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_bh, (__attribute__((address_space(3))) void*)(Bh + (wave * B_IT + q) * 16 * ROWB),
+                                                 16, (int)b_vo[q], (int)b_so, 0, 0);
+        if (NSPLIT > 1)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_bl, (__attribute__((address_space(3))) void*)(Bl + (wave * B_IT + q) * 16 * ROWB),
+                                                   16, (int)b_vo[q], (int)b_so, 0, 0);
+      }
+      ++g_tap;
+      if (++g_kx == p.KW) {
+        g_kx = 0;
+        if (++g_ky == p.KH) { g_ky = 0; g_tap = 0; ++g_cc; }
       }
     } else {
     // K order: channel chunk outer, filter tap inner.  The KH*KW shifted views of one 32-channel
@@ -674,7 +724,17 @@ static int launch_deep(const ConvParams& p, hipStream_t s) {
   return XDET_OK;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE = 2, bool PW = false, bool X8 = false>
+// multi-tap layers (the 256 x 256 tile's: the RPN conv, the direct large-separable convs) below 4 GiB: the generic form with
+// buffer loads (GBUF); XDET_CONV_GBUF=0: the pointer form, for A/B runs
+static bool gbuf_eligible(const ConvParams& p) {
+  static const bool off = getenv("XDET_CONV_GBUF") && !strcmp(getenv("XDET_CONV_GBUF"), "0");
+  if (off || p.group_rows != 0) return false;
+  const size_t a_bytes = ((((size_t)p.N * p.H * p.W + 15) >> 4) * (size_t)(p.ldi >> 5)) << 10;
+  const size_t b_bytes = (size_t)(p.Kp / 32) * p.Cout_pad * 64;
+  return a_bytes < ((size_t)1 << 32) && b_bytes < ((size_t)1 << 32) && p.Kp == p.Cin_p * p.KH * p.KW;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSPLIT, int NSTAGE = 2, bool PW = false, bool X8 = false, bool GBUF = false>
 static int launch_d(const ConvParams& p, hipStream_t s) {
   if (!PW && pw_eligible(p)) return launch_d<BM, BN, WAVES_M, WAVES_N, NSPLIT, NSTAGE, true>(p, s);
   if constexpr (PW && !X8 && NSPLIT == 3) {
@@ -682,7 +742,10 @@ static int launch_d(const ConvParams& p, hipStream_t s) {
   }
   XDET_REQUIRE(X8 || !p.x8, "conv(dma): x8 planes need a pointwise f16x3 layer below 4 GiB");
   constexpr size_t lds = (size_t)NSTAGE * (2 * BM + 2 * BN) * 32 * sizeof(u16);
-  auto kern = conv_dma_f16_kernel<BM, BN, WAVES_M, WAVES_N, NSPLIT, NSTAGE, PW, false, X8>;
+  if constexpr (!PW && !X8 && !GBUF && BM == 256 && BN == 256) {
+    if (gbuf_eligible(p)) return launch_d<BM, BN, WAVES_M, WAVES_N, NSPLIT, NSTAGE, false, false, true>(p, s);
+  }
+  auto kern = conv_dma_f16_kernel<BM, BN, WAVES_M, WAVES_N, NSPLIT, NSTAGE, PW, false, X8, GBUF>;
   static DeviceOnce once;
   XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
   dim3 grid((unsigned)(cdiv(cdiv(p.M, BM), 8) * 8 * (p.Cout_pad / BN)));
