@@ -628,6 +628,12 @@ def main():
                                                                 '(C-ABI, overlapped with the next forward)'
                                                                 if comm is not None else ''),
                        'weights': 'seeded random init (no checkpoint exists)', 'graph_replay': bool(use_graph)},
+            # device memory of ONE sub-batch net (weights + workspace) and the bytes of tensors placed into recycled blocks
+            # (option "workspace" = "reuse", include/xdet.h xdet_net_memory)
+            'memory': ({'net_instances': len(nets), 'images_per_instance': sb,
+                        'allocated_gb_per_instance': round(net.memory()['allocated_bytes'] / 1e9, 3),
+                        'recycled_gb_per_instance': round(net.memory()['recycled_bytes'] / 1e9, 3)}
+                       if args.workload == 'lighthead' else None),
             'device_ms_per_step': round(dev_ms / K, 3),
             'median_ms_per_step': round(float(np.median(step_ms)), 3),
             'min_ms_per_step': round(float(np.min(step_ms)), 3),

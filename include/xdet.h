@@ -238,6 +238,7 @@ int xdet_net_set_weight(void* net, const char* name, const float* data_host, int
  *   "ksplit" = "on" | "off" | "all": the 2048 -> 25 head GEMM (a single image: 3 tiles against 64 K steps) on the fixed
  *   split-K kernel (on, the default; a layer constant: results identical at every batch size), nothing (off), or the RPN
  *   3x3 conv as well (all: 32 tiles against 207 K steps; faster for one image, 0.9 % slower at bench-size batches).
+ *   "workspace" = "reuse" | "ssa": see xdet_net_memory.
  *   "check_range" = "off" | "on": after each forward validate everything that is turned into f16 against the f16 range --
  *   every split plane (no inf / NaN in the hi plane; the planes hold x * 2^-e after xdet_net_calibrate), the f32 input
  *   of a register-split conv (|x| <= 65504) and of a fused separable block (relu?(x) * sum|taps| * 2^-e <= 65504) -- and
@@ -285,6 +286,12 @@ int xdet_net_plane_scale_name(void* net, int idx, char* buf, int buflen);
  * the light-head net (net/xception_body.py:220-234, blocks 5-14). */
 int xdet_net_x8_planes(void* net, int* n_on);
 int xdet_net_graph_count(void* net, int* count);
+/* Device memory of the net's workspace and weights in bytes (everything the plan allocated), and how many bytes of
+ * tensors were placed into blocks recycled from dead tensors (option "workspace" = "reuse", the default: a builder hands a
+ * tensor's block back once its last consumer is planned and a later tensor of exactly the same size takes it over --
+ * the middle flow's 24 x 2 tensors live in a handful of blocks; "ssa": one block per tensor, which option check_range
+ * selects by itself because its validation pass reads every tensor after the forward). */
+int xdet_net_memory(void* net, size_t* allocated_bytes, size_t* recycled_bytes);
 /* per-kernel accounting of the last build: total dense FLOPs (2*MAC, unpadded) of one image */
 int xdet_net_flops_per_image(void* net, double* backbone, double* rpn, double* large_sep, double* head);
 

@@ -398,3 +398,40 @@ def test_cross_fp8_is_opt_in_bounded_and_batch_invariant(oracle, lh_weights):
         det.forward(imgs[i:i + 1])
         for k in both:
             assert np.array_equal(det.buffer(k, 1).numpy()[0], both[k][i]), (k, i)
+
+
+def test_workspace_reuse_changes_memory_not_results(lh_weights):
+    """option "workspace": 'reuse' (default) hands a dead tensor's block to a later tensor of the same size -- the middle
+    flow's 24 x 2 tensors live in a handful of blocks -- 'ssa' keeps one block per tensor.  Same detections bit for bit,
+    less memory; check_range (whose validation pass reads every tensor after the forward) selects 'ssa' by itself."""
+    from xdet import weights as W
+    from xdet.model import LightHeadDetector
+    from xdet.runtime import set_precision
+    imgs = W.synthetic_images(3, 480, seed=77)
+    set_precision('f16x3')
+    try:
+        reuse = LightHeadDetector(lh_weights, image_size=480, max_batch=3, rpn_post_nms_top_n=300)
+        ssa = LightHeadDetector(lh_weights, image_size=480, max_batch=3, rpn_post_nms_top_n=300, workspace='ssa')
+        checked = LightHeadDetector(lh_weights, image_size=480, max_batch=3, rpn_post_nms_top_n=300, check_range=True)
+    finally:
+        set_precision('f32')
+    a = reuse.forward(imgs, use_graph=True)
+    b = ssa.forward(imgs)
+    c = checked.forward(imgs)
+    for i in range(3):
+        for k in range(1, 21):
+            assert np.array_equal(a[i][k][0], b[i][k][0]) and np.array_equal(a[i][k][1], b[i][k][1]), (i, k)
+            assert np.array_equal(a[i][k][0], c[i][k][0]) and np.array_equal(a[i][k][1], c[i][k][1]), (i, k)
+    for name in ('mid_x', 'out', 'feat'):                 # the named buffers are never recycled
+        assert np.array_equal(reuse.buffer(name, 3).numpy(), ssa.buffer(name, 3).numpy()), name
+    mr, ms, mc = reuse.memory(), ssa.memory(), checked.memory()
+    print('workspace per image: reuse %.3f GB (recycled %.3f GB), ssa %.3f GB'
+          % (mr['allocated_bytes'] / 3e9, mr['recycled_bytes'] / 3e9, ms['allocated_bytes'] / 3e9))
+    assert ms['recycled_bytes'] == 0 and mc['recycled_bytes'] == 0
+    assert mr['recycled_bytes'] > 0 and mr['allocated_bytes'] < 0.85 * ms['allocated_bytes']
+    # a calibration measures every planes tensor right behind its producer (its block may be another tensor's by the end
+    # of the forward): the exponents it finds are those of the one-block-per-tensor net
+    nr = reuse.calibrate(imgs)
+    ns = ssa.calibrate(imgs)
+    assert nr == ns
+    assert reuse.plane_scales() == ssa.plane_scales()

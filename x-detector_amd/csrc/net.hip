@@ -467,17 +467,66 @@ struct Plan {
   ~Plan() {
     for (void* p : allocs) (void)hipFree(p);
   }
+  size_t allocated_bytes = 0;
   int alloc_bytes(size_t bytes, void** out, bool zero = true) {
     XDET_HIP(hipMalloc(out, std::max<size_t>(bytes, 256)));
+    allocated_bytes += std::max<size_t>(bytes, 256);
     if (zero) XDET_HIP(hipMemset(*out, 0, std::max<size_t>(bytes, 256)));
     allocs.push_back(*out);
     return XDET_OK;
   }
+  // ---- workspace ----
+  // One block per intermediate tensor, EXCEPT that a builder may hand a tensor's block back once its last consumer has been
+  // planned (release_f32 / release_planes); a later tensor that fits takes it over (best fit, at most 2x its size): the
+  // middle flow's 24 x (planes pair + f32 block output) live in a handful of blocks, the entry flow's blocks serve the
+  // exit flow and the head.
+  // Ops of one stream run in plan order, so a recycled block is never live twice; the side stream (RPN branch) has its own
+  // pool.  Named buffers of the graph-builder API (mid_x, out, feat, ...) are never released.  Option "workspace" = "reuse"
+  // (default) | "ssa"; check_range needs every tensor intact after the forward and turns reuse off.
+  bool reuse_workspace = true;
+  std::map<void*, size_t> ws_bytes;                      // blocks handed out by take() that are live
+  std::multimap<size_t, void*> ws_free[2][2];            // released blocks by size, per stream pool and kind (f32 / planes)
+  std::map<void*, int> ws_kind;
+  int ws_pool = 0;                                       // 0 = main stream, 1 = side stream
+  size_t ws_recycled_bytes = 0;
+  // f32 tensors: best fit, at most twice the tensor's size (consumers address a tensor by its own shape -- buffer
+  // descriptors are sized to the tensor, not to the block -- so what lies behind it is never interpreted; padded channels
+  // are written by every producer).  Planes: a released planes block of EXACTLY the same size only -- the last 16-pixel
+  // group of a planes tensor has pixel slots nobody writes, which the calibration's measurement and the GEMM's discarded
+  // tail rows do read: they must hold what a tensor of the same shape left there (finite f16), not another tensor's bytes.
+  int take(size_t bytes, void** out, int kind = 0) {
+    bytes = std::max<size_t>(bytes, 256);
+    if (reuse_workspace) {
+      auto& fl = ws_free[ws_pool][kind];
+      auto it = kind == 1 ? fl.find(bytes) : fl.lower_bound(bytes);
+      if (it != fl.end() && it->first <= 2 * bytes) {
+        *out = it->second;
+        const size_t block = it->first;
+        fl.erase(it);
+        ws_bytes[*out] = block;                          // (released again under its own size)
+        ws_recycled_bytes += bytes;
+        return XDET_OK;
+      }
+    }
+    XDET_TRY(alloc_bytes(bytes, out));
+    ws_bytes[*out] = bytes;
+    ws_kind[*out] = kind;
+    return XDET_OK;
+  }
+  void give(void* p) {
+    if (!reuse_workspace || !p) return;
+    auto it = ws_bytes.find(p);
+    if (it == ws_bytes.end()) return;                    // not a take() block, or released already
+    ws_free[ws_pool][ws_kind[p]].insert({it->second, p});
+    ws_bytes.erase(it);
+  }
+  void release_f32(const Buf& b) { give(b.p); }
+  void release_planes(const Buf& b) { give(b.hi); give(b.lo); }
   int new_buf(int H, int W, int C, Buf* b) {
     b->H = H; b->W = W; b->C = C;
     b->ld = C <= 4 ? 4 : round_up(C, 32);
     // +128 floats of slack: the conv loader may read a full 32-channel slice of the last pixel
-    XDET_TRY(alloc_bytes(((size_t)max_batch * b->per_image() + 128) * sizeof(float), reinterpret_cast<void**>(&b->p)));
+    XDET_TRY(take(((size_t)max_batch * b->per_image() + 128) * sizeof(float), reinterpret_cast<void**>(&b->p)));
     f32_bufs.emplace_back(b->p, b->per_image());
     return XDET_OK;
   }
@@ -538,7 +587,9 @@ struct Plan {
     bool x8_cand = false, x8_ok = false, x8_on = false;
     int x8_exp = 0;
     float last_max = 0.f;                             // largest magnitude of the operand in the last calibration pass
+    int op_index = -1;                                // measured right behind this op of the plan (-1: after the whole forward)
   };
+  std::function<int(int, hipStream_t)> after_op;      // calibration hook: called by run_stage behind every op
   bool cross8 = false;                                // option "cross" = "f16" | "fp8"
   bool plane_x8(int pidx, int* e) const {
     const bool on = pidx >= 0 && pscales[pidx].x8_ok && pscales[pidx].x8_on;
@@ -593,12 +644,23 @@ struct Plan {
     int pass = 0;
     for (; pass < max_passes && rc == XDET_OK; ++pass) {
       if ((rc = hipMemsetAsync(d_max, 0, pscales.size() * sizeof(unsigned), s) == hipSuccess ? XDET_OK : XDET_ERR_HIP) != XDET_OK) break;
-      if ((rc = run(s)) != XDET_OK) break;
-      for (size_t i = 0; i < pscales.size() && rc == XDET_OK; ++i) {
+      // tensors with a producing op in the plan are measured right behind it, on the stream it ran on (their workspace
+      // block may belong to another tensor by the end of the forward); the rest after the whole forward
+      auto measure = [&](size_t i, hipStream_t st) {
         const PlaneScale& p = pscales[i];
-        rc = p.hi ? launch_absmax_planes(p.hi, p.halves(N), d_max + i, s)
-                  : launch_absmax_f32(p.src, (int64_t)N * (int64_t)p.src_per_image, p.src_relu, d_max + i, s);
-      }
+        return p.hi ? launch_absmax_planes(p.hi, p.halves(N), d_max + i, st)
+                    : launch_absmax_f32(p.src, (int64_t)N * (int64_t)p.src_per_image, p.src_relu, d_max + i, st);
+      };
+      after_op = [&](int op, hipStream_t st) {
+        for (size_t i = 0; i < pscales.size(); ++i)
+          if (pscales[i].op_index == op) XDET_TRY(measure(i, st));
+        return (int)XDET_OK;
+      };
+      rc = run(s);
+      after_op = nullptr;
+      if (rc != XDET_OK) break;
+      for (size_t i = 0; i < pscales.size() && rc == XDET_OK; ++i)
+        if (pscales[i].op_index < 0) rc = measure(i, s);
       if (rc != XDET_OK) break;
       if (hipMemcpyAsync(h_max.data(), d_max, h_max.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess ||
           hipStreamSynchronize(s) != hipSuccess) { rc = XDET_ERR_HIP; break; }
@@ -668,11 +730,13 @@ struct Plan {
   int new_planes(Buf* b) {
     // [pixels/16][ld/32][16][32]: the pixel count is rounded up to a whole 16-pixel group
     const size_t bytes = ((size_t)cdiv((int64_t)max_batch * b->H * b->W, 16) * 16 * b->ld + 256) * sizeof(unsigned short);
-    XDET_TRY(alloc_bytes(bytes, reinterpret_cast<void**>(&b->hi)));
-    XDET_TRY(alloc_bytes(bytes, reinterpret_cast<void**>(&b->lo)));
+    XDET_TRY(take(bytes, reinterpret_cast<void**>(&b->hi), 1));
+    XDET_TRY(take(bytes, reinterpret_cast<void**>(&b->lo), 1));
     planes_bufs.push_back({b->hi, (int64_t)b->H * b->W, b->ld});
     PlaneScale ps;
     ps.hi = b->hi;
+    ps.op_index = (int)ops.size();   // every caller pushes the producing op next: a calibration measures the planes right
+                                     // behind it (their block may be recycled by a later tensor)
     const int64_t pix = (int64_t)b->H * b->W;
     const int ldp = b->ld;
     ps.halves = [pix, ldp](int N) { return cdiv((int64_t)N * pix, 16) * 16 * ldp; };
@@ -754,6 +818,7 @@ struct Plan {
   int pool_fuse_min_pixels = 100 * 100;   // ... for the 237 x 237 block (+0.8 %) and the 119 x 119 one (time-neutral, -0.9 GB)
   int add_conv(const std::string& name, int stage, const Buf& in_, ConvLayer* L, const Buf* res, int relu_in, Buf* out) {
     Buf in = in_;
+    bool own_split = false;
     const int emit = L->precision == PREC_F32 ? 0 : emit_planes_next;
     const bool folded_bn = emit && !emit_bn_scale.empty();
     if (folded_bn) XDET_TRY(L->set_planes_bn(emit_bn_scale, emit_bn_shift));
@@ -774,6 +839,7 @@ struct Plan {
         XDET_TRY(add_split(name + "/split_in", stage, in_, relu_in, &sp));
         in = sp;
         relu_in = 0;
+        own_split = true;                          // these planes have this conv as their only reader
       }
     } else {
       XDET_REQUIRE(!in.no_f32, "plan: this tensor exists as planes only");
@@ -819,6 +885,7 @@ struct Plan {
                                        z, o.hi, o.lo, (o.planes_relu || folded_bn) ? 1 : 0, aff ? L->d_pl_scale : nullptr,
                                        aff ? L->d_pl_shift : nullptr, 0, x8, x8_exp);
                    }});
+    if (own_split) release_planes(in);
     return XDET_OK;
   }
   // `planes_only`: the single consumer is a pointwise conv on the split path -> write f16 planes, no f32
@@ -899,7 +966,9 @@ struct Plan {
       ops.push_back({name + "/subsample_split", stage, 0.0, [=](int N, hipStream_t s) {
                        return launch_split_f32_subsample2(i.p, o.hi, o.lo, N, i.H, i.W, i.ld, s, pre_sc, pre_sh, pmul(o.pidx));
                      }});
-      return add_conv(name, stage, sub, L, res, 0, out);
+      XDET_TRY(add_conv(name, stage, sub, L, res, 0, out));
+      release_planes(sub);                         // read by this projection only
+      return XDET_OK;
     }
     XDET_TRY(L->init(k, k, in.C, cout, stride, 1, pad_mode, pad_expl, pad_expl, kt->v.data(), scp, shp, relu_out));
     // 3x3 VALID over 32 channels (block1_conv2): the input tile is staged in LDS once and the nine taps are shifted
@@ -955,6 +1024,7 @@ struct Plan {
         ps.bound = bound;
         ps.apply.push_back([D](int e) { return D->set_out_exp(e); });
         ps.apply.push_back([L](int e) { return L->set_in_exp(e); });
+        ps.op_index = (int)ops.size();               // the fused op is pushed next: its input is intact right behind it
         pscales.push_back(ps);
       }
       if (pool_res && fuse_hpool && in.H * in.W >= pool_fuse_min_pixels) {
@@ -975,6 +1045,7 @@ struct Plan {
         ops.push_back({name + "/vpool_add", stage, 0.0, [=](int N, hipStream_t s) {
                          return launch_maxpool_v3s2_add(h.p, rp, o.p, N, h.H, h.W, h.C, h.ld, Ho, pt, s);
                        }});
+        release_f32(hp);
         return XDET_OK;
       }
       Buf full;
@@ -985,14 +1056,26 @@ struct Plan {
                        return launch_sepconv_fused(i.p, D->d_w, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale, L->d_shift, o.p, N,
                                                    i.H, i.W, i.ld, o.ld, L->cout_pad, pre_relu, L->relu_out, s);
                      }});
-      return pool_res ? add_pool(name + "/pool_add", stage, full, pool_res, out) : XDET_OK;
+      if (!pool_res) return XDET_OK;
+      XDET_TRY(add_pool(name + "/pool_add", stage, full, pool_res, out));
+      release_f32(full);
+      return XDET_OK;
     }
     Buf t;
     XDET_TRY(add_dw(name + "/depthwise", stage, in, D, pre_relu, &t, /*planes_only=*/L->dma_capable()));
-    if (!pool_res) return add_conv(name + "/pointwise", stage, t, L, res, 0, out);
+    if (!pool_res) {
+      XDET_TRY(add_conv(name + "/pointwise", stage, t, L, res, 0, out));
+      release_planes(t);                           // the depthwise result: read by its pointwise conv only
+      release_f32(t);
+      return XDET_OK;
+    }
     Buf full;
     XDET_TRY(add_conv(name + "/pointwise", stage, t, L, res, 0, &full));
-    return add_pool(name + "/pool_add", stage, full, pool_res, out);
+    release_planes(t);
+    release_f32(t);
+    XDET_TRY(add_pool(name + "/pool_add", stage, full, pool_res, out));
+    release_f32(full);
+    return XDET_OK;
   }
   int run_stage(int stage, int N, hipStream_t s) {
     for (size_t i = 0; i < ops.size(); ++i) {
@@ -1010,6 +1093,7 @@ struct Plan {
       } else {
         XDET_TRY(op.run(N, s));
       }
+      if (after_op) XDET_TRY(after_op((int)i, s));
     }
     return XDET_OK;
   }
@@ -1125,6 +1209,9 @@ struct LightHeadNet : Plan {
       // the stencil's 192 VALU instructions per chunk when the block runs as the fused kernel) -- the same values
       XDET_TRY(sep_bn(b.s1, eps, ST_BODY, x, b.c, b.first_relu, 1, /*relu_out=*/1, nullptr, &a));
       XDET_TRY(sep_bn(b.s2, eps, ST_BODY, a, b.c, /*pre_relu=*/0, 1, 0, nullptr, &p, &r));
+      release_f32(x);                              // the block input: read by the projection and sepconv1
+      release_f32(a);
+      release_f32(r);
       x = p;
     }
     for (int blk = 5; blk <= 12; ++blk) {
@@ -1135,6 +1222,9 @@ struct LightHeadNet : Plan {
       XDET_TRY(sep_bn(pre + "_sepconv2", eps, ST_BODY, a, 728, 1, 1, 0, nullptr, &b2));
       if (blk == 12) emit_planes_next = 2;   // mid_outputs = ReLU(this) feeds the RPN 3x3 conv
       XDET_TRY(sep_bn(pre + "_sepconv3", eps, ST_BODY, b2, 728, 1, 1, 0, &res, &c3));
+      release_f32(a);                              // a block's three tensors die with it: the middle flow lives in four
+      release_f32(b2);                             // f32 blocks and one planes pair instead of 24 + 24
+      release_f32(res);
       x = c3;
     }
     mid_x = x;   // mid_outputs = ReLU(mid_x); consumers apply the ReLU on load
@@ -1153,12 +1243,18 @@ struct LightHeadNet : Plan {
     if (large_sep_mode == 2) XDET_REQUIRE(large_sep_spectral, "large_sep=spectral needs a split-precision mode and a 16/30/50 feature map");
     emit_planes_next = large_sep_spectral ? 0 : 1;   // the direct (15,1) conv takes planes; the DFT pass reads f32
     XDET_TRY(sep_bn("block14_sepconv2", eps, ST_EXIT, c3, 2048, 0, 2, 1, nullptr, &d4));   // :366-376
+    release_f32(a);
+    release_f32(r);
+    release_f32(b2);
+    release_f32(c3);
     out = d4;
     fmap = out.H;
     return XDET_OK;
   }
 
   int build_rpn() {
+    struct PoolGuard { int& p; int old; ~PoolGuard() { p = old; } } pool_guard{ws_pool, ws_pool};
+    ws_pool = rpn_side_stream ? 1 : 0;      // the branch runs beside the exit flow: no workspace block shared with the main stream
     const int A = cfg.num_anchors;
     const HostTensor *k0, *b0, *k1, *b1, *k2, *b2;
     XDET_TRY(need("rpn_head/conv2d/kernel", &k0, {3, 3, 728, 512}));
@@ -2042,6 +2138,12 @@ int xdet_net_set_option(void* net, const char* key, const char* value) {
     n->rpn_side_stream = v == "side";
     return XDET_OK;
   }
+  if (k == "workspace") {
+    XDET_REQUIRE(v == "reuse" || v == "ssa", "workspace: reuse | ssa");
+    XDET_REQUIRE(!(v == "reuse" && n->check_range), "workspace=reuse: check_range validates every tensor after the forward and needs workspace=ssa");
+    n->reuse_workspace = v == "reuse";
+    return XDET_OK;
+  }
   if (k == "sepconv") {
     XDET_REQUIRE(v == "fused" || v == "split", "sepconv must be fused | split");
     n->fuse_sepconv = v == "fused";
@@ -2061,6 +2163,7 @@ int xdet_net_set_option(void* net, const char* key, const char* value) {
   if (k == "check_range") {
     XDET_REQUIRE(v == "on" || v == "off", "check_range must be on | off");
     n->check_range = v == "on";
+    if (n->check_range) n->reuse_workspace = false;   // the validation pass reads every tensor after the forward
     return XDET_OK;
   }
   if (k == "pool") {
@@ -2258,6 +2361,12 @@ int xdet_net_graph_count(void* net, int* count) {
   return XDET_OK;
 }
 
+int xdet_net_memory(void* net, size_t* allocated_bytes, size_t* recycled_bytes) {
+  XDET_REQUIRE(net && allocated_bytes && recycled_bytes && (plan_of(net)->plan_kind == 0 || plan_of(net)->plan_kind == 1), "net_memory: bad arguments");
+  *allocated_bytes = plan_of(net)->allocated_bytes;
+  *recycled_bytes = plan_of(net)->ws_recycled_bytes;
+  return XDET_OK;
+}
 int xdet_net_flops_per_image(void* net, double* backbone, double* rpn, double* large_sep, double* head) {
   XDET_NET_KIND(net, 0, "net_flops_per_image");
   LightHeadNet* n = static_cast<LightHeadNet*>(net);

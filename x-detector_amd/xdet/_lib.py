@@ -121,6 +121,7 @@ SIGNATURES = {
     'xdet_net_x8_planes': (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     'xdet_net_plane_scale_name': (c_int, [c_void_p, c_int, ctypes.c_char_p, c_int]),
     'xdet_net_graph_count': (c_int, [c_void_p, ctypes.POINTER(c_int)]),
+    'xdet_net_memory': (c_int, [c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     'xdet_net_flops_per_image': (c_int, [c_void_p] + [ctypes.POINTER(c_double)] * 4),
     'xdet_profile_enable': (c_int, [c_void_p, c_int, c_int]),
     'xdet_profile_read': (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_double),

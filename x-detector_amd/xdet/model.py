@@ -21,10 +21,12 @@ class LightHeadDetector(object):
     def __init__(self, weights, image_size=480, max_batch=1, num_classes=21, rpn_pre_nms_top_n=5000,
                  rpn_post_nms_top_n=1000, rpn_nms_thres=0.7, rpn_min_size=None, select_threshold=0.01,
                  nms_threshold=0.3, nms_topk=200, device=None, large_sep='auto', sepconv='fused', rpn_stream='side',
-                 conv3x3='patch', pool='split', check_range=False, ksplit=True, cross='f16'):
+                 conv3x3='patch', pool='split', check_range=False, ksplit=True, cross='f16', workspace=None):
         """check_range=True: every activation tensor is validated against the f16 range of the split-precision convs
         after each forward (|x| <= 65504, no NaN); a violation raises in detections() / forward().  For validating a
         new checkpoint once: the pass re-reads every activation (~+30 % time).
+        workspace='reuse' (default) | 'ssa': dead tensors' workspace blocks are handed to later tensors of the same size, or
+        every tensor keeps its own block (check_range=True selects 'ssa' by itself); memory() reports both figures.
         cross='fp8': the cross terms of the split-precision products of the depthwise -> pointwise layers (28 of the 46
         contractions, the dominant ones) are computed from fp8 copies of the operands (the "x8" form, include/xdet.h) -- once
         calibrate() has measured the tensors; until then, and with 'f16', everything is f16x3."""
@@ -48,6 +50,8 @@ class LightHeadDetector(object):
         check(lib().xdet_net_set_option(self.handle, b'conv3x3', conv3x3.encode()))
         check(lib().xdet_net_set_option(self.handle, b'pool', pool.encode()))
         check(lib().xdet_net_set_option(self.handle, b'check_range', b'on' if check_range else b'off'))
+        if workspace is not None:
+            check(lib().xdet_net_set_option(self.handle, b'workspace', workspace.encode()))
         check(lib().xdet_net_set_option(self.handle, b'ksplit', ksplit.encode() if isinstance(ksplit, str) else (b'on' if ksplit else b'off')))
         check(lib().xdet_net_set_option(self.handle, b'cross', cross.encode()))
         check(lib().xdet_net_build(self.handle))
@@ -179,6 +183,12 @@ class LightHeadDetector(object):
         prob = e / e.sum(-1, keepdims=True)
         hb = self.flat('head_boxes', (n, self.R, 4))
         return {'classes': prob.argmax(-1), 'probabilities': prob.max(-1), 'bboxes_predict': hb}
+
+    def memory(self):
+        """{'allocated_bytes': device memory of workspace + weights, 'recycled_bytes': tensors placed into recycled blocks}"""
+        a, r = ctypes.c_size_t(), ctypes.c_size_t()
+        check(lib().xdet_net_memory(self.handle, ctypes.byref(a), ctypes.byref(r)))
+        return {'allocated_bytes': int(a.value), 'recycled_bytes': int(r.value)}
 
     def flops_per_image(self):
         v = [ctypes.c_double() for _ in range(4)]
