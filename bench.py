@@ -196,6 +196,25 @@ def cpu_model():
     return 'unknown'
 
 
+def host_memory_images(bytes_per_image):
+    """how many images' working sets fit into half of what the host (and the container's cgroup) has available"""
+    avail = None
+    try:
+        for line in open('/proc/meminfo'):
+            if line.startswith('MemAvailable:'):
+                avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    for f in ('/sys/fs/cgroup/memory.max', '/sys/fs/cgroup/memory/memory.limit_in_bytes'):
+        try:
+            v = open(f).read().strip()
+            if v.isdigit():
+                avail = int(v) if avail is None else min(avail, int(v))
+        except OSError:
+            pass
+    return 1 << 20 if avail is None else int(avail * 0.5 / bytes_per_image)
+
+
 def cpu_baseline(args, weights):
     """The oracle timed on this box's host cores (kind "port")."""
     from oracle import lighthead_oracle as O
@@ -205,6 +224,7 @@ def cpu_baseline(args, weights):
         fwd = getattr(O, 'lighthead_forward_fast', None) or O.lighthead_forward
         how = getattr(O, 'FAST_PATH_DESCRIPTION', 'NumPy fp32 + OpenBLAS')
         cb = args.cpu_batch if args.cpu_batch > 0 else min(256, os.cpu_count() or 8)   # images per call (image-parallel)
+        cb = max(1, min(cb, host_memory_images(0.4e9)))            # every image in flight holds ~0.35 GB of f32 tensors
         # inputs are synthesised BEFORE the clock starts (four different batches, cycled): the window times the forward only
         base = W.synthetic_images(min(cb, 16), 480, seed=20)           # 16 distinct images, repeated to fill a call
         full = np.concatenate([base] * (-(-cb // len(base))))[:cb]

@@ -1151,6 +1151,11 @@ struct LightHeadNet : Plan {
 
   ~LightHeadNet() {
     for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+    // the side stream and its fork / join events (created on the first forward): a net that leaves them behind leaks a
+    // hardware queue per instance -- a long test session (~150 nets) ran the runtime out of them and died inside a capture
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (aux) (void)hipStreamDestroy(aux);
   }
 
   int build_body() {
