@@ -106,6 +106,9 @@ def parse():
                     help='images per call of the C++ CPU baseline (0 = one per hardware thread, at most 256: the baseline '
                          'runs image-parallel, oracle/lighthead_cpu.cpp)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='time budget of the CPU-baseline sample')
+    ap.add_argument('--pool-sub', choices=['on', 'off'], default='on',
+                    help='blocks 2-3: the pool pass also writes the next projection\'s subsampled planes and relu(sum) '
+                         '(default) or not (A/B measurements)')
     ap.add_argument('--stagger', type=float, default=0.0,
                     help='EXPERIMENT (profiles/NOTES_r05.md): phase-shift the second sub-batch stream by this fraction of a '
                          'step (it first runs a forward over that fraction of its images, inside the timed region), so that '
@@ -408,7 +411,7 @@ def main():
         sb = B // ways                               # images per sub-batch / net instance
         nets = [LightHeadDetector(weights, image_size=S, max_batch=sb, rpn_post_nms_top_n=args.proposals,
                                   rpn_stream='main' if args.serial_rpn else 'side', conv3x3=args.conv3x3,
-                                  pool=args.pool, ksplit=args.ksplit, cross=args.cross)
+                                  pool=args.pool, ksplit=args.ksplit, cross=args.cross, pool_sub=args.pool_sub)
                 for _ in range(ways)]
         net = nets[0]
         kind = 0

@@ -239,6 +239,9 @@ int xdet_net_set_weight(void* net, const char* name, const float* data_host, int
  *   split-K kernel (on, the default; a layer constant: results identical at every batch size), nothing (off), or the RPN
  *   3x3 conv as well (all: 32 tiles against 207 K steps; faster for one image, 0.9 % slower at bench-size batches).
  *   "workspace" = "reuse" | "ssa": see xdet_net_memory.
+ *   "pool_sub" = "on" | "off": the vertical pool pass of blocks 2-3 also writes the split planes of the raw subsampled sum (the
+ *   next block's 1x1 / stride-2 projection reads those) and stores the sum as relu(sum) (its first separable conv reads that)
+ *   -- on (default) -- or leaves both to their own passes (off; the same values either way).
  *   "check_range" = "off" | "on": after each forward validate everything that is turned into f16 against the f16 range --
  *   every split plane (no inf / NaN in the hi plane; the planes hold x * 2^-e after xdet_net_calibrate), the f32 input
  *   of a register-split conv (|x| <= 65504) and of a fused separable block (relu?(x) * sum|taps| * 2^-e <= 65504) -- and

@@ -435,3 +435,29 @@ def test_workspace_reuse_changes_memory_not_results(lh_weights):
     ns = ssa.calibrate(imgs)
     assert nr == ns
     assert reuse.plane_scales() == ssa.plane_scales()
+
+
+def test_pool_pass_that_writes_the_next_projections_input(lh_weights):
+    """option "pool_sub": blocks 2-3's vertical pool pass also writes the raw subsampled planes the next block's projection
+    reads and stores relu(sum) for its first separable conv (on, default), or both are made by their own passes / on load
+    (off).  The same values either way: detections and feature maps bit for bit, at 480 and at a size with odd pooled maps."""
+    from xdet import weights as W
+    from xdet.model import LightHeadDetector
+    from xdet.runtime import set_precision
+    for size, n in ((480, 3), (256, 2)):
+        imgs = W.synthetic_images(n, size, seed=91)
+        set_precision('f16x3')
+        try:
+            on = LightHeadDetector(lh_weights, image_size=size, max_batch=n, rpn_post_nms_top_n=100)
+            off = LightHeadDetector(lh_weights, image_size=size, max_batch=n, rpn_post_nms_top_n=100, pool_sub='off')
+        finally:
+            set_precision('f32')
+        a = on.forward(imgs, use_graph=True)
+        b = off.forward(imgs)
+        for name in ('mid_x', 'out', 'feat'):
+            assert np.array_equal(on.buffer(name, n).numpy(), off.buffer(name, n).numpy()), (size, name)
+        for i in range(n):
+            for k in range(1, 21):
+                assert np.array_equal(a[i][k][0], b[i][k][0]) and np.array_equal(a[i][k][1], b[i][k][1]), (size, i, k)
+        # the same exponents from a calibration (the pool pass's planes are measured like the subsample pass's were)
+        assert on.calibrate(imgs) == off.calibrate(imgs) == {}

@@ -76,7 +76,8 @@ int launch_maxpool3x3s2_add(const float* in, const float* res, float* out, int N
                             int Ho, int Wo, int pad_t, int pad_l, hipStream_t s);
 // vertical half only, over rows the producer already pooled horizontally (sepconv_fused.hip HPOOL)
 int launch_maxpool_v3s2_add(const float* in_hpooled, const float* res, float* out, int N, int H, int Wo, int C, int ld,
-                            int Ho, int pad_t, hipStream_t s);
+                            int Ho, int pad_t, hipStream_t s, unsigned short* sub_hi = nullptr, unsigned short* sub_lo = nullptr,
+                            float sub_mul = 1.f);
 // diagnostic: bad_per_image[n] = 1 if any element of image n is NaN or beyond +-limit
 // groups > 1: a stack of `groups` blocks of group_elems floats / group_pix pixels (the frequency bins of the spectral
 // large-separable convs); the image of an element is its position inside its block / per_image, rows past N are padding

@@ -608,9 +608,17 @@ int launch_maxpool3x3s2_add(const float* in, const float* res, float* out, int N
 // The vertical half of max_pooling2d(3, 2, 'same') (+ residual) over a tensor whose rows were already pooled
 // horizontally by the producing kernel (sepconv_fused.hip, HPOOL): in [N][H][Wo][ld] -> out [N][Ho][Wo][ld].
 // Same walk as maxpool3x3s2_add_kernel: one thread = 4 channels of a column, the shared row carried in a register.
+// Round 5: the pooled sum x of an entry-flow block has two readers -- the next block's 1x1 / stride-2 projection (raw x, every
+// second pixel of every second row) and its first separable conv (relu(x), net/xception_body.py:261-277).  With SUB the pass
+// also writes what they read: the split planes of the raw subsampled tensor (what split_f32_subsample2_kernel made in a pass
+// of its own: hi = f16(x mul), lo = f16(x mul - hi), blocked [pix/16][ld/32][16][32]) and the f32 tensor as relu(x), which
+// takes the 72 v_max per chunk out of the fused separable kernel's window reads.  Same values on both paths.
+template <bool SUB>
 __global__ __launch_bounds__(256) void maxpool_v3s2_add_kernel(const float* __restrict__ in, const float* __restrict__ res,
                                                                float* __restrict__ out, int H, int Wo, int ld, int Ho,
-                                                               int pad_t, int nbands, int bands_per_image) {
+                                                               int pad_t, int nbands, int bands_per_image,
+                                                               unsigned short* __restrict__ sub_hi,
+                                                               unsigned short* __restrict__ sub_lo, float sub_mul, int Hs, int Ws) {
   const int c4n = ld >> 2;
   const int item = blockIdx.y * 256 + threadIdx.x;
   if (item >= Wo * c4n) return;
@@ -641,18 +649,42 @@ __global__ __launch_bounds__(256) void maxpool_v3s2_add_kernel(const float* __re
       const float4 r = *reinterpret_cast<const float4*>(res + o);
       m.x += r.x; m.y += r.y; m.z += r.z; m.w += r.w;
     }
+    if (SUB) {
+      const int ox = item / c4n, c = (item - ox * c4n) * 4;
+      if (!((oy | ox) & 1)) {
+        const int64_t pix = ((int64_t)n * Hs + (oy >> 1)) * Ws + (ox >> 1);
+        const size_t po = ((size_t)((pix >> 4) * (ld >> 5) + (c >> 5)) << 9) + ((size_t)(pix & 15) << 5) + (size_t)(c & 31);
+        const float v[4] = {m.x * sub_mul, m.y * sub_mul, m.z * sub_mul, m.w * sub_mul};
+        _Float16 h[4], l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          h[k] = (_Float16)v[k];
+          l[k] = (_Float16)(v[k] - (float)h[k]);
+        }
+        *reinterpret_cast<uint2*>(sub_hi + po) = *reinterpret_cast<const uint2*>(h);
+        *reinterpret_cast<uint2*>(sub_lo + po) = *reinterpret_cast<const uint2*>(l);
+      }
+      m.x = fmaxf(m.x, 0.f); m.y = fmaxf(m.y, 0.f); m.z = fmaxf(m.z, 0.f); m.w = fmaxf(m.w, 0.f);
+    }
     *reinterpret_cast<float4*>(out + o) = m;
   }
 }
 
+// sub_hi != NULL: also write the raw subsampled planes (x * sub_mul; ld a multiple of 32) and store relu(x) -- see the kernel
 int launch_maxpool_v3s2_add(const float* in_hpooled, const float* res, float* out, int N, int H, int Wo, int C, int ld,
-                            int Ho, int pad_t, hipStream_t s) {
+                            int Ho, int pad_t, hipStream_t s, unsigned short* sub_hi, unsigned short* sub_lo, float sub_mul) {
   XDET_REQUIRE(ld % 4 == 0 && ld >= C, "maxpool: channel stride must be a multiple of 4");
+  XDET_REQUIRE(!sub_hi || (sub_lo && ld % 32 == 0), "maxpool: the subsampled planes need both planes and a channel stride that is a multiple of 32");
   if ((int64_t)N * Ho == 0) return XDET_OK;
   const int bpi = (int)cdiv(Ho, MP_ROWS), nbands = N * bpi;
   const dim3 grid((unsigned)(cdiv(nbands, 8) * 8), (unsigned)cdiv((int64_t)Wo * (ld / 4), 256));
-  hipLaunchKernelGGL(maxpool_v3s2_add_kernel, grid, dim3(256), 0, s, in_hpooled, res, out, H, Wo, ld, Ho, pad_t, nbands,
-                     bpi);
+  const int Hs = (Ho + 1) / 2, Ws = (Wo + 1) / 2;
+  if (sub_hi)
+    hipLaunchKernelGGL(maxpool_v3s2_add_kernel<true>, grid, dim3(256), 0, s, in_hpooled, res, out, H, Wo, ld, Ho, pad_t, nbands,
+                       bpi, sub_hi, sub_lo, sub_mul, Hs, Ws);
+  else
+    hipLaunchKernelGGL(maxpool_v3s2_add_kernel<false>, grid, dim3(256), 0, s, in_hpooled, res, out, H, Wo, ld, Ho, pad_t, nbands,
+                       bpi, nullptr, nullptr, 1.f, Hs, Ws);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }

@@ -813,6 +813,8 @@ struct Plan {
   }
   bool fuse_sepconv = true;      // option "sepconv" = "fused" | "split"
   bool subsample_projections = true;
+  bool pool_writes_projection_input = true;   // option "pool_sub" = "on" | "off": blocks 2-3's pool pass also writes the next
+                                              // projection's subsampled planes and stores relu(sum) (off: A/B runs, tests)
   bool patch_conv3x3 = true;     // option "conv3x3" = "patch" | "gemm"
   bool fuse_hpool = true;        // option "pool" = "split" | "whole": horizontal half of an entry-flow pool in the producer
   int pool_fuse_min_pixels = 100 * 100;   // ... for the 237 x 237 block (+0.8 %) and the 119 x 119 one (time-neutral, -0.9 GB)
@@ -938,7 +940,7 @@ struct Plan {
   // relu(in * pre_sc + pre_sh) -- the pre-activation BN of a ResNet v2 block, applied in the subsample pass
   int conv_bn(const std::string& name, const std::string& bn, float eps, int stage, const Buf& in, int k, int cout,
               int stride, int pad_mode, int relu_out, const Buf* res, int relu_in, Buf* out, int pad_expl = 0,
-              const float* pre_sc = nullptr, const float* pre_sh = nullptr) {
+              const float* pre_sc = nullptr, const float* pre_sh = nullptr, const Buf* presub = nullptr) {
     const HostTensor* kt;
     XDET_TRY(need(name + "/kernel", &kt, {k, k, in.C, cout}));
     std::vector<float> sc, sh;
@@ -958,6 +960,14 @@ struct Plan {
       // in one small pass (a quarter of the input), then a plain stride-1 GEMM on the LDS-DMA kernel -- the strided
       // gather through registers ran at 60-120 TFLOP/s.  Same products in the same order: bit-identical.
       XDET_TRY(L->init(1, 1, in.C, cout, 1, 1, 1, 0, 0, kt->v.data(), scp, shp, relu_out));
+      if (presub && presub->hi) {
+        // the producer of `in` (the pool pass in front of this block) already wrote the raw subsampled planes
+        XDET_REQUIRE(!pre_sc && presub->H == (in.H + 1) / 2 && presub->W == (in.W + 1) / 2 && presub->ld == in.ld,
+                     "plan: pre-made subsampled planes do not match the projection's input");
+        XDET_TRY(add_conv(name, stage, *presub, L, res, 0, out));
+        release_planes(*presub);
+        return XDET_OK;
+      }
       Buf sub;
       sub.H = (in.H + 1) / 2; sub.W = (in.W + 1) / 2; sub.C = in.C; sub.ld = in.ld; sub.no_f32 = true;
       XDET_TRY(new_planes(&sub));
@@ -970,6 +980,7 @@ struct Plan {
       release_planes(sub);                         // read by this projection only
       return XDET_OK;
     }
+    XDET_REQUIRE(!(presub && presub->hi), "plan: pre-made subsampled planes, but this conv is not a subsampled 1x1 / stride-2 projection");
     XDET_TRY(L->init(k, k, in.C, cout, stride, 1, pad_mode, pad_expl, pad_expl, kt->v.data(), scp, shp, relu_out));
     // 3x3 VALID over 32 channels (block1_conv2): the input tile is staged in LDS once and the nine taps are shifted
     // fragment reads of it (conv3x3_patch.hip) instead of nine DMA'd K steps; same products, same order
@@ -991,8 +1002,11 @@ struct Plan {
   // net/xception_body.py:281-286); *out is then the pooled sum.  Where the fused kernel runs and the map is large enough
   // to be HBM-bound (pool_fuse_min_hw), its epilogue does the horizontal half of the pool and a light pass the vertical
   // half + the add: the full-resolution block output is written and read at half size.
+  // next_sub != NULL (with pool_res, when the pool runs as the split vertical pass): the pass also writes the raw pooled sum's
+  // subsampled planes into *next_sub (what the NEXT block's 1x1 / stride-2 projection reads) and stores relu(sum) as *out
+  // (what its first separable conv reads): maxpool_v3s2_add_kernel<SUB>.  next_sub->hi stays NULL where that form is not taken.
   int sep_bn(const std::string& name, float eps, int stage, const Buf& in, int cout, int pre_relu, int dilation,
-             int relu_out, const Buf* res, Buf* out, const Buf* pool_res = nullptr) {
+             int relu_out, const Buf* res, Buf* out, const Buf* pool_res = nullptr, Buf* next_sub = nullptr) {
     const HostTensor *dk, *pk;
     XDET_TRY(need(name + "/depthwise_kernel", &dk, {3, 3, in.C, 1}));
     XDET_TRY(need(name + "/pointwise_kernel", &pk, {1, 1, in.C, cout}));
@@ -1042,8 +1056,17 @@ struct Plan {
                          return launch_sepconv_fused(i.p, D->d_w, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale, L->d_shift, h.p, N,
                                                      i.H, i.W, i.ld, h.ld, L->cout_pad, pre_relu, L->relu_out, s, pl);
                        }});
-        ops.push_back({name + "/vpool_add", stage, 0.0, [=](int N, hipStream_t s) {
-                         return launch_maxpool_v3s2_add(h.p, rp, o.p, N, h.H, h.W, h.C, h.ld, Ho, pt, s);
+        Buf sub;
+        if (next_sub && out->ld % 32 == 0) {
+          sub.H = (Ho + 1) / 2; sub.W = (Wo + 1) / 2; sub.C = out->C; sub.ld = out->ld; sub.no_f32 = true;
+          XDET_TRY(new_planes(&sub));                // (measured right behind the pass below: op_index)
+          pscales[sub.pidx].name = name + "/vpool_add (subsampled planes for the next projection)";
+          *next_sub = sub;
+        }
+        const Buf sb = sub;
+        ops.push_back({name + (sb.hi ? "/vpool_add+subsample_split+relu" : "/vpool_add"), stage, 0.0, [=](int N, hipStream_t s) {
+                         return launch_maxpool_v3s2_add(h.p, rp, o.p, N, h.H, h.W, h.C, h.ld, Ho, pt, s, sb.hi, sb.lo,
+                                                        sb.hi ? pmul(sb.pidx) : 1.f);
                        }});
         release_f32(hp);
         return XDET_OK;
@@ -1206,14 +1229,26 @@ struct LightHeadNet : Plan {
     const Blk blks[3] = {{"conv2d_1", "batch_normalization_1", "block2_sepconv1", "block2_sepconv2", 128, 0},
                          {"conv2d_2", "batch_normalization_2", "block3_sepconv1", "block3_sepconv2", 256, 1},
                          {"conv2d_3", "batch_normalization_3", "block4_sepconv1", "block4_sepconv2", 728, 1}};
-    for (const Blk& b : blks) {
-      XDET_TRY(conv_bn(b.res, b.bn, eps, ST_BODY, x, 1, b.c, 2, 1, 0, nullptr, 0, &r));
+    Buf presub;                                    // raw subsampled planes of x, written by the pool pass that produced x
+    bool x_is_relu = false;                        // ... which then stored x as relu(x)
+    for (int bi = 0; bi < 3; ++bi) {
+      const Blk& b = blks[bi];
+      XDET_TRY(conv_bn(b.res, b.bn, eps, ST_BODY, x, 1, b.c, 2, 1, 0, nullptr, 0, &r, 0, nullptr, nullptr,
+                       presub.hi ? &presub : nullptr));
       Buf a, p;
       // relu -> sepconv2 (net/xception_body.py:271-277) is the ONLY consumer of sepconv1's BN output: the ReLU is taken
       // in sepconv1's epilogue (one v_max per element on its way out) instead of on sepconv2's 3 x 3 window reads (72 of
       // the stencil's 192 VALU instructions per chunk when the block runs as the fused kernel) -- the same values
-      XDET_TRY(sep_bn(b.s1, eps, ST_BODY, x, b.c, b.first_relu, 1, /*relu_out=*/1, nullptr, &a));
-      XDET_TRY(sep_bn(b.s2, eps, ST_BODY, a, b.c, /*pre_relu=*/0, 1, 0, nullptr, &p, &r));
+      XDET_TRY(sep_bn(b.s1, eps, ST_BODY, x, b.c, x_is_relu ? 0 : b.first_relu, 1, /*relu_out=*/1, nullptr, &a));
+      // The pooled sum of blocks 2 and 3 is read by exactly two consumers, the next block's projection (raw, every second
+      // pixel) and its sepconv1 (through a ReLU): where the pool runs as the split vertical pass it writes both forms.
+      // (Block 4's sum is the middle flow's residual stream: it stays raw.)
+      Buf nsub;
+      const bool two_readers = bi < 2 && pool_writes_projection_input && subsample_projections &&
+                               g_default_precision != PREC_F32 && b.c % 32 == 0;
+      XDET_TRY(sep_bn(b.s2, eps, ST_BODY, a, b.c, /*pre_relu=*/0, 1, 0, nullptr, &p, &r, two_readers ? &nsub : nullptr));
+      presub = nsub;
+      x_is_relu = nsub.hi != nullptr;
       release_f32(x);                              // the block input: read by the projection and sepconv1
       release_f32(a);
       release_f32(r);
@@ -2141,6 +2176,11 @@ int xdet_net_set_option(void* net, const char* key, const char* value) {
   if (k == "rpn_stream") {
     XDET_REQUIRE(v == "side" || v == "main", "rpn_stream must be side | main");
     n->rpn_side_stream = v == "side";
+    return XDET_OK;
+  }
+  if (k == "pool_sub") {
+    XDET_REQUIRE(v == "on" || v == "off", "pool_sub: on | off");
+    n->pool_writes_projection_input = v == "on";
     return XDET_OK;
   }
   if (k == "workspace") {
