@@ -103,8 +103,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=2000, help='images of the bounded CPU-baseline sample (~10-20 s)')
     ap.add_argument('--cpu-batch', type=int, default=0,
-                    help='images per call of the C++ CPU baseline (0 = one per hardware thread, at most 256: the baseline '
-                         'runs image-parallel, oracle/lighthead_cpu.cpp)')
+                    help='images per call of the C++ CPU baseline (0 = two per CPU the container may use -- affinity cut by '
+                         'the cgroup quota --, at most 256: the baseline runs image-parallel, oracle/lighthead_cpu.cpp)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='time budget of the CPU-baseline sample')
     ap.add_argument('--pool-sub', choices=['on', 'off'], default='on',
                     help='blocks 2-3: the pool pass also writes the next projection\'s subsampled planes and relu(sum) '
@@ -226,7 +226,8 @@ def cpu_baseline(args, weights):
     if args.workload == 'lighthead':
         fwd = getattr(O, 'lighthead_forward_fast', None) or O.lighthead_forward
         how = getattr(O, 'FAST_PATH_DESCRIPTION', 'NumPy fp32 + OpenBLAS')
-        cb = args.cpu_batch if args.cpu_batch > 0 else min(256, os.cpu_count() or 8)   # images per call (image-parallel)
+        # images per call: two per CPU the container can really use (its cgroup quota, not the host's thread count)
+        cb = args.cpu_batch if args.cpu_batch > 0 else min(256, 2 * O.effective_cpus())
         cb = max(1, min(cb, host_memory_images(0.4e9)))            # every image in flight holds ~0.35 GB of f32 tensors
         # inputs are synthesised BEFORE the clock starts (four different batches, cycled): the window times the forward only
         base = W.synthetic_images(min(cb, 16), 480, seed=20)           # 16 distinct images, repeated to fill a call
@@ -264,7 +265,8 @@ def cpu_baseline(args, weights):
         except Exception:
             cores = os.cpu_count()
     out = {'value': round(n / dt, 3), 'unit': 'images/sec', 'cores': int(cores), 'kind': 'port', 'sample': what,
-           'host': {'nproc': os.cpu_count(), 'cpu': cpu_model()}}
+           'host': {'nproc': os.cpu_count(), 'cpu': cpu_model(),
+                    'usable_cpus': O.effective_cpus() if hasattr(O, 'effective_cpus') else None}}
     if args.workload == 'lighthead' and getattr(O, '_fast_cache', None):
         tun = getattr(next(iter(O._fast_cache.values())), 'tuning', None)
         if tun:

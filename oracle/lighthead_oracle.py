@@ -412,6 +412,31 @@ FAST_PATH_DESCRIPTION = ('C++17 + OpenMP restatement of the reference graph (ora
                          'image-parallel: one image per thread at a time)')
 
 
+def effective_cpus():
+    """CPUs this process can actually use at once: the scheduler affinity, cut by the container's cgroup CPU quota
+    (cpu.max = "quota period": the GPU boxes show 256 hardware threads and grant 16 cores' worth of time -- threads beyond
+    the quota only time-share it, which is why the baseline used to be "fastest at 16 threads")."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for f in ('/sys/fs/cgroup/cpu.max',):
+        try:
+            q, p = open(f).read().split()[:2]
+            if q != 'max':
+                n = min(n, max(1, int(math.ceil(float(q) / float(p)))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if q > 0 and p > 0:
+            n = min(n, max(1, int(math.ceil(q / p))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 class CppForward(object):
     """the C++ baseline as an object that keeps its packed weights (building them is not part of a timed forward)"""
     def __init__(self, w, image_size=480, rpn_post_nms_top_n=300):
@@ -438,15 +463,15 @@ class CppForward(object):
         self.threads = int(_cpp.lhcpu_threads())
 
     def tune_threads(self, images, candidates=None):
-        """pick the OpenMP thread count that runs one call fastest on THIS box; returns {threads: seconds}.  The
-        baseline runs image-parallel when a call brings at least one image per two threads (lighthead_cpu.cpp), so the
-        candidates are the box's hardware threads and half of them (the physical cores of an SMT-2 host) plus, for small
-        batches (layer-parallel form), the counts that used to win there."""
+        """pick the OpenMP thread count that runs one call fastest on THIS box; returns {threads: seconds}.  Candidates:
+        the CPUs the process can really use at once (effective_cpus(): affinity cut by the cgroup quota), twice and half
+        that.  The baseline runs image-parallel when a call brings at least one image per two threads."""
         import time
         hw = os.cpu_count() or 1
         n = int(np.asarray(images).shape[0])
         if candidates is None:
-            candidates = (hw, max(hw // 2, 1)) if 2 * n >= hw // 2 else (16, 32, 64, hw)
+            eff = effective_cpus()
+            candidates = (eff, 2 * eff, max(eff // 2, 1))
         seen = {}
         for c in sorted(set(max(1, min(int(c), hw)) for c in candidates)):
             self.set_threads(c)
