@@ -199,6 +199,16 @@ def cpu_model():
     return 'unknown'
 
 
+def net_memory(nets, sb):
+    try:
+        m = nets[0].memory()
+    except Exception:                                # an older build behind XDET_LIB has no xdet_net_memory
+        return None
+    return {'net_instances': len(nets), 'images_per_instance': sb,
+            'allocated_gb_per_instance': round(m['allocated_bytes'] / 1e9, 3),
+            'recycled_gb_per_instance': round(m['recycled_bytes'] / 1e9, 3)}
+
+
 def host_memory_images(bytes_per_image):
     """how many images' working sets fit into half of what the host (and the container's cgroup) has available"""
     avail = None
@@ -413,7 +423,9 @@ def main():
         sb = B // ways                               # images per sub-batch / net instance
         nets = [LightHeadDetector(weights, image_size=S, max_batch=sb, rpn_post_nms_top_n=args.proposals,
                                   rpn_stream='main' if args.serial_rpn else 'side', conv3x3=args.conv3x3,
-                                  pool=args.pool, ksplit=args.ksplit, cross=args.cross, pool_sub=args.pool_sub)
+                                  pool=args.pool, ksplit=args.ksplit, cross=args.cross,
+                                  pool_sub=None if args.pool_sub == 'on' else args.pool_sub)   # (None: the library's default;
+                                  # an older build behind XDET_LIB, tools/ab_bench.sh, does not know the option)
                 for _ in range(ways)]
         net = nets[0]
         kind = 0
@@ -655,10 +667,7 @@ def main():
                        'weights': 'seeded random init (no checkpoint exists)', 'graph_replay': bool(use_graph)},
             # device memory of ONE sub-batch net (weights + workspace) and the bytes of tensors placed into recycled blocks
             # (option "workspace" = "reuse", include/xdet.h xdet_net_memory)
-            'memory': ({'net_instances': len(nets), 'images_per_instance': sb,
-                        'allocated_gb_per_instance': round(net.memory()['allocated_bytes'] / 1e9, 3),
-                        'recycled_gb_per_instance': round(net.memory()['recycled_bytes'] / 1e9, 3)}
-                       if args.workload == 'lighthead' else None),
+            'memory': net_memory(nets, sb) if args.workload == 'lighthead' else None,
             'device_ms_per_step': round(dev_ms / K, 3),
             'median_ms_per_step': round(float(np.median(step_ms)), 3),
             'min_ms_per_step': round(float(np.min(step_ms)), 3),
