@@ -5,7 +5,7 @@ for B in 24 48 128; do
   python - "$f" $B <<PY
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1]))); B=int(sys.argv[2])
-want=['depthwise3x3_tile_kernel<1, true>','conv_dma_f16_kernel<256, 256, 2, 4, 3, 2, true, false>','conv_dma_f16_kernel<256, 128, 4, 2, 3, 2, true, false>','depthwise3x3_tile_kernel<2, true>','maxpool_v3s2_add_kernel','sepconv_fused_kernel<true, true, true, 2>']
+want=['depthwise3x3_tile_kernel<1, true>','conv_dma_f16_kernel<256, 256, 2, 4, 3, 2, true, false>','conv_dma_f16_kernel<256, 128, 4, 2, 3, 2, true, false>','depthwise3x3_tile_kernel<2, true>','maxpool_v3s2_add_kernel','sepconv_pc_kernel<true, false, true, 2>']
 tot=sum(float(r['TotalDurationNs']) for r in rows if 'rocclr' not in r['Name'])
 print('B=%d total kernel us per image (8 steps): %.1f' % (B, tot/1e3/8/B))
 for r in rows:

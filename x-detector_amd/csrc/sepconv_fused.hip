@@ -1,22 +1,20 @@
 // Fused separable block for the entry flow: (ReLU ->) depthwise 3x3 -> pointwise 1x1 -> BN (-> ReLU) in ONE
 // kernel, "nothing in between" (net/xception_body.py:220-234).  The two-kernel form moves the depthwise result
-// through HBM as split f16 planes (4 B written + 4 B read per element); at 237x237 / 119x119 with 64..256
-// channels those layers are HBM-bound, so the round trip is a third of their time.  Here the depthwise output
-// never leaves the CU:
+// through HBM as split f16 planes (4 B written + 4 B read per element); here it never leaves the CU:
 //
 //   patch of the f32 input (6 x 32 pixels x 32 channels)  --buffer_load ... lds (zero fill = SAME padding)-->  LDS
 //   3x3 stencil in VALU (same FMA order as depthwise3x3_tile_kernel) -> hi/lo f16 -> LDS A tile [128 px][32 ch]
 //   A x W (K-blocked f16 hi/lo weights straight from L2 into registers)  --3 x v_mfma_f32_32x32x16_f16-->  acc
 //   after the last channel chunk: y = acc * scale + shift (folded BN), optional ReLU, f32 NHWC store
-//   (straight from the accumulators: no LDS bounce, the next tile's patch is already in flight)
+//   (straight from the accumulators: no LDS bounce)
 //
-// A workgroup (4 waves) works on tiles of 4 rows x 30 pixels (a 128-row GEMM tile with 8 idle rows: 30 + 2 halo
-// pixels are exactly four 1 KB DMA pieces) x 128 output channels; channel chunks of 32 are the K steps.  The
-// patch of the next (tile, chunk) is in flight while the current one is filtered and multiplied; ~79 KB of LDS
-// -> two workgroups per CU cover each other's barriers.  Arithmetic and accumulation order are exactly those
-// of depthwise3x3_tile_kernel + split + conv_dma_f16_kernel, so the result is bit-identical to the two-kernel
-// form (tests/test_gpu_layers.py).  Cout = 256 runs as two 128-wide passes over the same patch (second pass
-// from L2); wider layers (728) stay on the two-kernel path.
+// Tiles of 4 rows x 30 pixels (a 128-row GEMM tile with 8 idle rows: 30 + 2 halo pixels are exactly four 1 KB DMA
+// pieces) x 128 or 256 output channels; channel chunks of 32 are the K steps.  Arithmetic and accumulation order are
+// exactly those of depthwise3x3_tile_kernel + split + conv_dma_f16_kernel, so the result is bit-identical to the
+// two-kernel form (tests/test_gpu_layers.py).  Wider layers run as 256-wide passes over the same patch (block4_sepconv1:
+// three); the 30 x 30 layers (728 channels) stay on the two-kernel path (profiles/NOTES_r05.md: why).
+// Rounds 2-4 ran the phases back to back on four waves, two workgroups per CU (git history; the same-box A/B against
+// that library is in profiles/r05_ab_lines.txt); round 5: sepconv_pc_kernel below.
 #include "common.h"
 #include <cstdlib>
 #include <type_traits>
@@ -120,20 +118,6 @@ __device__ __forceinline__ float sf_relu(float x) {
 // computes then hold every window of its 14 pooled columns (window k = local columns 2k .. 2k+2).
 constexpr int SF_XP = 28;
 
-// hi (and lo) halves of four channels of A-tile row `r` of a strip (r = 0..3: 64 B apart; lo plane 8 KB behind hi)
-template <bool SPLIT3>
-__device__ __forceinline__ void sf_write_row(unsigned wa0, int r, sf_f16x4 hv, sf_f32x4 a) {
-  sf_f16x4 lv = {(_Float16)(a.x - (float)hv[0]), (_Float16)(a.y - (float)hv[1]), (_Float16)(a.z - (float)hv[2]),
-                 (_Float16)(a.w - (float)hv[3])};
-  const uint2 h = *reinterpret_cast<uint2*>(&hv), l = *reinterpret_cast<uint2*>(&lv);
-  switch (r) {   // r is a compile-time constant after unrolling: one case survives
-    case 0: sf_ds_write_b64<0>(wa0, h); if (SPLIT3) sf_ds_write_b64<8192>(wa0, l); break;
-    case 1: sf_ds_write_b64<64>(wa0, h); if (SPLIT3) sf_ds_write_b64<8192 + 64>(wa0, l); break;
-    case 2: sf_ds_write_b64<128>(wa0, h); if (SPLIT3) sf_ds_write_b64<8192 + 128>(wa0, l); break;
-    default: sf_ds_write_b64<192>(wa0, h); if (SPLIT3) sf_ds_write_b64<8192 + 192>(wa0, l); break;
-  }
-}
-
 // hi = f16(a), lo = f16(a - float(hi)) of four values, as two packed pairs each.  v_fma_mixlo/hi_f16 take the f16 hi half
 // straight as an fma operand and round the f32 difference (exact: it has at most 13 significant bits) to f16 into one
 // half of the destination: one instruction per value where convert-back + subtract + convert were two -- the same bits.
@@ -164,372 +148,19 @@ __device__ __forceinline__ void sf_permlane32_swap(float& a, float& b) {
   asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
-// WAVES_N = 2: the four waves as 2 x 2 over a 128 x 128 tile (64 x 64 each), a 256-channel layer as two passes.
-// WAVES_N = 4: 1 x 4 over a 128 x 256 tile (a wave: all four tile rows x 64 channels) -- ONE pass: the patch DMA, the
-// stencil and the A-tile round trip of a chunk are paid once for all 256 output channels (they, not the MFMAs, are what
-// a chunk costs).  128 accumulator registers leave no room for the two-pass form's habits: the stencil runs in two
-// halves of 2 pixels (28 fewer live registers, the taps read twice), the pointwise weights are loaded AFTER it (and the
-// prefetch after them, to land under the chunk's 96 MFMAs), fragments one 16-deep half at a time.
-template <bool SPLIT3, bool RELU_IN, bool HPOOL, int WAVES_N>
-__global__ __launch_bounds__(256, 2) void sepconv_fused_kernel(SepFusedParams p) {
-  constexpr int TM = WAVES_N;                     // 32-row accumulator blocks (= tile rows) per wave
-  constexpr int BN = 64 * WAVES_N;                // output channels per pass
-  __shared__ __attribute__((aligned(16))) float s_patch[2][SF_PATCH_F];
-  __shared__ __attribute__((aligned(16))) u16 s_a[2 * 128 * 32];        // A tile: hi rows, then lo rows (16 KB)
-  __shared__ __attribute__((aligned(16))) float s_w[9 * SF_KMAX];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // Tile schedule.  Workgroups are dealt round-robin to the 8 XCDs (private 4 MB L2s).  XCD x owns the contiguous
-  // tile band [x*per_xcd, (x+1)*per_xcd); its resident workgroups take the band's tiles in an interleaved order
-  // (workgroup j: tiles j, j+G, j+2G, ...), so at any moment one XCD works on ~G CONSECUTIVE tiles: vertical
-  // neighbours (shared halo rows) and the two 128-channel passes of a tile read the same input lines within
-  // microseconds of each other and meet in that XCD's L2.  (A workgroup walking consecutive tiles by itself found
-  // its halo rows evicted by the time it came back to them: 1.6x / 3.1x input bytes over the fabric.)
-  const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, G = gridDim.x >> 3;
-  const int per_xcd = (p.ntiles + 7) >> 3;
-  const int t_begin = xcd * per_xcd + wg;
-  const int t_end = min(p.ntiles, (xcd + 1) * per_xcd);
-  if (t_begin >= t_end) return;
-  const int KC = p.ld >> 5;                       // channel chunks = K steps
-
-  // taps in LDS as [9][SF_KMAX]: a COMPILE-TIME row stride, so the nine tap reads of a chunk are one address register
-  // plus immediate offsets (with the tensor's runtime channel stride the compiler kept nine per-lane address registers
-  // and their nine bases alive across the chunk loop -- the registers the one-pass form was short of)
-  for (int i = tid; i < 9 * p.ld; i += 256) {
-    const int t = i / p.ld;
-    s_w[t * SF_KMAX + (i - t * p.ld)] = p.w9c[i];
-  }
-
-  // ---- tile walk: N-pass fastest (same patch again, from L2), then ty, tx, image ----
-  struct Coord { int nt, ty, tx, n; };
-  auto decode = [&](int q) {
-    Coord c;
-    c.nt = q % p.NT; q /= p.NT;
-    c.ty = q % p.TY; q /= p.TY;
-    c.tx = q % p.TX;
-    c.n = q / p.TX;
-    return c;
-  };
-  Coord cur = decode(t_begin);
-
-  // ---- DMA descriptors: piece i = wave + 4*jj moves 8 pixels x 128 B of patch row rr (raw buffer loads over the
-  //      whole input tensor; a lane that must read padding is sent out of bounds and gets zeros) ----
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.ld * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-      p.out, 0, (int)(unsigned)std::min<size_t>((size_t)p.N * p.H * (HPOOL ? p.Wo : p.W) * p.ldo * 4, 0xffffffffull),
-      0x00020000);
-  // Offsets are rebuilt from wave-uniform (scalar) parts + one per-lane register each time: keeping six per-lane
-  // descriptors resident cost 12 VGPRs the stencil needs.  `live == false` issues the same six instructions
-  // with every lane out of bounds (zero fill): an unconditional instruction count keeps the compiler's vmcnt
-  // bookkeeping exact, so waiting for the weights (issued earlier) never waits for the prefetch.
-  const int px8 = lane >> 3;
-  const int lane_off = (px8 * p.ld + (lane & 7) * 4) * 4;                            // bytes
-  auto issue = [&](const Coord& c, int chunk, int buf, bool live) {
-    const int y0 = c.ty * SF_R, x0 = HPOOL ? c.tx * SF_XP - p.pool_pad_l : c.tx * SF_X;
-    const int tile_base = ((((c.n * p.H + y0) * p.W + x0) * p.ld) + chunk * 32) * 4;   // bytes, < 2^31 (host check)
-#pragma unroll
-    for (int jj = 0; jj < SF_NJ; ++jj) {
-      const int i = wave + 4 * jj;
-      const int rr = i >> 2, seg = i & 3;                                            // wave-uniform
-      const bool rok = live && (unsigned)(y0 + rr - 1) < (unsigned)p.H;
-      const bool ok = rok && (unsigned)(x0 + seg * 8 - 1 + px8) < (unsigned)p.W;
-      const int soff = tile_base + ((rr - 1) * p.W + seg * 8 - 1) * p.ld * 4;
-      const unsigned voff = ok ? (unsigned)(soff + lane_off) : 0xffffffffu;          // out of bounds -> zeros
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsrc, (__attribute__((address_space(3))) void*)(&s_patch[buf][rr * SF_ROW_F + seg * SF_PIECE_F]), 16, voff, 0, 0, 0);
-    }
-  };
-
-  // ---- roles ----
-  const int c4 = lane & 7, strip = lane >> 3;     // depthwise: wave = tile row, 4 pixels x 4 channels per lane
-  const int frow = lane & 31, fh = lane >> 5;     // MFMA fragments
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  unsigned a_rd[2];                               // LDS byte address of this lane's A fragment [ks] in its first row block
-#pragma unroll                                    // (hi; lo = +8192; row block i = +2048 i, same chunk permutation)
-  for (int ks = 0; ks < 2; ++ks) {
-    const int rt = wm * TM * 32 + frow;
-    a_rd[ks] = sf_lds_addr(s_a) + (unsigned)(rt * 32 + (((ks * 2 + fh) ^ ((rt >> 2) & 3)) << 3)) * 2u;
-  }
-  // depthwise: this lane's 4 output pixels of tile row `wave` are pxb .. pxb+3.  The tile is 30 wide: the last strip's
-  // pixels 30, 31 are computed from whatever follows the patch row in LDS and land in A-tile rows that feed only masked
-  // output rows (an MFMA row depends on its own A row only).  A strip's four A rows share one chunk permutation
-  // ((row >> 2) & 3 with pxb a multiple of 4): one address register, the rows at immediate offsets.
-  const int pxb = strip * 4;
-  const unsigned wa0 = sf_lds_addr(s_a) + (unsigned)((wave * 32 + pxb) * 32 + (((c4 >> 1) ^ (strip & 3)) << 3) + (c4 & 1) * 4) * 2u;
-
-  sf_f32x16 acc[TM][2];
-  int buf = 0;
-  issue(cur, 0, 0, true);
-  for (int t = t_begin; t < t_end; t += G) {
-    const Coord nxt = decode(min(t + G, p.ntiles - 1));
-    const int y0 = cur.ty * SF_R, x0 = HPOOL ? cur.tx * SF_XP - p.pool_pad_l : cur.tx * SF_X, n0 = cur.nt * BN;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // folded-BN scale/shift of this lane's two output channels: requested here, so that they are older than every
-    // prefetch of the tile and using them in the epilogue never waits for a DMA (vmcnt retires in order)
-    // (one-pass form: no four registers to spare across the chunks; loaded in front of the epilogue, behind a prefetch
-    //  that has had the last chunk's 96 MFMAs to land)
-    float esc[2], esh[2];
-    auto load_bn = [&]() {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        esc[j] = p.scale[n0 + wn * 64 + j * 32 + frow];
-        esh[j] = p.shift[n0 + wn * 64 + j * 32 + frow];
-      }
-    };
-    if (TM == 2) load_bn();
-
-    for (int chunk = 0; chunk < KC; ++chunk, buf ^= 1) {
-      // patch(chunk) has landed (vmcnt(0): the DMA's LDS writes retire through vmcnt) and every wave is done with
-      // the A tile and the other patch buffer.  Explicit: the compiler sees no LDS read of s_patch (they are asm)
-      // and would not wait for the DMA at a plain __syncthreads().
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      // -- this chunk's pointwise weights: L2 -> registers, issued BEFORE the DMA so that waiting for them
-      //    (vmcnt retires in order) does not wait for the prefetch --
-      sf_f16x8 bh[2][2], bl[2][2];
-      auto load_b = [&]() {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const size_t o = ((size_t)chunk * p.Cout_pad + (n0 + wn * 64 + j * 32 + frow)) * 32 + (ks * 2 + fh) * 8;
-            bh[ks][j] = *reinterpret_cast<const sf_f16x8*>(p.wt_hi + o);
-            if (SPLIT3) bl[ks][j] = *reinterpret_cast<const sf_f16x8*>(p.wt_lo + o);
-          }
-      };
-      auto prefetch = [&]() {
-        const bool more = chunk + 1 < KC;
-        issue(more ? cur : nxt, more ? chunk + 1 : 0, buf ^ 1, more || t + G < t_end);
-      };
-      if (TM == 2) {
-        load_b();
-        __builtin_amdgcn_sched_barrier(0);
-        prefetch();
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // -- depthwise 3x3, one patch row (6 pixels x 4 channels) and its three taps at a time; per output the FMA
-      //    order is ky, kx ascending = depthwise3x3_tile_kernel's --
-      // pixels pxb .. pxb+3 sit in one piece; pxb+4, pxb+5 are in the next one (behind the pad) for the odd strips
-      const unsigned t_addr = sf_lds_addr(&s_patch[buf][0]) +
-                              (unsigned)((wave * SF_ROW_F + pxb * 32 + (pxb >> 3) * 32 + c4 * 4) * 4);
-      const unsigned t_hi = t_addr + 512u + ((pxb & 7) == 4 ? 128u : 0u);
-      const unsigned w_addr = sf_lds_addr(s_w) + (unsigned)((chunk * 32 + c4 * 4) * 4);
-      // NP pixels at a time: 4 (two-pass form) or 2 + 2 (one-pass form: fewer live registers)
-      constexpr int NP = TM == 2 ? 4 : 2;
-#pragma unroll
-      for (int half = 0; half < 4 / NP; ++half) {
-        sf_f32x4 a[NP];
-#pragma unroll
-        for (int k = 0; k < NP; ++k) a[k] = (sf_f32x4){0.f, 0.f, 0.f, 0.f};
-        auto tap_row = [&](auto KY) {
-          constexpr int ky = decltype(KY)::value;
-          sf_f32x4 col[NP + 2], ww[3];
-          const unsigned ra = t_addr + ky * (SF_ROW_F * 4), rb = t_hi + ky * (SF_ROW_F * 4);
-          if (NP == 4) {
-            col[0] = sf_ds_read_f4<0>(ra);   col[1] = sf_ds_read_f4<128>(ra); col[2] = sf_ds_read_f4<256>(ra);
-            col[3] = sf_ds_read_f4<384>(ra); col[NP] = sf_ds_read_f4<0>(rb);  col[NP + 1] = sf_ds_read_f4<128>(rb);
-          } else if (half == 0) {
-            col[0] = sf_ds_read_f4<0>(ra);   col[1] = sf_ds_read_f4<128>(ra); col[2] = sf_ds_read_f4<256>(ra);
-            col[3] = sf_ds_read_f4<384>(ra);
-          } else {
-            col[0] = sf_ds_read_f4<256>(ra); col[1] = sf_ds_read_f4<384>(ra); col[2] = sf_ds_read_f4<0>(rb);
-            col[3] = sf_ds_read_f4<128>(rb);
-          }
-          ww[0] = sf_ds_read_f4<(ky * 3 + 0) * SF_KMAX * 4>(w_addr);
-          ww[1] = sf_ds_read_f4<(ky * 3 + 1) * SF_KMAX * 4>(w_addr);
-          ww[2] = sf_ds_read_f4<(ky * 3 + 2) * SF_KMAX * 4>(w_addr);
-          if (NP == 4)
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(col[0]), "+v"(col[1]), "+v"(col[2]), "+v"(col[3]), "+v"(col[NP]), "+v"(col[NP + 1]),
-                           "+v"(ww[0]), "+v"(ww[1]), "+v"(ww[2])::"memory");
-          else
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(col[0]), "+v"(col[1]), "+v"(col[2]), "+v"(col[3]), "+v"(ww[0]), "+v"(ww[1]), "+v"(ww[2])::"memory");
-#pragma unroll
-          for (int k = 0; k < NP + 2; ++k) {
-            if (RELU_IN) {
-              col[k].x = sf_relu(col[k].x); col[k].y = sf_relu(col[k].y);
-              col[k].z = sf_relu(col[k].z); col[k].w = sf_relu(col[k].w);
-            }
-          }
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-              a[k].x = fmaf(col[k + kx].x, ww[kx].x, a[k].x); a[k].y = fmaf(col[k + kx].y, ww[kx].y, a[k].y);
-              a[k].z = fmaf(col[k + kx].z, ww[kx].z, a[k].z); a[k].w = fmaf(col[k + kx].w, ww[kx].w, a[k].w);
-            }
-        };
-        tap_row(std::integral_constant<int, 0>{});
-        tap_row(std::integral_constant<int, 1>{});
-        tap_row(std::integral_constant<int, 2>{});
-        // -- split into f16 hi/lo, A tile rows wave*32 + pxb + k (chunk-permuted like the conv kernel's DMA layout) --
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-          const _Float16 h0 = (_Float16)a[k].x, h1 = (_Float16)a[k].y, h2 = (_Float16)a[k].z, h3 = (_Float16)a[k].w;
-          sf_f16x4 hv = {h0, h1, h2, h3};
-          sf_write_row<SPLIT3>(wa0, half * NP + k, hv, a[k]);
-        }
-      }
-      // A tile visible to the workgroup: LDS writes only (lgkmcnt) -- the prefetch DMA stays in flight
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (TM != 2) {
-        load_b();
-        __builtin_amdgcn_sched_barrier(0);
-        prefetch();
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // -- pointwise: two 16-deep halves, products in the conv kernel's order (lo*hi, hi*lo, hi*hi) --
-      auto read_half = [&](int ks, sf_f16x8* ah, sf_f16x8* al) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          ah[i] = sf_ds_read_b128<0>(a_rd[ks] + i * 2048);
-          if (SPLIT3) al[i] = sf_ds_read_b128<128 * 64>(a_rd[ks] + i * 2048);
-        }
-      };
-      // one wait for the reads; the operands pass through it so that no MFMA can be scheduled above it
-      auto wait_half = [&](sf_f16x8* ah, sf_f16x8* al) {
-#pragma unroll
-        for (int i = 0; i < TM; i += 2) {
-          if (SPLIT3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i]), "+v"(ah[i + 1]), "+v"(al[i]), "+v"(al[i + 1])::"memory");
-          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i]), "+v"(ah[i + 1])::"memory");
-        }
-      };
-      auto mma_half = [&](int ks, const sf_f16x8* ah, const sf_f16x8* al) {
-        if (SPLIT3) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[ks][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[ks][j], acc[i][j], 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[ks][j], acc[i][j], 0, 0, 0);
-      };
-      if (TM == 2) {
-        sf_f16x8 ah[2][TM], al[2][TM];
-        read_half(0, ah[0], al[0]);
-        read_half(1, ah[1], al[1]);
-        wait_half(ah[0], al[0]);
-        wait_half(ah[1], al[1]);
-        mma_half(0, ah[0], al[0]);
-        mma_half(1, ah[1], al[1]);
-      } else {
-        sf_f16x8 ah[TM], al[TM];
-        read_half(0, ah, al);
-        wait_half(ah, al);
-        mma_half(0, ah, al);
-        __builtin_amdgcn_sched_barrier(0);
-        read_half(1, ah, al);
-        wait_half(ah, al);
-        mma_half(1, ah, al);
-      }
-    }
-
-    if (TM != 2) load_bn();
-    if (HPOOL) {
-      // Horizontal half of the pool, from the accumulators.  A lane holds columns c + 4 fh (c = 0..3, 8..11 in registers
-      // 0..7, 16..19, 24..27 in 8..15) of one channel; v_permlane32_swap of register r with r + 8 leaves lanes 0..31
-      // with columns 0..15 and lanes 32..63 with 16..31, window k = columns 2k..2k+2: the lower half takes k = 0..7
-      // (its last window borrows column 16), the upper half k = 8..13.  Columns outside the image are -inf (SAME
-      // padding never wins a maximum); max is exact, so the order of the nine comparisons does not matter.
-      const int klim = min(SF_XP / 2, p.Wo - cur.tx * (SF_XP / 2)) - 8 * fh;   // this lane's windows are 8 fh + kk
-      const bool edge = x0 < 0 || x0 + 32 > p.W;                               // wave-uniform
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int y = y0 + wm * TM + i;
-        if (y >= p.H) continue;                                                // wave-uniform
-        const unsigned row_off = (unsigned)((((size_t)cur.n * p.H + y) * p.Wo + cur.tx * (SF_XP / 2)) * p.ldo * 4);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int co = n0 + wn * 64 + j * 32 + frow;
-          const unsigned lane_off = co < p.ldo ? (unsigned)((8 * fh * p.ldo + co) * 4) : 0xffffffffu;
-          float v[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            v[r] = fmaf(acc[i][j][r], esc[j], esh[j]);
-            if (p.relu_out) v[r] = fmaxf(v[r], 0.f);
-          }
-          if (edge) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int col = x0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-              if ((unsigned)col >= (unsigned)p.W) v[r] = -INFINITY;
-            }
-          }
-          float X[8], Y[8];
-#pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            X[r] = v[r];
-            Y[r] = v[r + 8];
-            sf_permlane32_swap(X[r], Y[r]);
-          }
-          // column q of this half (q = 0..15): X or Y [(q & 3) + 4 (q >> 3)] by (q & 4)
-          auto colv = [&](int q) { return (q & 4) ? Y[(q & 3) + 4 * (q >> 3)] : X[(q & 3) + 4 * (q >> 3)]; };
-          float c16a = X[0], col16 = X[0];
-          sf_permlane32_swap(c16a, col16);                                    // lower half: the upper half's column 16
-#pragma unroll
-          for (int kk = 0; kk < 8; ++kk) {
-            const float c2 = kk < 7 ? colv(2 * kk + 2) : col16;
-            const float m = fmaxf(fmaxf(colv(2 * kk), colv(2 * kk + 1)), c2);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), orsrc, kk < klim ? lane_off : 0xffffffffu,
-                                                  row_off + kk * p.ldo * 4, 0);
-          }
-        }
-      }
-      cur = nxt;
-      continue;
-    }
-    const int lim = min(SF_X, p.W - x0) - 4 * fh;            // this lane's pixels are c + 4*fh, c = 0..3, 8..11, 16.., 24..
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int y = y0 + wm * TM + i;                        // tile row of this 32-row accumulator block
-      if (y >= p.H) continue;                                // wave-uniform
-      const unsigned row_off = (unsigned)((((size_t)cur.n * p.H + y) * p.W + x0) * p.ldo * 4);   // < 2^32 (host check)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int co = n0 + wn * 64 + j * 32 + frow;
-        const unsigned lane_off = co < p.ldo ? (unsigned)((4 * fh * p.ldo + co) * 4) : 0xffffffffu;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int c = (r & 3) + 8 * (r >> 2);
-          float v = fmaf(acc[i][j][r], esc[j], esh[j]);
-          if (p.relu_out) v = fmaxf(v, 0.f);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, c < lim ? lane_off : 0xffffffffu, row_off + c * p.ldo * 4, 0);
-        }
-      }
-    }
-    cur = nxt;
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// Producer / consumer form (round 5).  The kernel above runs DMA wait -> stencil -> split -> A tile -> barrier -> MFMA
-// back to back on the same four waves; two workgroups per CU were meant to cover each other's phases and measured
-// 5,500 clocks per 32-channel chunk and CU against ~2,100 of VALU issue and 1,536 of MFMA issue (the 119^2 layers:
-// 2.2-3.2 TB/s with the matrix pipe 24-35 % busy -- bound by neither).  Here the phases are different WAVES of one
-// 512-thread workgroup, one of each on every SIMD:
+// Producer / consumer form (round 5).  Rounds 2-4 ran DMA wait -> stencil -> split -> A tile -> barrier -> MFMA back to
+// back on the same four waves, two workgroups per CU (5,500 clocks per 32-channel chunk and CU; the 119^2 layers at
+// 2.2-3.2 TB/s with the matrix pipe 24-35 % busy).  Here the phases are different WAVES of one 512-thread workgroup, one
+// of each on every SIMD:
 //   waves 0-3 (producers): patch DMA three steps deep, 3x3 stencil, hi/lo split, A tile of step s into s_a[s & 1]
 //   waves 4-7 (consumers): the MFMAs of step s-1 out of s_a[(s-1) & 1] against weights that were requested one
 //                          half-step earlier, and the tile's epilogue (folded BN / ReLU / h-pool) after its last chunk
 // with ONE s_barrier per step (a step = one 32-channel chunk of one tile): a SIMD's VALU (producer) and its matrix
-// pipe (consumer) work on adjacent steps at the same time.  Step order, FMA order, product order and K order are those
-// of the kernel above: bit-identical (tests/test_gpu_layers.py runs both forms against the two-kernel path).
+// pipe (consumer) work on adjacent steps at the same time -- as far as they can: measured, a co-resident wave's VALU
+// instructions cost the MFMA stream ~7 clocks each, so a step costs the SUM of both streams and what made the kernel
+// faster than its predecessor was the lower instruction count (profiles/NOTES_r05.md).  Step order, FMA order, product
+// order and K order are the predecessor's: bit-identical to the two-kernel path (tests/test_gpu_layers.py).
 template <bool SPLIT3, bool RELU_IN, bool HPOOL, int WAVES_N>
 __global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
   constexpr int TM = WAVES_N;
@@ -543,7 +174,11 @@ __global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // tile schedule: the XCD bands of the kernel above, one workgroup per CU
+  // Tile schedule.  Workgroups are dealt round-robin to the 8 XCDs (private 4 MB L2s).  XCD x owns the contiguous tile
+  // band [x*per_xcd, (x+1)*per_xcd); its resident workgroups take the band's tiles in an interleaved order (workgroup j:
+  // tiles j, j+G, j+2G, ...), so at any moment one XCD works on ~G CONSECUTIVE tiles: vertical neighbours (shared halo
+  // rows) and the N passes of a tile read the same input lines within microseconds of each other and meet in that
+  // XCD's L2.  One workgroup per CU.
   const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, G = gridDim.x >> 3;
   const int per_xcd = (p.ntiles + 7) >> 3;
   const int t_begin = xcd * per_xcd + wg;
@@ -852,7 +487,7 @@ __global__ __launch_bounds__(512, 1) void sepconv_pc_kernel(SepFusedParams p) {
       continue;
     }
 
-    // ---- epilogue of the tile (as in the kernel above; scale / shift from LDS: a global load here would sit in the
+    // ---- epilogue of the tile (scale / shift from LDS: a global load here would sit in the
     //      same in-order vmcnt queue as the weight requests of the next step) ----
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -1006,20 +641,13 @@ int launch_sepconv_fused(const float* in, const float* w9c, const unsigned short
     const int64_t nt = (int64_t)n * p.TY * p.TX * p.NT;
     p.ntiles = (int)nt;
     p.tiles_per_block = 0;
-    // producer / consumer form: one 512-thread workgroup per CU; XDET_SEPCONV_SERIAL=1: the four-wave form above, two
-    // workgroups per CU (LDS) -- for A/B runs; a multiple of 8 so that every XCD gets the same number
-    static const bool serial = getenv("XDET_SEPCONV_SERIAL") != nullptr;
-    const dim3 g((unsigned)std::min<int64_t>(serial ? 512 : 256, cdiv(nt, 8) * 8));
-    auto go = [&](auto kern, int threads) { hipLaunchKernelGGL(kern, g, dim3(threads), 0, s, p); };
+    // one 512-thread workgroup per CU; a multiple of 8 so that every XCD gets the same number
+    const dim3 g((unsigned)std::min<int64_t>(256, cdiv(nt, 8) * 8));
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, g, dim3(512), 0, s, p); };
     auto pick = [&](auto split3, auto relu, auto pool) {
       constexpr bool S3 = decltype(split3)::value, RL = decltype(relu)::value, PL = decltype(pool)::value;
-      if (serial) {
-        if (wide) go(sepconv_fused_kernel<S3, RL, PL, 4>, 256);
-        else go(sepconv_fused_kernel<S3, RL, PL, 2>, 256);
-      } else {
-        if (wide) go(sepconv_pc_kernel<S3, RL, PL, 4>, 512);
-        else go(sepconv_pc_kernel<S3, RL, PL, 2>, 512);
-      }
+      if (wide) go(sepconv_pc_kernel<S3, RL, PL, 4>);
+      else go(sepconv_pc_kernel<S3, RL, PL, 2>);
     };
     auto pick2 = [&](auto split3, auto relu) {
       if (hpool) pick(split3, relu, std::true_type{});
