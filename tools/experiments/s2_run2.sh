@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/s2
+timeout 600 python -m pytest tests/test_gpu_resnet_bneck.py tests/test_gpu_resnet.py -x -q > gpurun_out/s2/pytest2.log 2>&1; echo "pytest rc $?" >> gpurun_out/s2/pytest2.log
+tail -15 gpurun_out/s2/pytest2.log
+RN="timeout 300 python bench.py --workload resnet50 --batch 8 --resnet-ways 1 --steps 200 --warmup 20 --no-cpu-baseline --no-roofline --sustain-seconds 0"
+for i in 1 2; do
+  XDET_RESNET_BNECK=0 $RN 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('rn 3-launch', d['value'], d['ms_per_step'])"
+  $RN 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('rn fused   ', d['value'], d['ms_per_step'])"
+done

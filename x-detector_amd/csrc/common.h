@@ -124,6 +124,20 @@ int launch_conv3x3_patch(const unsigned short* in_hi, const unsigned short* in_l
                          const unsigned short* wt_lo_blocked, const float* scale, const float* shift, float* out, int N, int H,
                          int W, int ldo, int relu, hipStream_t s);
 
+// ---- one ResNet v2 identity bottleneck block as a single kernel (resnet_bneck.hip) ----
+struct BneckLaunch {
+  const unsigned short *xin_hi, *xin_lo;   // relu(bn(x)) planes of the block input
+  const float* x;                          // the block input (identity shortcut), channel stride cout
+  const unsigned short *wa_hi, *wa_lo, *wb_hi, *wb_lo, *wc_hi, *wc_lo;   // K-blocked weights of the three convs
+  const float *sc_a, *sh_a, *sc_b, *sh_b, *sc_c, *sh_c;                   // their epilogue scale / shift
+  const float *pl_sc, *pl_sh;              // the planes copy of the output: relu(out * pl_sc + pl_sh)
+  float* out;
+  unsigned short *out_hi, *out_lo;         // (NULL: no planes copy)
+  int H, W, cin, cmid, cout;
+};
+bool resnet_bneck_supported(int cin, int cmid, int cout, int H, int W, int N);
+int launch_resnet_bneck(const BneckLaunch& a, int N, hipStream_t s);
+
 // ---- F1 pre-processing (preprocess.hip) ----------------------------------------------
 int launch_preprocess_eval(const unsigned char* img, int H, int W, float* out_chw, int S, hipStream_t s);
 

@@ -1727,6 +1727,8 @@ struct ResNetTrunk : Plan {
   Buf in4, outb;
   double flops = 0;
   bool ksplit_enabled = true;                      // XDET_RESNET_KSPLIT=0: the round-3 launch plan (A/B measurements)
+  bool bneck_enabled = true;                       // identity blocks the fused kernel supports run as one launch
+  bool bneck_fused_now = false;                    // set by a block's first op for its other two (ops run in order on one stream)
   typedef std::array<uintptr_t, 3> Key;            // (N, images, out): every pointer a captured graph bakes in
   std::map<Key, hipGraphExec_t> graphs;
   std::vector<Key> graph_order;
@@ -1840,10 +1842,13 @@ int ResNetTrunk::build() {
       }
       const std::string c1 = cname(), b1 = bname(), c2 = cname(), b2 = bname(), c3 = cname();
       // conv1x1 -> (BN+ReLU fused into its epilogue) -> conv3x3/s -> (BN+ReLU fused) -> conv1x1 + shortcut
+      const size_t op_first = ops.size();
       emit_planes_next = 3;                       // the 3x3 (stride 1 or 2) takes its input as planes (only)
       XDET_TRY(conv_bn(c1, b1, 1e-5f, 0, pre, 1, f, 1, 1, 1, nullptr, 0, &y1));
+      ConvLayer* La = static_cast<ConvLayer*>(layers.back().get());
       emit_planes_next = 3;                       // the closing 1x1 always does
       XDET_TRY(conv_bn(c2, b2, 1e-5f, 0, y1, 3, f, s, s > 1 ? 2 : 1, 1, nullptr, 0, &y2, 1));
+      ConvLayer* Lb = static_cast<ConvLayer*>(layers.back().get());
       // The next block opens with BN+ReLU of this block's output.  Fold it in: the closing conv writes its f32
       // output (the identity shortcut) AND relu(bn_next(output)) as planes, and the separate element-wise pass
       // disappears.  (A stage opener's strided projection cannot read those full-resolution planes: see above.)
@@ -1865,6 +1870,34 @@ int ResNetTrunk::build() {
         emit_bn_shift = sh;                         //  planes' pre-scale; nsc / nsh below stay as they are for the projection)
       }
       XDET_TRY(conv_bn(c3, "", 0.f, 0, y2, 1, 4 * f, 1, 1, 0, &shortcut, 0, &y3));
+      ConvLayer* Lc = static_cast<ConvLayer*>(layers.back().get());
+      // An identity block of stages 1-2 as ONE kernel (resnet_bneck.hip): the three ops stay in the plan -- a calibration
+      // pass measures the two inner planes tensors behind them, and a block whose inner planes carry an activation
+      // pre-scale keeps the three-launch form -- but the first one launches the fused kernel and the other two do nothing.
+      if (bneck_enabled && b > 0 && g_default_precision == PREC_F16X3 && nsc && ops.size() == op_first + 3 && pre.hi && y3.hi &&
+          La->ksplit < 1 && Lb->ksplit < 1 && Lc->ksplit < 1 &&
+          resnet_bneck_supported(pre.C, f, 4 * f, pre.H, pre.W, max_batch)) {
+        BneckLaunch a;
+        a.xin_hi = pre.hi; a.xin_lo = pre.lo; a.x = shortcut.p;
+        a.wa_hi = La->d_wt_hi_b; a.wa_lo = La->d_wt_lo_b; a.wb_hi = Lb->d_wt_hi_b; a.wb_lo = Lb->d_wt_lo_b;
+        a.wc_hi = Lc->d_wt_hi_b; a.wc_lo = Lc->d_wt_lo_b;
+        a.sc_a = La->d_scale; a.sh_a = La->d_shift; a.sc_b = Lb->d_scale; a.sh_b = Lb->d_shift;
+        a.sc_c = Lc->d_scale; a.sh_c = Lc->d_shift;
+        a.pl_sc = nullptr; a.pl_sh = nullptr;     // (Lc's planes affine is allocated by now; read at launch time below)
+        a.out = y3.p; a.out_hi = y3.hi; a.out_lo = y3.lo;
+        a.H = pre.H; a.W = pre.W; a.cin = pre.C; a.cmid = f; a.cout = 4 * f;
+        const auto run_a = ops[op_first].run, run_b = ops[op_first + 1].run, run_c = ops[op_first + 2].run;
+        ops[op_first].run = [=](int N, hipStream_t st) {
+          bneck_fused_now = !after_op && La->out_exp == 0 && Lb->in_exp == 0 && Lb->out_exp == 0 && Lc->in_exp == 0;
+          if (!bneck_fused_now) return run_a(N, st);
+          BneckLaunch l = a;
+          l.pl_sc = Lc->d_pl_scale; l.pl_sh = Lc->d_pl_shift;
+          return launch_resnet_bneck(l, N, st);
+        };
+        ops[op_first + 1].run = [=](int N, hipStream_t st) { return bneck_fused_now ? (int)XDET_OK : run_b(N, st); };
+        ops[op_first + 2].run = [=](int N, hipStream_t st) { return bneck_fused_now ? (int)XDET_OK : run_c(N, st); };
+        ops[op_first].name += " [+2: one kernel]";
+      }
       if (nsc) {
         fused_pre = y3;                             // same shape; lives as planes only
         fused_pre.p = nullptr;
@@ -2065,6 +2098,32 @@ int xdet_conv3x3_patch_forward(void* layer, const uint16_t* in_hi, const uint16_
   DeviceGuard guard(L->device);
   return launch_conv3x3_patch(in_hi, L->precision == PREC_F16 ? nullptr : in_lo, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale,
                               L->d_shift, out, N, H, W, ld_out, L->relu_out, S(stream));
+}
+int xdet_resnet_bneck_forward(void* conv_a, void* conv_b, void* conv_c, const uint16_t* pre_hi, const uint16_t* pre_lo,
+                              const float* x, int N, int H, int W, float* out, const float* next_scale,
+                              const float* next_shift, uint16_t* out_hi, uint16_t* out_lo, void* stream) {
+  LayerBase* b[3] = {static_cast<LayerBase*>(conv_a), static_cast<LayerBase*>(conv_b), static_cast<LayerBase*>(conv_c)};
+  XDET_REQUIRE(b[0] && b[1] && b[2] && b[0]->kind == 1 && b[1]->kind == 1 && b[2]->kind == 1, "resnet_bneck: three conv layers");
+  ConvLayer *A = static_cast<ConvLayer*>(b[0]), *B = static_cast<ConvLayer*>(b[1]), *C = static_cast<ConvLayer*>(b[2]);
+  XDET_REQUIRE(A->precision == PREC_F16X3 && B->precision == PREC_F16X3 && C->precision == PREC_F16X3 && A->dma_capable() &&
+                   B->dma_capable() && C->dma_capable() && A->groups == 1 && B->groups == 1 && C->groups == 1,
+               "resnet_bneck: the three layers must be created in mode 1 (f16x3)");
+  XDET_REQUIRE(A->kh == 1 && A->kw == 1 && A->stride == 1 && A->relu_out == 1 && B->kh == 3 && B->kw == 3 && B->stride == 1 &&
+                   B->dil == 1 && B->pad_mode == 1 && B->relu_out == 1 && C->kh == 1 && C->kw == 1 && C->stride == 1 &&
+                   C->relu_out == 0 && A->cout == B->cin && B->cout == C->cin && B->cin == B->cout && C->cout == A->cin &&
+                   A->cout_pad == A->cout && B->cout_pad == B->cout && C->cout_pad == C->cout,
+               "resnet_bneck: need 1x1 (ReLU) -> 3x3 SAME stride 1 (ReLU) -> 1x1 with Cin -> Cmid -> Cmid -> Cin channels");
+  XDET_REQUIRE(resnet_bneck_supported(A->cin, A->cout, C->cout, H, W, N), "resnet_bneck: unsupported channel counts / tensor size");
+  XDET_REQUIRE(pre_hi && pre_lo && x && out && (!out_hi || (out_lo && next_scale && next_shift)), "resnet_bneck: NULL argument");
+  BneckLaunch a;
+  a.xin_hi = pre_hi; a.xin_lo = pre_lo; a.x = x;
+  a.wa_hi = A->d_wt_hi_b; a.wa_lo = A->d_wt_lo_b; a.wb_hi = B->d_wt_hi_b; a.wb_lo = B->d_wt_lo_b; a.wc_hi = C->d_wt_hi_b; a.wc_lo = C->d_wt_lo_b;
+  a.sc_a = A->d_scale; a.sh_a = A->d_shift; a.sc_b = B->d_scale; a.sh_b = B->d_shift; a.sc_c = C->d_scale; a.sh_c = C->d_shift;
+  a.pl_sc = next_scale; a.pl_sh = next_shift;
+  a.out = out; a.out_hi = out_hi; a.out_lo = out_lo;
+  a.H = H; a.W = W; a.cin = A->cin; a.cmid = A->cout; a.cout = C->cout;
+  DeviceGuard guard(A->device);
+  return launch_resnet_bneck(a, N, S(stream));
 }
 int xdet_sepconv_fused_hpool_forward(void* dw_layer, void* pw_layer, const float* in, int N, int H, int W, int ld_in,
                                      float* out_hpooled, int ld_out, int relu_in, void* stream) {
@@ -2465,6 +2524,7 @@ int xdet_resnet_create(void** net, int image_size, int max_batch) {
   r->image_size = image_size;
   r->max_batch = max_batch;
   if (const char* e = getenv("XDET_RESNET_KSPLIT")) r->ksplit_enabled = strcmp(e, "0") != 0;
+  if (const char* e = getenv("XDET_RESNET_BNECK")) r->bneck_enabled = strcmp(e, "0") != 0;     // 0: three launches per block (A/B runs, tests)
   XDET_HIP(hipGetDevice(&r->device));
   *net = r;
   return XDET_OK;

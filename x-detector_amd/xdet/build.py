@@ -18,6 +18,7 @@ SOURCES = [
     ('spectral.hip', []),
     ('sepconv_fused.hip', []),
     ('conv3x3_patch.hip', []),
+    ('resnet_bneck.hip', []),
     ('psroialign.hip', ['-ffp-contract=off']),
     ('proposals.hip', ['-ffp-contract=off']),
     ('detect.hip', ['-ffp-contract=off']),
