@@ -160,14 +160,17 @@ int xdet_conv3x3_patch_forward(void* layer, const uint16_t* in_hi, const uint16_
                                int ld_out, void* stream);
 /* One ResNet v2 bottleneck block with an identity shortcut (net/resnet_v2.py:142-184 with projection_shortcut = None,
  * strides = 1: shortcut = inputs; BN-ReLU -> conv 1x1 -> BN-ReLU -> conv 3x3 -> BN-ReLU -> conv 1x1; + shortcut) as ONE
- * kernel (csrc/resnet_bneck.hip): the two narrow intermediates stay on the CU.  conv_a / conv_b / conv_c: layers from
- * xdet_conv_create in mode 1 -- 1x1 Cin -> Cmid with the folded BN that follows it and relu 1; 3x3 SAME stride 1
- * Cmid -> Cmid likewise; 1x1 Cmid -> Cin, relu 0 (Cin 256, Cmid 64: stage 1 of ResNet-50).  pre_hi / pre_lo: the planes
- * (xdet_split_f32 layout) of the block's pre-activation relu(bn(x)); x: the block input NHWC f32 [N][H][W][Cin];
+ * kernel (csrc/resnet_bneck.hip): the block input is read once per use, the pre-activation and the two narrow
+ * intermediates never leave the CU.  conv_a / conv_b / conv_c: layers from xdet_conv_create in mode 1 -- 1x1 Cin -> Cmid
+ * with the folded BN that follows it and relu 1; 3x3 SAME stride 1 Cmid -> Cmid likewise; 1x1 Cmid -> Cin, relu 0
+ * (Cin 256, Cmid 64: stage 1 of ResNet-50).  x: the block input, NHWC f32 [N][H][W][Cin]; pre_scale / pre_shift
+ * (device, [Cin]): the block's first BN folded, i.e. the pre-activation is relu(x * pre_scale + pre_shift) (one fused
+ * multiply-add per element, then hi = f16(.), lo = f16(. - hi): what xdet_split_f32 makes of that tensor);
  * out = x + branch.  With out_hi / out_lo given, relu(out * next_scale + next_shift) -- the NEXT block's pre-activation --
- * is written as planes too.  Bit-identical to three xdet_conv_forward_planes calls with xdet_split_f32 in between.
- * Inside xdet_resnet_*: the identity blocks of stage 1 (environment XDET_RESNET_BNECK=0 at create time: three launches). */
-int xdet_resnet_bneck_forward(void* conv_a, void* conv_b, void* conv_c, const uint16_t* pre_hi, const uint16_t* pre_lo,
+ * is also written as planes (xdet_split_f32 layout) for a successor that runs layer by layer.  Bit-identical to
+ * xdet_split_f32 + three xdet_conv_forward_planes calls.  Inside xdet_resnet_*: the identity blocks of stage 1
+ * (environment XDET_RESNET_BNECK=0 at create time: three launches per block). */
+int xdet_resnet_bneck_forward(void* conv_a, void* conv_b, void* conv_c, const float* pre_scale, const float* pre_shift,
                               const float* x, int N, int H, int W, float* out, const float* next_scale,
                               const float* next_shift, uint16_t* out_hi, uint16_t* out_lo, void* stream);
 /* The entry-flow tail "separable block -> max_pooling2d(3, 2, 'same') -> tf.add(residual)" (net/xception_body.py:268-286)

@@ -14,7 +14,9 @@ N, H, W = [int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (1, 8, 30))]
 rng = np.random.RandomState(5)
 cin, cmid = 256, 64
 x = rng.standard_normal((N, H, W, cin)).astype(np.float32)
-pre = np.maximum(x * 0.9 + 0.1, 0).astype(np.float32)
+ps = np.full(cin, 0.5, np.float32)
+ph = np.full(cin, 0.1, np.float32)
+pre = np.maximum(x * ps + ph, 0).astype(np.float32)
 wa = (rng.standard_normal((1, 1, cin, cmid)) / np.sqrt(cin)).astype(np.float32)
 wb = (rng.standard_normal((3, 3, cmid, cmid)) / np.sqrt(9 * cmid)).astype(np.float32)
 wc = (rng.standard_normal((1, 1, cmid, cin)) / np.sqrt(cmid)).astype(np.float32)
@@ -28,14 +30,11 @@ dx, dpre = DeviceTensor.from_numpy(x), DeviceTensor.from_numpy(pre)
 y1 = A(dpre, planes=True)
 y2 = B(y1, planes=True)
 ref = C(y2, planes=True, residual=dx).numpy()
-n_pix = N * H * W
-nh16 = -(-n_pix // 16) * 16
-hi, lo = DeviceBuffer(nh16 * cin * 2 + 512, zero=True), DeviceBuffer(nh16 * cin * 2 + 512, zero=True)
-check(lib().xdet_split_f32(dpre.ptr, hi.ptr, lo.ptr, n_pix, cin, 0, None))
+dps, dph = to_device(ps), to_device(ph)
 for mode, want in ((1, y1.numpy()), (2, y2.numpy()), (0, ref)):
     os.environ['XDET_BNECK_DEBUG'] = str(mode)
     out = DeviceTensor.empty((N, H, W, cin))
-    check(lib().xdet_resnet_bneck_forward(A.handle, B.handle, C.handle, hi.ptr, lo.ptr, dx.ptr, N, H, W, out.ptr, None, None,
+    check(lib().xdet_resnet_bneck_forward(A.handle, B.handle, C.handle, dps.ptr, dph.ptr, dx.ptr, N, H, W, out.ptr, None, None,
                                           None, None, None))
     synchronize()
     got = out.numpy()

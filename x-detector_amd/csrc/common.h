@@ -126,8 +126,8 @@ int launch_conv3x3_patch(const unsigned short* in_hi, const unsigned short* in_l
 
 // ---- one ResNet v2 identity bottleneck block as a single kernel (resnet_bneck.hip) ----
 struct BneckLaunch {
-  const unsigned short *xin_hi, *xin_lo;   // relu(bn(x)) planes of the block input
-  const float* x;                          // the block input (identity shortcut), channel stride cout
+  const float* x;                          // the block input (identity shortcut and, through bn + ReLU, the first conv's operand)
+  const float *pre_sc, *pre_sh;            // the block's pre-activation BN, folded: relu(x * pre_sc + pre_sh)
   const unsigned short *wa_hi, *wa_lo, *wb_hi, *wb_lo, *wc_hi, *wc_lo;   // K-blocked weights of the three convs
   const float *sc_a, *sh_a, *sc_b, *sh_b, *sc_c, *sh_c;                   // their epilogue scale / shift
   const float *pl_sc, *pl_sh;              // the planes copy of the output: relu(out * pl_sc + pl_sh)

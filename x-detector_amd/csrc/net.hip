@@ -464,7 +464,7 @@ struct Plan {
   std::vector<Op> ops;
   WeightMap w;
 
-  ~Plan() {
+  virtual ~Plan() {
     for (void* p : allocs) (void)hipFree(p);
   }
   size_t allocated_bytes = 0;
@@ -771,6 +771,11 @@ struct Plan {
   // a following BN+ReLU pre-activation folded into this conv's epilogue.
   int emit_planes_next = 0;
   std::vector<float> emit_bn_scale, emit_bn_shift;   // host, ld floats each (empty: no folded BN)
+  // Set by a builder right before add_conv: the planes copy of this conv's output is only read by the three-launch form of
+  // the next block -- a forward in which planes_dropped() says that block runs fused (resnet_bneck.hip makes its own
+  // pre-activation from the f32 tensor) does not write it
+  bool planes_optional_next = false;
+  virtual bool planes_dropped() const { return false; }
   // Split-K policy (conv_mfma_ksplit.hip).  ksplit_design_batch > 0: a conv whose grid at THAT batch size (a constant
   // of the plan: 8 for the ResNet trunk = BASELINE config 2, 1 for the detector's single-image latency path) leaves
   // most of the 256 CUs idle gets its K steps cut into S ranges, S = what fills the chip at the design batch, at
@@ -874,6 +879,8 @@ struct Plan {
       pscales[in.pidx].x8_ok = false;                // a second consumer: keep the f16 form
     }
     const int x8_pidx = in.hi ? in.pidx : -1;
+    const bool planes_optional = planes_optional_next && emit != 0 && emit != 3;
+    planes_optional_next = false;
     const Buf i = in, o = *out;
     const float* rp = res ? res->p : nullptr;
     const unsigned short* z = zeros;
@@ -883,8 +890,9 @@ struct Plan {
                      const bool aff = folded_bn || L->out_exp != 0;
                      int x8_exp = 0;
                      const int x8 = plane_x8(x8_pidx, &x8_exp) ? 1 : 0;
+                     const bool drop = planes_optional && planes_dropped();
                      return L->forward(i.p, N, i.H, i.W, i.ld, o.no_f32 ? nullptr : o.p, o.ld, rp, relu_in, s, i.hi, i.lo,
-                                       z, o.hi, o.lo, (o.planes_relu || folded_bn) ? 1 : 0, aff ? L->d_pl_scale : nullptr,
+                                       z, drop ? nullptr : o.hi, drop ? nullptr : o.lo, (o.planes_relu || folded_bn) ? 1 : 0, aff ? L->d_pl_scale : nullptr,
                                        aff ? L->d_pl_shift : nullptr, 0, x8, x8_exp);
                    }});
     if (own_split) release_planes(in);
@@ -1729,6 +1737,23 @@ struct ResNetTrunk : Plan {
   bool ksplit_enabled = true;                      // XDET_RESNET_KSPLIT=0: the round-3 launch plan (A/B measurements)
   bool bneck_enabled = true;                       // identity blocks the fused kernel supports run as one launch
   bool bneck_fused_now = false;                    // set by a block's first op for its other two (ops run in order on one stream)
+  struct BneckGroup {
+    ConvLayer *La, *Lb, *Lc, *Lprev;               // the block's three convs; the closing conv of the block before it
+    BneckLaunch a;
+    size_t op_first;
+    bool next_fused = false;
+  };
+  std::vector<BneckGroup> bneck_groups;
+  // one decision per forward (the answer cannot change inside one): no calibration pass is measuring, and no planes tensor a
+  // fused kernel keeps on the CU carries an activation pre-scale
+  bool planes_dropped() const override { return !bneck_groups.empty() && bneck_all_ok(); }
+  bool bneck_all_ok() const {
+    if (after_op) return false;
+    for (const BneckGroup& g : bneck_groups)
+      if (g.Lprev->out_exp != 0 || g.La->in_exp != 0 || g.La->out_exp != 0 || g.Lb->in_exp != 0 || g.Lb->out_exp != 0 || g.Lc->in_exp != 0)
+        return false;
+    return true;
+  }
   typedef std::array<uintptr_t, 3> Key;            // (N, images, out): every pointer a captured graph bakes in
   std::map<Key, hipGraphExec_t> graphs;
   std::vector<Key> graph_order;
@@ -1817,6 +1842,8 @@ int ResNetTrunk::build() {
   XDET_TRY(add_pool("initial_max_pool", 0, x, nullptr, &t));
   x = t;
   const int filters[4] = {64, 128, 256, 512}, blocks[4] = {3, 4, 6, 3}, strides[4] = {1, 2, 2, 2};
+  ConvLayer* prev_Lc = nullptr;  // the closing conv of the block before (its planes affine is the next block's pre-activation BN)
+  bool have_prev_pl = false;
   Buf fused_pre;                 // planes-only pre-activation of the NEXT block, written by this block's last conv
   bool have_fused = false;
   const float *fused_sc = nullptr, *fused_sh = nullptr;   // its BN (a strided projection applies it to its own subsample)
@@ -1869,35 +1896,51 @@ int ResNetTrunk::build() {
         emit_bn_scale = sc;                         // (host copies: the conv keeps its own device arrays, which carry the
         emit_bn_shift = sh;                         //  planes' pre-scale; nsc / nsh below stay as they are for the projection)
       }
+      // (a stage's opening block in front of an identity block that can run fused: its planes copy is optional)
+      planes_optional_next = bneck_enabled && b == 0 && blocks[st] > 1 && g_default_precision == PREC_F16X3 && nsc != nullptr &&
+                             resnet_bneck_supported(4 * f, f, 4 * f, y2.H, y2.W, max_batch);
       XDET_TRY(conv_bn(c3, "", 0.f, 0, y2, 1, 4 * f, 1, 1, 0, &shortcut, 0, &y3));
       ConvLayer* Lc = static_cast<ConvLayer*>(layers.back().get());
-      // An identity block of stages 1-2 as ONE kernel (resnet_bneck.hip): the three ops stay in the plan -- a calibration
-      // pass measures the two inner planes tensors behind them, and a block whose inner planes carry an activation
-      // pre-scale keeps the three-launch form -- but the first one launches the fused kernel and the other two do nothing.
+      // An identity block as ONE kernel (resnet_bneck.hip), reading the raw block input (it applies the pre-activation BN +
+      // ReLU itself, with the arithmetic of the planes copy the previous block's closing conv writes) and writing the
+      // pre-activation planes of the next block only if that one runs as three launches.  The three ops stay in the plan:
+      // a calibration pass measures the inner planes tensors behind them, and a trunk in which any tensor of a fusable
+      // block carries an activation pre-scale runs every block as three launches (all or nothing per forward: a fused
+      // block does not write the planes an unfused successor would read).
       if (bneck_enabled && b > 0 && g_default_precision == PREC_F16X3 && nsc && ops.size() == op_first + 3 && pre.hi && y3.hi &&
-          La->ksplit < 1 && Lb->ksplit < 1 && Lc->ksplit < 1 &&
+          have_prev_pl && La->ksplit < 1 && Lb->ksplit < 1 && Lc->ksplit < 1 &&
           resnet_bneck_supported(pre.C, f, 4 * f, pre.H, pre.W, max_batch)) {
-        BneckLaunch a;
-        a.xin_hi = pre.hi; a.xin_lo = pre.lo; a.x = shortcut.p;
-        a.wa_hi = La->d_wt_hi_b; a.wa_lo = La->d_wt_lo_b; a.wb_hi = Lb->d_wt_hi_b; a.wb_lo = Lb->d_wt_lo_b;
-        a.wc_hi = Lc->d_wt_hi_b; a.wc_lo = Lc->d_wt_lo_b;
-        a.sc_a = La->d_scale; a.sh_a = La->d_shift; a.sc_b = Lb->d_scale; a.sh_b = Lb->d_shift;
-        a.sc_c = Lc->d_scale; a.sh_c = Lc->d_shift;
-        a.pl_sc = nullptr; a.pl_sh = nullptr;     // (Lc's planes affine is allocated by now; read at launch time below)
-        a.out = y3.p; a.out_hi = y3.hi; a.out_lo = y3.lo;
-        a.H = pre.H; a.W = pre.W; a.cin = pre.C; a.cmid = f; a.cout = 4 * f;
+        BneckGroup gr;
+        gr.La = La; gr.Lb = Lb; gr.Lc = Lc; gr.Lprev = prev_Lc;
+        gr.a.x = shortcut.p;
+        gr.a.wa_hi = La->d_wt_hi_b; gr.a.wa_lo = La->d_wt_lo_b; gr.a.wb_hi = Lb->d_wt_hi_b; gr.a.wb_lo = Lb->d_wt_lo_b;
+        gr.a.wc_hi = Lc->d_wt_hi_b; gr.a.wc_lo = Lc->d_wt_lo_b;
+        gr.a.sc_a = La->d_scale; gr.a.sh_a = La->d_shift; gr.a.sc_b = Lb->d_scale; gr.a.sh_b = Lb->d_shift;
+        gr.a.sc_c = Lc->d_scale; gr.a.sh_c = Lc->d_shift;
+        gr.a.pre_sc = gr.a.pre_sh = gr.a.pl_sc = gr.a.pl_sh = nullptr;     // (the planes affines: read at launch time)
+        gr.a.out = y3.p; gr.a.out_hi = y3.hi; gr.a.out_lo = y3.lo;
+        gr.a.H = pre.H; gr.a.W = pre.W; gr.a.cin = pre.C; gr.a.cmid = f; gr.a.cout = 4 * f;
+        gr.op_first = op_first;
+        if (!bneck_groups.empty() && bneck_groups.back().op_first + 3 == op_first) bneck_groups.back().next_fused = true;
+        bneck_groups.push_back(gr);
+        const size_t gi = bneck_groups.size() - 1;
         const auto run_a = ops[op_first].run, run_b = ops[op_first + 1].run, run_c = ops[op_first + 2].run;
         ops[op_first].run = [=](int N, hipStream_t st) {
-          bneck_fused_now = !after_op && La->out_exp == 0 && Lb->in_exp == 0 && Lb->out_exp == 0 && Lc->in_exp == 0;
+          bneck_fused_now = bneck_all_ok();
           if (!bneck_fused_now) return run_a(N, st);
-          BneckLaunch l = a;
-          l.pl_sc = Lc->d_pl_scale; l.pl_sh = Lc->d_pl_shift;
+          const BneckGroup& G = bneck_groups[gi];
+          BneckLaunch l = G.a;
+          l.pre_sc = G.Lprev->d_pl_scale; l.pre_sh = G.Lprev->d_pl_shift;
+          l.pl_sc = G.Lc->d_pl_scale; l.pl_sh = G.Lc->d_pl_shift;
+          if (G.next_fused) l.out_hi = l.out_lo = nullptr;          // the next block makes its own pre-activation
           return launch_resnet_bneck(l, N, st);
         };
         ops[op_first + 1].run = [=](int N, hipStream_t st) { return bneck_fused_now ? (int)XDET_OK : run_b(N, st); };
         ops[op_first + 2].run = [=](int N, hipStream_t st) { return bneck_fused_now ? (int)XDET_OK : run_c(N, st); };
         ops[op_first].name += " [+2: one kernel]";
       }
+      prev_Lc = Lc;
+      have_prev_pl = nsc != nullptr && g_default_precision != PREC_F32;
       if (nsc) {
         fused_pre = y3;                             // same shape; lives as planes only
         fused_pre.p = nullptr;
@@ -2099,7 +2142,7 @@ int xdet_conv3x3_patch_forward(void* layer, const uint16_t* in_hi, const uint16_
   return launch_conv3x3_patch(in_hi, L->precision == PREC_F16 ? nullptr : in_lo, L->d_wt_hi_b, L->d_wt_lo_b, L->d_scale,
                               L->d_shift, out, N, H, W, ld_out, L->relu_out, S(stream));
 }
-int xdet_resnet_bneck_forward(void* conv_a, void* conv_b, void* conv_c, const uint16_t* pre_hi, const uint16_t* pre_lo,
+int xdet_resnet_bneck_forward(void* conv_a, void* conv_b, void* conv_c, const float* pre_scale, const float* pre_shift,
                               const float* x, int N, int H, int W, float* out, const float* next_scale,
                               const float* next_shift, uint16_t* out_hi, uint16_t* out_lo, void* stream) {
   LayerBase* b[3] = {static_cast<LayerBase*>(conv_a), static_cast<LayerBase*>(conv_b), static_cast<LayerBase*>(conv_c)};
@@ -2114,9 +2157,9 @@ int xdet_resnet_bneck_forward(void* conv_a, void* conv_b, void* conv_c, const ui
                    A->cout_pad == A->cout && B->cout_pad == B->cout && C->cout_pad == C->cout,
                "resnet_bneck: need 1x1 (ReLU) -> 3x3 SAME stride 1 (ReLU) -> 1x1 with Cin -> Cmid -> Cmid -> Cin channels");
   XDET_REQUIRE(resnet_bneck_supported(A->cin, A->cout, C->cout, H, W, N), "resnet_bneck: unsupported channel counts / tensor size");
-  XDET_REQUIRE(pre_hi && pre_lo && x && out && (!out_hi || (out_lo && next_scale && next_shift)), "resnet_bneck: NULL argument");
+  XDET_REQUIRE(pre_scale && pre_shift && x && out && (!out_hi || (out_lo && next_scale && next_shift)), "resnet_bneck: NULL argument");
   BneckLaunch a;
-  a.xin_hi = pre_hi; a.xin_lo = pre_lo; a.x = x;
+  a.x = x; a.pre_sc = pre_scale; a.pre_sh = pre_shift;
   a.wa_hi = A->d_wt_hi_b; a.wa_lo = A->d_wt_lo_b; a.wb_hi = B->d_wt_hi_b; a.wb_lo = B->d_wt_lo_b; a.wc_hi = C->d_wt_hi_b; a.wc_lo = C->d_wt_lo_b;
   a.sc_a = A->d_scale; a.sh_a = A->d_shift; a.sc_b = B->d_scale; a.sh_b = B->d_shift; a.sc_c = C->d_scale; a.sh_c = C->d_shift;
   a.pl_sc = next_scale; a.pl_sh = next_shift;

@@ -88,7 +88,7 @@ SIGNATURES = {
     'xdet_depthwise_forward': (c_int, [c_void_p, PF, c_int, c_int, c_int, c_int, PF, c_int, c_void_p]),
     'xdet_sepconv_fused_forward': (c_int, [c_void_p, c_void_p, PF, c_int, c_int, c_int, c_int, PF, c_int, c_int, c_void_p]),
     'xdet_conv3x3_patch_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, PF, c_int, c_void_p]),
-    'xdet_resnet_bneck_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, PF, c_int, c_int, c_int, PF, PF, PF,
+    'xdet_resnet_bneck_forward': (c_int, [c_void_p, c_void_p, c_void_p, PF, PF, PF, c_int, c_int, c_int, PF, PF, PF,
                                           c_void_p, c_void_p, c_void_p]),
     'xdet_sepconv_fused_hpool_forward': (c_int, [c_void_p, c_void_p, PF, c_int, c_int, c_int, c_int, PF, c_int, c_int,
                                                  c_void_p]),
