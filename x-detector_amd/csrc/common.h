@@ -74,6 +74,10 @@ int launch_depthwise3x3(const float* in, const float* w9c, float* out, int N, in
                         int dil, int relu_in, hipStream_t s);
 int launch_maxpool3x3s2_add(const float* in, const float* res, float* out, int N, int H, int W, int C, int ld,
                             int Ho, int Wo, int pad_t, int pad_l, hipStream_t s);
+// pool -> bn + ReLU -> split planes only (the ResNet stem tail in front of the first block's pre-activation)
+int launch_maxpool3x3s2_bn_planes(const float* in, const float* scale, const float* shift, unsigned short* hi, unsigned short* lo,
+                                  int N, int H, int W, int C, int ld, int Ho, int Wo, int pad_t, int pad_l, float mul,
+                                  hipStream_t s);
 // vertical half only, over rows the producer already pooled horizontally (sepconv_fused.hip HPOOL)
 int launch_maxpool_v3s2_add(const float* in_hpooled, const float* res, float* out, int N, int H, int Wo, int C, int ld,
                             int Ho, int pad_t, hipStream_t s, unsigned short* sub_hi = nullptr, unsigned short* sub_lo = nullptr,

@@ -605,6 +605,77 @@ int launch_maxpool3x3s2_add(const float* in, const float* res, float* out, int N
   return XDET_OK;
 }
 
+// ResNet v2 stem tail (net/resnet_v2.py:311-330 initial_max_pool, then the first block's batch_norm_relu :142-156): the pooled
+// tensor has ONE reader, the first block's pre-activation, and that one is read as split planes only (its shortcut is a
+// projection of the pre-activation).  Same window walk as maxpool3x3s2_add_kernel; the result goes through bn + ReLU and
+// out as planes [pix/16][ld/32][16][32] (the arithmetic of bn_relu_kernel in net.hip: fma, NaN-keeping ReLU, * mul, hi / lo)
+// -- the pooled f32 tensor (29.5 MB per batch of 8) is neither written nor read back.
+__global__ __launch_bounds__(256) void maxpool3x3s2_bn_planes_kernel(const float* __restrict__ in, const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift,
+                                                                     unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+                                                                     int H, int W, int ld, int Ho, int Wo, int pad_t, int pad_l,
+                                                                     int nbands, int bands_per_image, float mul) {
+  const int c4n = ld >> 2;
+  const int item = blockIdx.y * 256 + threadIdx.x;
+  if (item >= Wo * c4n) return;
+  const int ox = item / c4n;
+  const int c = (item - ox * c4n) * 4;
+  const int per_xcd = gridDim.x >> 3;
+  const int band = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (band >= nbands) return;
+  const int n = band / bands_per_image;
+  const int oy0 = (band - n * bands_per_image) * MP_ROWS;
+  const float* base = in + (size_t)n * H * W * ld + c;
+  const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  const int ix0 = ox * 2 - pad_l;
+  auto hmax = [&](int iy) {
+    float4 m = ninf;
+    if ((unsigned)iy >= (unsigned)H) return m;
+    const float* row = base + (size_t)iy * W * ld;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ix0 + kx;
+      if ((unsigned)ix < (unsigned)W) m = mp_max4(m, *reinterpret_cast<const float4*>(row + (size_t)ix * ld));
+    }
+    return m;
+  };
+  const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+  float4 carry = hmax(oy0 * 2 - pad_t);
+  const int oy1 = min(Ho, oy0 + MP_ROWS);
+  for (int oy = oy0; oy < oy1; ++oy) {
+    const int iy = oy * 2 - pad_t;
+    const float4 a = hmax(iy + 1), b = hmax(iy + 2);
+    const float4 m = mp_max4(mp_max4(carry, a), b);
+    carry = b;
+    float v[4] = {fmaf(m.x, sc.x, sh.x), fmaf(m.y, sc.y, sh.y), fmaf(m.z, sc.z, sh.z), fmaf(m.w, sc.w, sh.w)};
+    _Float16 h[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = !(v[k] <= 0.f) ? v[k] : 0.f;
+      v[k] *= mul;
+      h[k] = (_Float16)v[k];
+      l[k] = (_Float16)(v[k] - (float)h[k]);
+    }
+    const int64_t pix = ((int64_t)n * Ho + oy) * Wo + ox;
+    const size_t po = ((size_t)((pix >> 4) * (ld >> 5) + (c >> 5)) << 9) + ((size_t)(pix & 15) << 5) + (size_t)(c & 31);
+    *reinterpret_cast<uint2*>(hi + po) = *reinterpret_cast<const uint2*>(h);
+    *reinterpret_cast<uint2*>(lo + po) = *reinterpret_cast<const uint2*>(l);
+  }
+}
+
+int launch_maxpool3x3s2_bn_planes(const float* in, const float* scale, const float* shift, unsigned short* hi, unsigned short* lo,
+                                  int N, int H, int W, int C, int ld, int Ho, int Wo, int pad_t, int pad_l, float mul,
+                                  hipStream_t s) {
+  XDET_REQUIRE(ld % 32 == 0 && ld >= C && in && scale && shift && hi && lo, "maxpool + bn planes: channel stride must be a multiple of 32");
+  if ((int64_t)N * Ho == 0) return XDET_OK;
+  const int bpi = (int)cdiv(Ho, MP_ROWS), nbands = N * bpi;
+  const dim3 grid((unsigned)(cdiv(nbands, 8) * 8), (unsigned)cdiv((int64_t)Wo * (ld / 4), 256));
+  hipLaunchKernelGGL(maxpool3x3s2_bn_planes_kernel, grid, dim3(256), 0, s, in, scale, shift, hi, lo, H, W, ld, Ho, Wo, pad_t, pad_l,
+                     nbands, bpi, mul);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
 // The vertical half of max_pooling2d(3, 2, 'same') (+ residual) over a tensor whose rows were already pooled
 // horizontally by the producing kernel (sepconv_fused.hip, HPOOL): in [N][H][Wo][ld] -> out [N][Ho][Wo][ld].
 // Same walk as maxpool3x3s2_add_kernel: one thread = 4 channels of a column, the shared row carried in a register.

@@ -524,6 +524,7 @@ struct Plan {
   void release_planes(const Buf& b) { give(b.hi); give(b.lo); }
   int new_buf(int H, int W, int C, Buf* b) {
     b->H = H; b->W = W; b->C = C;
+    b->no_f32 = false;                             // (a Buf that was copied from a planes-only tensor must not keep that flag)
     b->ld = C <= 4 ? 4 : round_up(C, 32);
     // +128 floats of slack: the conv loader may read a full 32-channel slice of the last pixel
     XDET_TRY(take(((size_t)max_batch * b->per_image() + 128) * sizeof(float), reinterpret_cast<void**>(&b->p)));
@@ -1125,6 +1126,12 @@ struct Plan {
         XDET_TRY(op.run(N, s));
       }
       if (after_op) XDET_TRY(after_op((int)i, s));
+      static const bool trace = getenv("XDET_TRACE_OPS") != nullptr;   // diagnosis: name the op a device fault belongs to
+      if (trace) {
+        fprintf(stderr, "xdet op %zu: %s ...", i, op.name.c_str());
+        const hipError_t e = hipStreamSynchronize(s);
+        fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e));
+      }
     }
     return XDET_OK;
   }
@@ -1735,6 +1742,7 @@ struct ResNetTrunk : Plan {
   Buf in4, outb;
   double flops = 0;
   bool ksplit_enabled = true;                      // XDET_RESNET_KSPLIT=0: the round-3 launch plan (A/B measurements)
+  bool stem_pool_bn = true;                        // XDET_RESNET_STEM_POOL=0: pool and pre-activation as two passes (A/B runs, tests)
   bool bneck_enabled = true;                       // identity blocks the fused kernel supports run as one launch
   bool bneck_fused_now = false;                    // set by a block's first op for its other two (ops run in order on one stream)
   struct BneckGroup {
@@ -1839,8 +1847,42 @@ int ResNetTrunk::build() {
   Buf x, t;
   // conv2d_fixed_padding(7, stride 2): explicit pad 3/3 then VALID (:89-100)
   XDET_TRY(conv_bn(cname(), "", 0.f, 0, in4, 7, 64, 2, 2, 0, nullptr, 0, &x, 3));
-  XDET_TRY(add_pool("initial_max_pool", 0, x, nullptr, &t));
-  x = t;
+  // initial_max_pool (:311-330).  On the split path its one reader is the first block's pre-activation, which is read as
+  // planes only: pool + that block's bn + ReLU + split in one pass (no pooled f32 tensor, one launch less)
+  bool stem_pre_fused = false;
+  Buf stem_pre;
+  if (g_default_precision != PREC_F32 && x.ld % 32 == 0 && stem_pool_bn) {
+    int Ho, Wo, pt, pl;
+    same_pad(x.H, 3, 2, 1, &pt, &Ho);
+    same_pad(x.W, 3, 2, 1, &pl, &Wo);
+    const std::string bn0 = "batch_normalization";
+    std::vector<float> sc, sh;
+    XDET_TRY(fold_bn(bn0, x.C, 1e-5f, nullptr, &sc, &sh));
+    sc.resize(x.ld, 0.f);
+    sh.resize(x.ld, 0.f);
+    float *dsc, *dsh;
+    XDET_TRY(alloc_bytes(sc.size() * 4, reinterpret_cast<void**>(&dsc)));
+    XDET_TRY(alloc_bytes(sh.size() * 4, reinterpret_cast<void**>(&dsh)));
+    XDET_HIP(hipMemcpy(dsc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+    XDET_HIP(hipMemcpy(dsh, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
+    stem_pre = Buf();
+    stem_pre.H = Ho; stem_pre.W = Wo; stem_pre.C = x.C; stem_pre.ld = x.ld; stem_pre.no_f32 = true;
+    XDET_TRY(new_planes(&stem_pre));
+    pscales[stem_pre.pidx].name = bn0 + " (pre-activation planes)";
+    const Buf i = x, o = stem_pre;
+    ops.push_back({"initial_max_pool + " + bn0, 0, 0.0, [=](int N, hipStream_t s) {
+                     return launch_maxpool3x3s2_bn_planes(i.p, dsc, dsh, o.hi, o.lo, N, i.H, i.W, i.C, i.ld, Ho, Wo, pt, pl,
+                                                          pmul(o.pidx), s);
+                   }});
+    stem_pre_fused = true;
+    // block 0 takes its shortcut from a projection of the pre-activation: the pooled tensor has no f32 reader.  `x` keeps the
+    // shape only (no pointer, no planes, no flags: the block loop copies it into its output descriptors)
+    x = Buf();
+    x.H = Ho; x.W = Wo; x.C = stem_pre.C; x.ld = stem_pre.ld;
+  } else {
+    XDET_TRY(add_pool("initial_max_pool", 0, x, nullptr, &t));
+    x = t;
+  }
   const int filters[4] = {64, 128, 256, 512}, blocks[4] = {3, 4, 6, 3}, strides[4] = {1, 2, 2, 2};
   ConvLayer* prev_Lc = nullptr;  // the closing conv of the block before (its planes affine is the next block's pre-activation BN)
   bool have_prev_pl = false;
@@ -1854,6 +1896,9 @@ int ResNetTrunk::build() {
       if (have_fused) {
         pre = fused_pre;
         (void)bname();                              // its BN was folded into the previous block's epilogue
+      } else if (st == 0 && b == 0 && stem_pre_fused) {
+        pre = stem_pre;
+        (void)bname();                              // ... into the pool pass
       } else {
         XDET_TRY(add_bn_relu(bname(), x, &pre));
       }
@@ -2567,6 +2612,7 @@ int xdet_resnet_create(void** net, int image_size, int max_batch) {
   r->image_size = image_size;
   r->max_batch = max_batch;
   if (const char* e = getenv("XDET_RESNET_KSPLIT")) r->ksplit_enabled = strcmp(e, "0") != 0;
+  if (const char* e = getenv("XDET_RESNET_STEM_POOL")) r->stem_pool_bn = strcmp(e, "0") != 0;
   if (const char* e = getenv("XDET_RESNET_BNECK")) r->bneck_enabled = strcmp(e, "0") != 0;     // 0: three launches per block (A/B runs, tests)
   XDET_HIP(hipGetDevice(&r->device));
   *net = r;
