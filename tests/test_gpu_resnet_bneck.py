@@ -1,5 +1,5 @@
-"""The fused identity-bottleneck kernel (csrc/resnet_bneck.hip; net/resnet_v2.py:142-184) and the stem's pool + pre-activation
-pass (maxpool3x3s2_bn_planes_kernel; :311-330 + :142-156) against the three-launch / two-pass forms of the
+"""The fused identity-bottleneck kernel (csrc/resnet_bneck.hip; net/resnet_v2.py:142-184) and the stem's own kernels
+(resnet_stem.hip, the 7x7 conv from NCHW; maxpool3x3s2_bn_planes_kernel, pool + pre-activation; :311-330 + :142-156) against the three-launch / two-pass forms of the
 same blocks: same products in the same order, so the trunk's output must be the same BITS -- on whole tiles (120 x 120
 and 60 x 60 maps: 480 x 480 input), on ragged ones (40 x 40 / 20 x 20: 160 x 160 input; 24 x 24: 96 x 96) and for a batch
 tail -- and, through tests/test_gpu_resnet.py, within 1e-4 of the oracle."""
@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def _trunk(w, size, max_batch, fused):
     from xdet.resnet import ResNet50Trunk
     from xdet.runtime import set_precision
-    keys = ('XDET_RESNET_BNECK', 'XDET_RESNET_STEM_POOL')     # read by xdet_resnet_create
+    keys = ('XDET_RESNET_BNECK', 'XDET_RESNET_STEM_POOL', 'XDET_RESNET_STEM7')     # read by xdet_resnet_create
     old = {k: os.environ.get(k) for k in keys}
     for k in keys:
         os.environ[k] = '1' if fused else '0'

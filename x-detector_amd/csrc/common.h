@@ -128,6 +128,11 @@ int launch_conv3x3_patch(const unsigned short* in_hi, const unsigned short* in_l
                          const unsigned short* wt_lo_blocked, const float* scale, const float* shift, float* out, int N, int H,
                          int W, int ldo, int relu, hipStream_t s);
 
+// ---- ResNet v2 stem conv 7x7 / stride 2 / 3 -> 64 from the NCHW input, patch staged in LDS (resnet_stem.hip) ----
+bool resnet_stem7x7_supported(int kh, int kw, int cin, int cout, int stride, int pad_mode, int pad, int S);
+int launch_resnet_stem7x7(const float* img_nchw, const unsigned short* wt_hi, const unsigned short* wt_lo, const float* scale,
+                          const float* shift, float* out, int N, int S, hipStream_t s);
+
 // ---- one ResNet v2 identity bottleneck block as a single kernel (resnet_bneck.hip) ----
 struct BneckLaunch {
   const float* x;                          // the block input (identity shortcut and, through bn + ReLU, the first conv's operand)

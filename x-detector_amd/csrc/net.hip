@@ -1742,6 +1742,9 @@ struct ResNetTrunk : Plan {
   Buf in4, outb;
   double flops = 0;
   bool ksplit_enabled = true;                      // XDET_RESNET_KSPLIT=0: the round-3 launch plan (A/B measurements)
+  bool stem7_enabled = true;                       // XDET_RESNET_STEM7=0: the stem conv on the generic small-cin kernel (A/B runs, tests)
+  bool stem7_direct = false;                       // decided at build: the stem op reads the NCHW images itself
+  const float* cur_images = nullptr;               // (graphs are keyed on this pointer)
   bool stem_pool_bn = true;                        // XDET_RESNET_STEM_POOL=0: pool and pre-activation as two passes (A/B runs, tests)
   bool bneck_enabled = true;                       // identity blocks the fused kernel supports run as one launch
   bool bneck_fused_now = false;                    // set by a block's first op for its other two (ops run in order on one stream)
@@ -1847,6 +1850,19 @@ int ResNetTrunk::build() {
   Buf x, t;
   // conv2d_fixed_padding(7, stride 2): explicit pad 3/3 then VALID (:89-100)
   XDET_TRY(conv_bn(cname(), "", 0.f, 0, in4, 7, 64, 2, 2, 0, nullptr, 0, &x, 3));
+  // ... on its own kernel, straight from the NCHW input (resnet_stem.hip): the generic small-cin kernel gathers one 16-byte
+  // load per (pixel, tap) from an NHWC4 copy of the image; same products, same order
+  if (stem7_enabled && g_default_precision == PREC_F16X3 && ops.size() == 1 &&
+      resnet_stem7x7_supported(7, 7, 3, 64, 2, 2, 3, image_size)) {
+    ConvLayer* L0 = static_cast<ConvLayer*>(layers.back().get());
+    const Buf o = x;
+    const int S = image_size;
+    ops[0].run = [=](int N, hipStream_t s) {
+      return launch_resnet_stem7x7(cur_images, L0->d_wt_hi, L0->d_wt_lo, L0->d_scale, L0->d_shift, o.p, N, S, s);
+    };
+    ops[0].name += " [LDS-staged patch, from NCHW]";
+    stem7_direct = true;
+  }
   // initial_max_pool (:311-330).  On the split path its one reader is the first block's pre-activation, which is read as
   // planes only: pool + that block's bn + ReLU + split in one pass (no pooled f32 tensor, one launch less)
   bool stem_pre_fused = false;
@@ -2612,6 +2628,7 @@ int xdet_resnet_create(void** net, int image_size, int max_batch) {
   r->image_size = image_size;
   r->max_batch = max_batch;
   if (const char* e = getenv("XDET_RESNET_KSPLIT")) r->ksplit_enabled = strcmp(e, "0") != 0;
+  if (const char* e = getenv("XDET_RESNET_STEM7")) r->stem7_enabled = strcmp(e, "0") != 0;
   if (const char* e = getenv("XDET_RESNET_STEM_POOL")) r->stem_pool_bn = strcmp(e, "0") != 0;
   if (const char* e = getenv("XDET_RESNET_BNECK")) r->bneck_enabled = strcmp(e, "0") != 0;     // 0: three launches per block (A/B runs, tests)
   XDET_HIP(hipGetDevice(&r->device));
@@ -2635,7 +2652,8 @@ int xdet_resnet_forward(void* net, const float* images, int N, float* out_nhwc, 
   XDET_REQUIRE(N > 0 && N <= r->max_batch, "batch must be in 1..max_batch");
   DeviceGuard guard(r->device);
   hipStream_t s = S(stream);
-  XDET_TRY(launch_nchw_to_nhwc4(images, r->in4.p, N, 3, r->image_size, r->image_size, 4, s));
+  r->cur_images = images;
+  if (!r->stem7_direct) XDET_TRY(launch_nchw_to_nhwc4(images, r->in4.p, N, 3, r->image_size, r->image_size, 4, s));
   XDET_TRY(r->run_stage(0, N, s));
   if (out_nhwc)
     XDET_HIP(hipMemcpyAsync(out_nhwc, r->outb.p, (size_t)N * r->outb.per_image() * 4, hipMemcpyDeviceToDevice, s));

@@ -19,6 +19,7 @@ SOURCES = [
     ('sepconv_fused.hip', []),
     ('conv3x3_patch.hip', []),
     ('resnet_bneck.hip', []),
+    ('resnet_stem.hip', []),
     ('psroialign.hip', ['-ffp-contract=off']),
     ('proposals.hip', ['-ffp-contract=off']),
     ('detect.hip', ['-ffp-contract=off']),
