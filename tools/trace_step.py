@@ -12,8 +12,8 @@ def main():
     back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
     rows = [r for r in rows if 'rocclr' not in r['Kernel_Name']]
-    # a step starts at every nchw_to_nhwc4 / stem kernel
-    starts = [i for i, r in enumerate(rows) if 'nchw_to_nhwc4' in r['Kernel_Name'] or 'stem_conv' in r['Kernel_Name']]
+    # a step starts at every nchw_to_nhwc4 / stem kernel (the detector's, the ResNet trunk's)
+    starts = [i for i, r in enumerate(rows) if 'nchw_to_nhwc4' in r['Kernel_Name'] or 'stem_conv' in r['Kernel_Name'] or 'stem7x7' in r['Kernel_Name']]
     a, b = starts[-back - 1], starts[-back]
     t0 = int(rows[a]['Start_Timestamp'])
     prev_end = t0
