@@ -38,8 +38,8 @@ names = ['wait all landed', 'transform0 + phase 1', 'epilogue 1', 'phase 2', 'ep
 per = 8
 for t in range(len(st) // per):
     row = st[t * per:(t + 1) * per]
-    if row[0] == 0 or (t and row[0] < st[(t - 1) * per]):
-        break
-    nxt = st[(t + 1) * per] if (t + 1) * per < len(st) and st[(t + 1) * per] > row[-1] else row[-1]
+    if row[0] == 0 or (t and row[0] < st[(t - 1) * per]) or np.any(np.diff(row) < 0) or row[-1] - row[0] > 10 ** 7:
+        break                                        # (slots behind the workgroup's last tile hold whatever the output row held)
+    nxt = st[(t + 1) * per] if (t + 1) * per < len(st) and 0 < st[(t + 1) * per] - row[-1] < 10 ** 6 else row[-1]
     d = list(np.diff(row)) + [nxt - row[-1]]
     print('tile %d: total %6d clk | ' % (t, nxt - row[0]) + ', '.join('%s %d' % (n, v) for n, v in zip(names, d)))

@@ -794,6 +794,14 @@ struct Plan {
     const int64_t tiles = conv_ksplit_tiles((int64_t)ksplit_design_batch * Ho * Wo, L->cout_pad, bn);
     static const int max_s = getenv("XDET_KSPLIT_MAX") ? atoi(getenv("XDET_KSPLIT_MAX")) : 8;      // A/B knobs
     static const int max_tiles = getenv("XDET_KSPLIT_TILES") ? atoi(getenv("XDET_KSPLIT_TILES")) : 128;
+    // A 3x3 layer of about one round of 128 x 128 tiles (ResNet-50 stage 2 at batch 8: 225) is not short of workgroups but of
+    // pipeline: the two-stage kernel pays ~1.2 us per 32-deep step there; the split-K kernel's four-stage ring with
+    // compile-time taps runs the same reduction with ONE range (bit-identical to the plain kernels) at ~0.65 us per step
+    static const int one_tiles = getenv("XDET_KSPLIT_ONE_TILES") ? atoi(getenv("XDET_KSPLIT_ONE_TILES")) : 0;
+    if (L->kh == 3 && bn == 128 && tiles > max_tiles && tiles <= one_tiles && nk >= 16) {
+      XDET_TRY(L->enable_ksplit(1, 1));
+      return XDET_OK;
+    }
     if (tiles > max_tiles || nk < 16) return XDET_OK;
     const int S = std::min(std::min(max_s, pow2_floor(256 / tiles)), pow2_floor(nk / 8));
     if (S < 2) return XDET_OK;
