@@ -794,11 +794,13 @@ struct Plan {
     const int64_t tiles = conv_ksplit_tiles((int64_t)ksplit_design_batch * Ho * Wo, L->cout_pad, bn);
     static const int max_s = getenv("XDET_KSPLIT_MAX") ? atoi(getenv("XDET_KSPLIT_MAX")) : 8;      // A/B knobs
     static const int max_tiles = getenv("XDET_KSPLIT_TILES") ? atoi(getenv("XDET_KSPLIT_TILES")) : 128;
-    // A 3x3 layer of about one round of 128 x 128 tiles (ResNet-50 stage 2 at batch 8: 225) is not short of workgroups but of
-    // pipeline: the two-stage kernel pays ~1.2 us per 32-deep step there; the split-K kernel's four-stage ring with
-    // compile-time taps runs the same reduction with ONE range (bit-identical to the plain kernels) at ~0.65 us per step
-    static const int one_tiles = getenv("XDET_KSPLIT_ONE_TILES") ? atoi(getenv("XDET_KSPLIT_ONE_TILES")) : 0;
-    if (L->kh == 3 && bn == 128 && tiles > max_tiles && tiles <= one_tiles && nk >= 16) {
+    // A layer of about one round of 128 x 128 tiles with a long K loop (ResNet-50 stage 2 at batch 8: the 3x3 convs and the
+    // opening 1x1 convs, 225 tiles, 36 / 16 steps) is not short of workgroups but of pipeline: the two-stage kernels pay
+    // ~1.2 us per 32-deep step there; the split-K kernel's four-stage ring (taps unrolled at compile time) runs the same
+    // reduction with ONE range -- bit-identical to the plain kernels -- at ~0.65 us per step (trunk 1.99 -> 1.92 ms, same-box
+    // A/B; XDET_KSPLIT_ONE_TILES=0: off)
+    static const int one_tiles = getenv("XDET_KSPLIT_ONE_TILES") ? atoi(getenv("XDET_KSPLIT_ONE_TILES")) : 256;
+    if (bn == 128 && tiles > max_tiles && tiles <= one_tiles && nk >= 16) {
       XDET_TRY(L->enable_ksplit(1, 1));
       return XDET_OK;
     }
