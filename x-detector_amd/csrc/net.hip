@@ -145,6 +145,7 @@ struct ConvLayer : LayerBase {
   // layer runs on that kernel at every batch size (its two modes are bit-identical), so results never depend on the batch.
   int ksplit = 0;                      // 0 = the layer is not on the split-K kernel
   int ks_mode = 0;                     // 0 = by grid size, 1 = parallel ranges, 2 = one workgroup per tile (tests)
+  bool ks_narrow = false;              // 128 x 64 tiles although the layer is a multiple of 128 wide (one range, twice the workgroups)
   int64_t ks_tiles = 0;                // tiles the scratch below was sized for
   float* d_ks_partial = nullptr;
   bool ks_owns_scratch = false;        // false: the slab belongs to the plan (one per stream, shared by its layers)
@@ -385,7 +386,7 @@ struct ConvLayer : LayerBase {
         XDET_REQUIRE(conv_ksplit_supported(kh, kw, (int64_t)N * H * W, ldi, cin_p, cout_pad),
                      "conv(ksplit): this batch's planes exceed the split-K kernel's 4 GiB addressing; run it in smaller batches");
         p.ksplit = ksplit; p.ks_partial = d_ks_partial;
-        return launch_conv_mfma_ksplit(p, cout_pad % 128 == 0 ? 128 : 64, precision == PREC_F16X3 ? 3 : 1, ks_mode, ks_tiles, s);
+        return launch_conv_mfma_ksplit(p, cout_pad % 128 == 0 && !ks_narrow ? 128 : 64, precision == PREC_F16X3 ? 3 : 1, ks_mode, ks_tiles, s);
       }
       return launch_conv_mfma_dma(p, n_tile, precision == PREC_F16X3 ? 3 : 1, s);
     }
@@ -807,6 +808,15 @@ struct Plan {
     if (tiles > max_tiles || nk < 16) return XDET_OK;
     const int S = std::min(std::min(max_s, pow2_floor(256 / tiles)), pow2_floor(nk / 8));
     if (S < 2) return XDET_OK;
+    // A pointwise layer that two ranges of 128-wide tiles only just spread over the chip (ResNet-50 stage 3's opening 1x1 at
+    // batch 8: 114 tiles, 32 steps -> 228 workgroups + a fold launch) runs as ONE range of 128 x 64 tiles instead: the same
+    // 228 workgroups, no scratch traffic, no second launch
+    static const bool narrow_on = !(getenv("XDET_KSPLIT_NARROW") && !strcmp(getenv("XDET_KSPLIT_NARROW"), "0"));
+    if (narrow_on && S == 2 && bn == 128 && L->kh == 1 && tiles * 2 <= 256 && nk <= 32) {
+      XDET_TRY(L->enable_ksplit(1, 1));
+      L->ks_narrow = true;
+      return XDET_OK;
+    }
     // scratch: borrowed from the plan -- bound in finish_ksplit() once every layer's need is known
     XDET_TRY(L->enable_ksplit(1, 448 / S));
     L->ksplit = S;
