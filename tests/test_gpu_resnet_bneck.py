@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def _trunk(w, size, max_batch, fused):
     from xdet.resnet import ResNet50Trunk
     from xdet.runtime import set_precision
-    keys = ('XDET_RESNET_BNECK', 'XDET_RESNET_STEM_POOL', 'XDET_RESNET_STEM7')     # read by xdet_resnet_create
+    keys = ('XDET_RESNET_BNECK', 'XDET_RESNET_STEM_POOL', 'XDET_RESNET_STEM7', 'XDET_RESNET_PRECONV')     # read by xdet_resnet_create
     old = {k: os.environ.get(k) for k in keys}
     for k in keys:
         os.environ[k] = '1' if fused else '0'

@@ -133,6 +133,13 @@ bool resnet_stem7x7_supported(int kh, int kw, int cin, int cout, int stride, int
 int launch_resnet_stem7x7(const float* img_nchw, const unsigned short* wt_hi, const unsigned short* wt_lo, const float* scale,
                           const float* shift, float* out, int N, int S, hipStream_t s);
 
+// ---- a bottleneck block's opening 1x1 conv with the pre-activation (bn + ReLU + split of the raw input) made on the CU
+//      (resnet_preconv.hip): out = planes of relu(bn_b(conv1x1(relu(bn_a(x))))) ----
+bool resnet_preconv_supported(int cin, int cmid, int64_t M);
+int launch_resnet_preconv(const float* x, const float* pre_sc, const float* pre_sh, const unsigned short* w_hi,
+                          const unsigned short* w_lo, const float* sc, const float* sh, unsigned short* out_hi,
+                          unsigned short* out_lo, int64_t M, int cin, int cmid, hipStream_t s);
+
 // ---- one ResNet v2 identity bottleneck block as a single kernel (resnet_bneck.hip) ----
 struct BneckLaunch {
   const float* x;                          // the block input (identity shortcut and, through bn + ReLU, the first conv's operand)

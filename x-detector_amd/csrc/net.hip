@@ -777,6 +777,8 @@ struct Plan {
   // the next block -- a forward in which planes_dropped() says that block runs fused (resnet_bneck.hip makes its own
   // pre-activation from the f32 tensor) does not write it
   bool planes_optional_next = false;
+  std::vector<char> planes_drop_ok;      // per registered conv: its one planes reader turned out to be a kernel that does not read them
+  int last_optional_idx = -1;            // index the last add_conv registered (-1: it registered nothing)
   virtual bool planes_dropped() const { return false; }
   // Split-K policy (conv_mfma_ksplit.hip).  ksplit_design_batch > 0: a conv whose grid at THAT batch size (a constant
   // of the plan: 8 for the ResNet trunk = BASELINE config 2, 1 for the detector's single-image latency path) leaves
@@ -902,6 +904,12 @@ struct Plan {
     const int x8_pidx = in.hi ? in.pidx : -1;
     const bool planes_optional = planes_optional_next && emit != 0 && emit != 3;
     planes_optional_next = false;
+    last_optional_idx = -1;
+    if (planes_optional) {
+      last_optional_idx = (int)planes_drop_ok.size();
+      planes_drop_ok.push_back(0);
+    }
+    const int drop_idx = last_optional_idx;
     const Buf i = in, o = *out;
     const float* rp = res ? res->p : nullptr;
     const unsigned short* z = zeros;
@@ -911,7 +919,7 @@ struct Plan {
                      const bool aff = folded_bn || L->out_exp != 0;
                      int x8_exp = 0;
                      const int x8 = plane_x8(x8_pidx, &x8_exp) ? 1 : 0;
-                     const bool drop = planes_optional && planes_dropped();
+                     const bool drop = planes_optional && planes_drop_ok[drop_idx] && planes_dropped();
                      return L->forward(i.p, N, i.H, i.W, i.ld, o.no_f32 ? nullptr : o.p, o.ld, rp, relu_in, s, i.hi, i.lo,
                                        z, drop ? nullptr : o.hi, drop ? nullptr : o.lo, (o.planes_relu || folded_bn) ? 1 : 0, aff ? L->d_pl_scale : nullptr,
                                        aff ? L->d_pl_shift : nullptr, 0, x8, x8_exp);
@@ -1768,6 +1776,9 @@ struct ResNetTrunk : Plan {
   bool stem_pool_bn = true;                        // XDET_RESNET_STEM_POOL=0: pool and pre-activation as two passes (A/B runs, tests)
   bool bneck_enabled = true;                       // identity blocks the fused kernel supports run as one launch
   bool bneck_fused_now = false;                    // set by a block's first op for its other two (ops run in order on one stream)
+  bool preconv_enabled = true;                     // XDET_RESNET_PRECONV=0: stage 2's opening 1x1 convs read planes (A/B runs, tests)
+  struct PreconvLayers { ConvLayer *Lprev, *La; };  // a conv1x1 that makes its pre-activation from the raw input (resnet_preconv.hip)
+  std::vector<PreconvLayers> preconv_layers;
   struct BneckGroup {
     ConvLayer *La, *Lb, *Lc, *Lprev;               // the block's three convs; the closing conv of the block before it
     BneckLaunch a;
@@ -1777,12 +1788,14 @@ struct ResNetTrunk : Plan {
   std::vector<BneckGroup> bneck_groups;
   // one decision per forward (the answer cannot change inside one): no calibration pass is measuring, and no planes tensor a
   // fused kernel keeps on the CU carries an activation pre-scale
-  bool planes_dropped() const override { return !bneck_groups.empty() && bneck_all_ok(); }
+  bool planes_dropped() const override { return (!bneck_groups.empty() || !preconv_layers.empty()) && bneck_all_ok(); }
   bool bneck_all_ok() const {
     if (after_op) return false;
     for (const BneckGroup& g : bneck_groups)
       if (g.Lprev->out_exp != 0 || g.La->in_exp != 0 || g.La->out_exp != 0 || g.Lb->in_exp != 0 || g.Lb->out_exp != 0 || g.Lc->in_exp != 0)
         return false;
+    for (const PreconvLayers& g : preconv_layers)
+      if (g.Lprev->out_exp != 0 || g.La->in_exp != 0 || g.La->out_exp != 0) return false;
     return true;
   }
   typedef std::array<uintptr_t, 3> Key;            // (N, images, out): every pointer a captured graph bakes in
@@ -1921,6 +1934,8 @@ int ResNetTrunk::build() {
   }
   const int filters[4] = {64, 128, 256, 512}, blocks[4] = {3, 4, 6, 3}, strides[4] = {1, 2, 2, 2};
   ConvLayer* prev_Lc = nullptr;  // the closing conv of the block before (its planes affine is the next block's pre-activation BN)
+  int prev_group = -1;
+  int prev_drop_idx = -1;        // planes_drop_ok entry of the previous block's closing conv (-1: none / that block runs fused)
   bool have_prev_pl = false;
   Buf fused_pre;                 // planes-only pre-activation of the NEXT block, written by this block's last conv
   bool have_fused = false;
@@ -1951,9 +1966,31 @@ int ResNetTrunk::build() {
       const std::string c1 = cname(), b1 = bname(), c2 = cname(), b2 = bname(), c3 = cname();
       // conv1x1 -> (BN+ReLU fused into its epilogue) -> conv3x3/s -> (BN+ReLU fused) -> conv1x1 + shortcut
       const size_t op_first = ops.size();
+      const int my_prev_group = prev_group;       // the bneck group of the block before, if it runs fused
+      prev_group = -1;
       emit_planes_next = 3;                       // the 3x3 (stride 1 or 2) takes its input as planes (only)
       XDET_TRY(conv_bn(c1, b1, 1e-5f, 0, pre, 1, f, 1, 1, 1, nullptr, 0, &y1));
       ConvLayer* La = static_cast<ConvLayer*>(layers.back().get());
+      // The opening 1x1 of a stage-2 block on resnet_preconv.hip: it makes relu(bn(x)) from the raw block input itself, so
+      // the producer of x does not write the planes copy (decided per forward with the fused blocks: bneck_all_ok()).
+      const bool preconv = preconv_enabled && g_default_precision == PREC_F16X3 && have_prev_pl && pre.hi && pre.no_f32 && x.p &&
+                           ops.size() == op_first + 1 && y1.hi && resnet_preconv_supported(pre.C, f, (int64_t)max_batch * pre.H * pre.W) &&
+                           !(bneck_enabled && b > 0 && resnet_bneck_supported(pre.C, f, 4 * f, pre.H, pre.W, max_batch));
+      if (preconv) {
+        preconv_layers.push_back({prev_Lc, La});
+        if (my_prev_group >= 0) bneck_groups[my_prev_group].next_fused = true;
+        if (prev_drop_idx >= 0) planes_drop_ok[prev_drop_idx] = 1;
+        ConvLayer* Lp = prev_Lc;
+        const Buf xi = x, yo = y1;
+        const int cin = pre.C, cm = f;
+        const auto run_a = ops[op_first].run;
+        ops[op_first].run = [=](int N, hipStream_t st) {
+          if (!bneck_all_ok()) return run_a(N, st);
+          return launch_resnet_preconv(xi.p, Lp->d_pl_scale, Lp->d_pl_shift, La->d_wt_hi_b, La->d_wt_lo_b, La->d_scale, La->d_shift,
+                                       yo.hi, yo.lo, (int64_t)N * xi.H * xi.W, cin, cm, st);
+        };
+        ops[op_first].name += " [pre-activation on the CU]";
+      }
       emit_planes_next = 3;                       // the closing 1x1 always does
       XDET_TRY(conv_bn(c2, b2, 1e-5f, 0, y1, 3, f, s, s > 1 ? 2 : 1, 1, nullptr, 0, &y2, 1));
       ConvLayer* Lb = static_cast<ConvLayer*>(layers.back().get());
@@ -1978,10 +2015,12 @@ int ResNetTrunk::build() {
         emit_bn_shift = sh;                         //  planes' pre-scale; nsc / nsh below stay as they are for the projection)
       }
       // (a stage's opening block in front of an identity block that can run fused: its planes copy is optional)
-      planes_optional_next = bneck_enabled && b == 0 && blocks[st] > 1 && g_default_precision == PREC_F16X3 && nsc != nullptr &&
-                             resnet_bneck_supported(4 * f, f, 4 * f, y2.H, y2.W, max_batch);
+      // (the planes copy of this block's output has one reader, the next block's opening conv: if that block turns out to run on
+      //  a kernel that makes its own pre-activation, it marks this conv's planes as droppable)
+      planes_optional_next = g_default_precision == PREC_F16X3 && nsc != nullptr;
       XDET_TRY(conv_bn(c3, "", 0.f, 0, y2, 1, 4 * f, 1, 1, 0, &shortcut, 0, &y3));
       ConvLayer* Lc = static_cast<ConvLayer*>(layers.back().get());
+      const int my_drop_idx = last_optional_idx;  // this block's closing conv, if its planes copy is optional
       // An identity block as ONE kernel (resnet_bneck.hip), reading the raw block input (it applies the pre-activation BN +
       // ReLU itself, with the arithmetic of the planes copy the previous block's closing conv writes) and writing the
       // pre-activation planes of the next block only if that one runs as three launches.  The three ops stay in the plan:
@@ -2003,8 +2042,10 @@ int ResNetTrunk::build() {
         gr.a.H = pre.H; gr.a.W = pre.W; gr.a.cin = pre.C; gr.a.cmid = f; gr.a.cout = 4 * f;
         gr.op_first = op_first;
         if (!bneck_groups.empty() && bneck_groups.back().op_first + 3 == op_first) bneck_groups.back().next_fused = true;
+        if (prev_drop_idx >= 0) planes_drop_ok[prev_drop_idx] = 1;
         bneck_groups.push_back(gr);
         const size_t gi = bneck_groups.size() - 1;
+        prev_group = (int)gi;
         const auto run_a = ops[op_first].run, run_b = ops[op_first + 1].run, run_c = ops[op_first + 2].run;
         ops[op_first].run = [=](int N, hipStream_t st) {
           bneck_fused_now = bneck_all_ok();
@@ -2022,6 +2063,7 @@ int ResNetTrunk::build() {
       }
       prev_Lc = Lc;
       have_prev_pl = nsc != nullptr && g_default_precision != PREC_F32;
+      prev_drop_idx = prev_group >= 0 ? -1 : my_drop_idx;      // (a fused block never runs its closing conv's op)
       if (nsc) {
         fused_pre = y3;                             // same shape; lives as planes only
         fused_pre.p = nullptr;
@@ -2650,7 +2692,8 @@ int xdet_resnet_create(void** net, int image_size, int max_batch) {
   if (const char* e = getenv("XDET_RESNET_KSPLIT")) r->ksplit_enabled = strcmp(e, "0") != 0;
   if (const char* e = getenv("XDET_RESNET_STEM7")) r->stem7_enabled = strcmp(e, "0") != 0;
   if (const char* e = getenv("XDET_RESNET_STEM_POOL")) r->stem_pool_bn = strcmp(e, "0") != 0;
-  if (const char* e = getenv("XDET_RESNET_BNECK")) r->bneck_enabled = strcmp(e, "0") != 0;     // 0: three launches per block (A/B runs, tests)
+  if (const char* e = getenv("XDET_RESNET_BNECK")) r->bneck_enabled = strcmp(e, "0") != 0;
+  if (const char* e = getenv("XDET_RESNET_PRECONV")) r->preconv_enabled = strcmp(e, "0") != 0;     // 0: three launches per block (A/B runs, tests)
   XDET_HIP(hipGetDevice(&r->device));
   *net = r;
   return XDET_OK;

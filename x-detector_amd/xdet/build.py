@@ -20,6 +20,7 @@ SOURCES = [
     ('conv3x3_patch.hip', []),
     ('resnet_bneck.hip', []),
     ('resnet_stem.hip', []),
+    ('resnet_preconv.hip', []),
     ('psroialign.hip', ['-ffp-contract=off']),
     ('proposals.hip', ['-ffp-contract=off']),
     ('detect.hip', ['-ffp-contract=off']),
