@@ -100,6 +100,8 @@ def parse():
     ap.add_argument('--cross', default='f16', choices=['f16', 'fp8'],
                     help="cross terms of the split-precision products of the depthwise -> pointwise layers: f16 (f16x3 everywhere) "
                          "or fp8 copies of the operands (the x8 form, after the calibration pass)")
+    ap.add_argument('--large-sep', default='auto', choices=['auto', 'direct', 'spectral'],
+                    help='large-separable convs: DFT-domain GEMMs (auto, where the feature map allows) or the direct (15,1)/(1,15) convs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=2000, help='images of the bounded CPU-baseline sample (~10-20 s)')
     ap.add_argument('--cpu-batch', type=int, default=0,
@@ -423,7 +425,7 @@ def main():
         sb = B // ways                               # images per sub-batch / net instance
         nets = [LightHeadDetector(weights, image_size=S, max_batch=sb, rpn_post_nms_top_n=args.proposals,
                                   rpn_stream='main' if args.serial_rpn else 'side', conv3x3=args.conv3x3,
-                                  pool=args.pool, ksplit=args.ksplit, cross=args.cross,
+                                  pool=args.pool, ksplit=args.ksplit, cross=args.cross, large_sep=args.large_sep,
                                   pool_sub=None if args.pool_sub == 'on' else args.pool_sub)   # (None: the library's default;
                                   # an older build behind XDET_LIB, tools/ab_bench.sh, does not know the option)
                 for _ in range(ways)]
