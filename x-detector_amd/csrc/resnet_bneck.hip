@@ -270,16 +270,21 @@ __global__ __launch_bounds__(512) void resnet_bneck_kernel(BneckParams p) {
   //      tile's phase 2 (a phase later they are there; held across the whole kernel they cost the other phases 32 registers
   //      and the compiler spilled -- every scratch reload waits with vmcnt(0), i.e. for the whole weight stream) ----
   bk_f16x8 wch[NB3][NCC2][2], wcl[NB3][NCC2][2];
-  auto load_wc = [&]() {
+  // (raw buffer loads: one 32-bit per-lane offset, the K block / half in the scalar offset -- as plain pointer loads the eight
+  //  64-bit addresses were loop invariants the compiler kept across the whole tile loop, and spilled)
+  const __amdgpu_buffer_rsrc_t r_wch = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.wc_hi), 0, NCC2 * COUT * 64, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_wcl = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.wc_lo), 0, NCC2 * COUT * 64, 0x00020000);
+  auto load_wc = [&](int frow_l, int fh_l) {
+    const int vo = frow_l * 64 + fh_l * 16;
 #pragma unroll
     for (int j = 0; j < NB3; ++j)
 #pragma unroll
       for (int kb = 0; kb < NCC2; ++kb)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const size_t o = ((size_t)kb * COUT + (wave * NB3 + j) * 32 + frow) * 32 + (ks * 2 + fh) * 8;
-          wch[j][kb][ks] = *reinterpret_cast<const bk_f16x8*>(p.wc_hi + o);
-          wcl[j][kb][ks] = *reinterpret_cast<const bk_f16x8*>(p.wc_lo + o);
+          const int so = (kb * COUT + (wave * NB3 + j) * 32) * 64 + ks * 32;
+          wch[j][kb][ks] = __builtin_bit_cast(bk_f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_wch, vo, so, 0));
+          wcl[j][kb][ks] = __builtin_bit_cast(bk_f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_wcl, vo, so, 0));
         }
   };
 
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(512) void resnet_bneck_kernel(BneckParams p) {
     stamp();                                       // 3: epilogue 1 issued
     // ---- conv1x1_c's weights: requested now, used a phase later.  They enter the in-order VMEM queue behind W(NK1 + 2) and in
     //      front of W(NK1 + 3): the first three steps of phase 2 count them as younger ----
-    load_wc();
+    load_wc(frow_t, fh_t);
     // =============================== phase 2: conv3x3_b out of mid1 ===============================
     bk_f32x16 acc2;
 #pragma unroll
@@ -622,7 +627,11 @@ __global__ __launch_bounds__(512) void resnet_bneck_kernel(BneckParams p) {
   }
   if (p.dbg == 9 && blockIdx.x == 0) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (tid < 64) reinterpret_cast<unsigned long long*>(p.out)[tid] = reinterpret_cast<const unsigned long long*>(smem + G::OFF_STAMP)[tid];
+    if (wave == 0) {                               // (the lane id recomputed: `tid` kept alive to here cost a spilled register)
+      int l;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+      reinterpret_cast<unsigned long long*>(p.out)[l] = reinterpret_cast<const unsigned long long*>(smem + G::OFF_STAMP)[l];
+    }
   }
 }
 
