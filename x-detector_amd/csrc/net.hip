@@ -1974,7 +1974,8 @@ int ResNetTrunk::build() {
       // The opening 1x1 of a stage-2 block on resnet_preconv.hip: it makes relu(bn(x)) from the raw block input itself, so
       // the producer of x does not write the planes copy (decided per forward with the fused blocks: bneck_all_ok()).
       const bool preconv = preconv_enabled && g_default_precision == PREC_F16X3 && have_prev_pl && pre.hi && pre.no_f32 && x.p &&
-                           ops.size() == op_first + 1 && y1.hi && resnet_preconv_supported(pre.C, f, (int64_t)max_batch * pre.H * pre.W) &&
+                           ops.size() == op_first + 1 && y1.hi && La->ksplit <= 1 &&     // (a layer with a split reduction keeps its summation tree)
+                           resnet_preconv_supported(pre.C, f, (int64_t)max_batch * pre.H * pre.W) &&
                            !(bneck_enabled && b > 0 && resnet_bneck_supported(pre.C, f, 4 * f, pre.H, pre.W, max_batch));
       if (preconv) {
         preconv_layers.push_back({prev_Lc, La});

@@ -11,7 +11,8 @@
 // weights come through a four-stage LDS-DMA ring three steps ahead; one barrier per 32-deep K step.  The producer of x then
 // does not write the planes copy at all (ResNetTrunk: planes_optional_next / BneckGroup::next_fused).
 //
-// Tile = 128 consecutive pixels x all CMID output channels (8 waves: 4 row blocks x 2 column halves), persistent workgroups.
+// Tile = 128 (or 64) consecutive pixels x all CMID output channels (8 waves: 4 row blocks x 2 column halves, or 2 x 4),
+// persistent workgroups.
 // MFMAs with the operands swapped (weights first): a lane holds one pixel and four consecutive channels per register
 // group, the epilogue (bn_b + ReLU, split) stores 8 bytes per plane straight into the [pix/16][C/32][16][32] layout.
 // K order, product order and epilogue arithmetic are conv_dma_f16_kernel's: bit-identical (tests/test_gpu_resnet_bneck.py).
@@ -71,18 +72,19 @@ __device__ __forceinline__ void pc_static_for(F&& f) {
   }
 }
 
-template <int CMID, int CIN>
+template <int CMID, int CIN, int BM_>
 struct PreconvGeom {
-  static constexpr int BM = 128;                   // pixels per tile
+  static constexpr int BM = BM_;                   // pixels per tile (128, or 64 where 128 leaves too few tiles)
+  static constexpr int MB = BM / 32, WPM = 8 / MB;  // row blocks; waves per row block
   static constexpr int NK = CIN / 32;
-  static constexpr int NBW = CMID / 64;            // 32-column blocks per wave (the wave's half of the output channels)
+  static constexpr int NBW = (CMID / 32) / WPM;    // 32-column blocks per wave
   static constexpr int A_PLANE = BM * 64, A_STAGE = 2 * A_PLANE;
   static constexpr int B_PLANE = CMID * 64, B_STAGE = 2 * B_PLANE;
   static constexpr int OFF_A = 0, OFF_B = 2 * A_STAGE, OFF_T = OFF_B + 4 * B_STAGE;
   static constexpr int LDS_BYTES = OFF_T + (2 * CIN + 2 * CMID) * 4;
   static constexpr int XQ = BM * 8 / 512;          // 4-channel items of a K step's A tile per lane (2)
   static constexpr int BPW = CMID / 64;            // weight pieces per wave and K step
-  static_assert(CMID % 64 == 0 && CIN % 32 == 0 && LDS_BYTES <= 160 * 1024, "geometry");
+  static_assert(CMID % 64 == 0 && CIN % 32 == 0 && (BM == 64 || BM == 128) && (CMID / 32) % WPM == 0 && LDS_BYTES <= 160 * 1024, "geometry");
   // in-order VMEM queue of a wave: step s (after its barrier) issues the x loads of step s + 3, then the weight pieces of
   // step s + 3; the prologue issues groups -3, -2, -1 (resnet_bneck.hip, BneckGeom)
   static constexpr int nx(int s) { return s + 3 < NK ? XQ : 0; }
@@ -91,9 +93,9 @@ struct PreconvGeom {
   static constexpr int younger_x(int s) { return nb(s - 2) + nx(s - 1) + nb(s - 1) + nx(s) + nb(s); }
 };
 
-template <int CMID, int CIN>
+template <int CMID, int CIN, int BM_>
 __global__ __launch_bounds__(512) void resnet_preconv_kernel(PreconvParams p) {
-  using G = PreconvGeom<CMID, CIN>;
+  using G = PreconvGeom<CMID, CIN, BM_>;
   constexpr int NK = G::NK, NBW = G::NBW, XQ = G::XQ, BPW = G::BPW, BM = G::BM;
   constexpr int A_PLANE = G::A_PLANE, A_STAGE = G::A_STAGE, B_PLANE = G::B_PLANE, B_STAGE = G::B_STAGE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -176,8 +178,8 @@ __global__ __launch_bounds__(512) void resnet_preconv_kernel(PreconvParams p) {
       pc_ds_write_b64<A_PLANE>(base + aw_off[q], l);
     }
   };
-  // fragments: this wave's row block mi = wave >> 1, column blocks (wave & 1) * NBW + j
-  const int mi = wave >> 1, nh = wave & 1;
+  // fragments: this wave's row block mi = wave / WPM, column blocks (wave % WPM) * NBW + j
+  const int mi = wave / G::WPM, nh = wave % G::WPM;
   unsigned a_off[2], b_off[2][NBW];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
@@ -279,6 +281,9 @@ __global__ __launch_bounds__(512) void resnet_preconv_kernel(PreconvParams p) {
   }
 }
 
+// (cin, cmid): stage 2's blocks (256 / 512 -> 128; 128-pixel tiles: 900 / 225 at batch 8).  Stage 3's (512 / 1024 -> 256 as
+// 64-pixel tiles: 450 / 113) was built and measured: the 7,200-row layers do not fill the chip either way and every tile
+// streams the whole 1 MB filter -- trunk 1.867 -> 1.878 ms, not kept (the template still takes BM = 64).
 bool resnet_preconv_supported(int cin, int cmid, int64_t M) {
   return cmid == 128 && (cin == 256 || cin == 512) && (size_t)M * cin * 4 < ((size_t)1 << 31);
 }
@@ -293,17 +298,17 @@ int launch_resnet_preconv(const float* x, const float* pre_sc, const float* pre_
   p.x = x; p.pre_sc = pre_sc; p.pre_sh = pre_sh; p.w_hi = w_hi; p.w_lo = w_lo; p.sc = sc; p.sh = sh;
   p.out_hi = out_hi; p.out_lo = out_lo;
   p.M = (int)M;
-  p.ntiles = (int)cdiv(M, 128);
-  const dim3 g((unsigned)std::min<int64_t>(256, cdiv(p.ntiles, 8) * 8));
-  auto go = [&](auto kern, int lds) {
+  auto go = [&](auto kern, int lds, int bm) {
     static DeviceOnce once;
     XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), lds));
+    p.ntiles = (int)cdiv(M, bm);
+    const dim3 g((unsigned)std::min<int64_t>(256, cdiv(p.ntiles, 8) * 8));
     hipLaunchKernelGGL(kern, g, dim3(512), lds, s, p);
     XDET_LAUNCH_CHECK();
     return (int)XDET_OK;
   };
-  if (cin == 256) return go(resnet_preconv_kernel<128, 256>, PreconvGeom<128, 256>::LDS_BYTES);
-  return go(resnet_preconv_kernel<128, 512>, PreconvGeom<128, 512>::LDS_BYTES);
+  if (cin == 256) return go(resnet_preconv_kernel<128, 256, 128>, PreconvGeom<128, 256, 128>::LDS_BYTES, 128);
+  return go(resnet_preconv_kernel<128, 512, 128>, PreconvGeom<128, 512, 128>::LDS_BYTES, 128);
 }
 
 }  // namespace xdet
