@@ -114,8 +114,9 @@ struct BneckGeom {
   static constexpr int MP = CMID * 4 + 16;         // bytes per mid row: hi | lo | pad (pitch = 4 banks mod 64: 16 consecutive rows
                                                    // of a ds_read_b128 lane group hit 16 different 4-bank windows)
   static constexpr int OFF_A = 0;                  // two A tiles (phase 1); mid2 (phases 2 -> 3) lies over them
-  static constexpr int OFF_B = 2 * A_STAGE;        // four weight stages
-  static constexpr int OFF_M1 = OFF_B + 4 * B_STAGE;
+  static constexpr int NRING = 6;                  // weight stages: phase 1 runs three steps ahead, phase 2 one triple of taps
+  static constexpr int OFF_B = 2 * A_STAGE;
+  static constexpr int OFF_M1 = OFF_B + NRING * B_STAGE;
   static constexpr int OFF_T = OFF_M1 + (M1 + 4) * MP;   // (+4 rows: the idle columns 30, 31 read up to 3 pixels past the patch)
   static constexpr int T_FLOATS = 4 * CMID + 6 * COUT;
   static constexpr int OFF_STAMP = OFF_T + T_FLOATS * 4;      // XDET_BNECK_DEBUG=9: s_memtime stamps of workgroup 0 (64 x 8 bytes)
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(512) void resnet_bneck_kernel(BneckParams p) {
   }
   // weight stream of a tile: steps 0 .. NK1-1 = K blocks of W_a, then NK2 steps of W_b in (chunk, tap) order
   auto issue_b = [&](int j) {
-    const int slot = j & 3;
+    const int slot = j % G::NRING;
     unsigned char* dst = smem + G::OFF_B + slot * B_STAGE + (wave & 1) * B_PLANE;
     if (j < NK1) {
 #pragma unroll
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(512) void resnet_bneck_kernel(BneckParams p) {
           for (int q = 0; q < 4; ++q)
             res[i][0][q] = __builtin_bit_cast(bk_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_x, (int)o_vo[i], 8 * q * 4, 0));
       }
-      const unsigned sa = lds0 + G::OFF_A + (kt & 1) * A_STAGE, sb = lds0 + G::OFF_B + (kt & 3) * B_STAGE;
+      const unsigned sa = lds0 + G::OFF_A + (kt & 1) * A_STAGE, sb = lds0 + G::OFF_B + (kt % G::NRING) * B_STAGE;
       bk_f16x8 bh[2], bl[2], ah0[2], al0[2], ah1[2], al1[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -451,27 +452,28 @@ __global__ __launch_bounds__(512) void resnet_bneck_kernel(BneckParams p) {
     bk_f32x16 acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    // One barrier per TRIPLE of taps (a row of the 3 x 3 window of one 32-channel chunk): its three weight stages were requested
+    // a triple earlier; the next triple's are requested right behind the barrier into the stages the previous one used.
+    constexpr int NLATE = NB3 * NCC2 * 4;          // the loads requested in front of this phase (conv1x1_c's weights)
+    static_assert(3 * BPW + NLATE + NRES < 64, "vmcnt is a 6-bit counter");
+    static_assert(G::NK2 % 3 == 0 && G::NRING == 6, "two triples of weight stages");
 #pragma unroll 1
-    for (int cc = 0; cc < NCC2; ++cc) {
+    for (int T = 0; T < G::NK2 / 3; ++T) {
+      const int cc = T / 3, ky = T - cc * 3;
+      const int j0 = NK1 + 3 * T;
+      // first triple: younger than its stages are conv1x1_c's weights and, in the wave whose K step was phase 1's last, the
+      // shortcut rows; later triples: everything older has to be there anyway
+      if (T == 0) {
+        if (wave == NK1 - 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NLATE + NRES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NLATE) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+      if (T + 1 < G::NK2 / 3) { issue_b(j0 + 3); issue_b(j0 + 4); issue_b(j0 + 5); }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int j = NK1 + cc * 9 + tap;
-        // W(j) has landed (younger: the pieces of the next two steps, while there are any); mid1 is complete (first step) /
-        // every wave is done with W(j - 1)
-        const bool last_cc = cc == NCC2 - 1;
-        constexpr int NLATE = NB3 * NCC2 * 4;                      // the loads requested in front of this phase (conv1x1_c's weights)
-        static_assert(2 * BPW + NLATE + NRES < 64, "vmcnt is a 6-bit counter");
-        if (tap == 8 && last_cc) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else if (tap == 7 && last_cc) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(BPW) : "memory");
-        else if (tap < 3 && cc == 0) {
-          // (the shortcut loads of the waves whose K step was one of phase 1's last three are still inside their window)
-          if (NK1 + tap - wave <= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * BPW + NLATE + NRES) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * BPW + NLATE) : "memory");
-        } else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * BPW) : "memory");
-        if (!(last_cc && tap >= 6)) issue_b(j + 3);
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned sb = lds0 + G::OFF_B + (j & 3) * B_STAGE;
-        const int ky = tap / 3, kx = tap - ky * 3;
+      for (int kx = 0; kx < 3; ++kx) {
+        const unsigned sb = lds0 + G::OFF_B + (unsigned)((j0 + kx) % G::NRING) * B_STAGE;
         const unsigned ar = m1_base + (unsigned)(((mi2 + ky) * 32 + frow_t + kx) * MP + cc * 64 + fh_t * 16);
         bk_f16x8 bh[2], bl[2], ah[2], al[2];
 #pragma unroll
