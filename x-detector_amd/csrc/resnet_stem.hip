@@ -36,6 +36,25 @@ constexpr int RS_W_B = 64 * RS_WP;                   // bytes per filter plane
 constexpr int RS_NPIX = (RS_PR * RS_PC + 511) / 512; // patch pixels per thread (3)
 constexpr int RS_LDS = 2 * RS_PATCH_B + 2 * RS_W_B;
 
+typedef unsigned rs_u4 __attribute__((ext_vector_type(4)));
+
+// (one asm block: gfx950 wants a wait state between a half-register write and a VALU read of the register, and inline asm is
+//  opaque to the hazard recogniser -- see sf_split4)
+__device__ __forceinline__ void rs_split4(const float4 a, uint2* h, uint2* l) {
+  unsigned h0, h1, l0, l1;
+  asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+      "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
+      "v_fma_mixlo_f16 %2, %4, 1.0, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %3, %6, 1.0, -%1 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %2, %5, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %3, %7, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "s_nop 0"
+      : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1)
+      : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w));
+  *h = make_uint2(h0, h1);
+  *l = make_uint2(l0, l1);
+}
+
 struct ResnetStemParams {
   const float* img;          // NCHW f32 [N][3][S][S]
   const u16* wt_hi; const u16* wt_lo;   // [64][224] f16, k = tap * 4 + channel
@@ -129,14 +148,13 @@ __global__ __launch_bounds__(512) void resnet_stem7x7_kernel(ResnetStemParams p)
       const unsigned o1 = fh ? (unsigned)tap_off(4 * kk + 3) : (unsigned)tap_off(4 * kk + 1);
       const float4 v0 = *reinterpret_cast<const float4*>(a_base + o0);
       const float4 v1 = *reinterpret_cast<const float4*>(a_base + o1);
-      const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      rs_f16x8 ah, al;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const _Float16 h = (_Float16)v[e];
-        ah[e] = h;
-        al[e] = (_Float16)(v[e] - (float)h);
-      }
+      // hi = f16(v), lo = f16(v - float(hi)): v_cvt_pk_f16_f32 + v_fma_mixlo / mixhi_f16 (sepconv_fused.hip sf_split4: the same bits
+      // as convert / convert back / subtract / convert -- the difference has at most 13 significant bits -- in 6 instructions per 4 values)
+      uint2 h0, l0, h1, l1;
+      rs_split4(v0, &h0, &l0);
+      rs_split4(v1, &h1, &l1);
+      const rs_u4 hq = {h0.x, h0.y, h1.x, h1.y}, lq = {l0.x, l0.y, l1.x, l1.y};
+      const rs_f16x8 ah = __builtin_bit_cast(rs_f16x8, hq), al = __builtin_bit_cast(rs_f16x8, lq);
       rs_f16x8 bh[2], bl[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
