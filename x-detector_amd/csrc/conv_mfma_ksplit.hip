@@ -63,9 +63,13 @@ __device__ __forceinline__ void ks_static_for(F&& f) {
 // on addresses (the generic LDS-DMA kernels recompute ~12 per piece, and every issue slot between MFMAs costs
 // matrix-pipe time).  Ranges are whole channel chunks: range r = chunks [r * cs, (r + 1) * cs), all taps of each.
 template <int BN, int WAVES_M, int WAVES_N, int NSPLIT, bool PARALLEL, int NT>
-__global__ __launch_bounds__(256) void conv_dma_ksplit_kernel(ConvParams p) {
-  constexpr int BM = 128, NW = 4;
-  static_assert(WAVES_M * WAVES_N == NW, "four waves");
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_ksplit_kernel(ConvParams p) {
+  // NW = 8 (round 5; the 128 x 128 tile): two waves per SIMD, each with half the
+  // accumulator blocks, half the DMA pieces and half the fragment reads of a step -- with one wave per SIMD nothing runs under
+  // a wave's DMA issue and fragment waits, and a step took ~1,800 clocks for 768 of MFMAs.  Same K order, same product
+  // order per accumulator: bit-identical to the four-wave form.
+  constexpr int BM = 128, NW = WAVES_M * WAVES_N;
+  static_assert(NW == 4 || (NW == 8 && BN == 128), "four waves; eight for the 128-wide tile");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int NSTAGE = 4;
@@ -285,16 +289,16 @@ __global__ __launch_bounds__(256) void conv_dma_ksplit_kernel(ConvParams p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = first ? acc[i][j] : tot[i][j] + acc[i][j];
     }
   } else if (S > 1) {
-    // park the raw accumulators: slab [tile][range][v][tid] of float4 (every store instruction one contiguous 4 KB)
+    // park the raw accumulators: slab [tile][range][v][tid] of float4 (every store instruction one contiguous 4 / 8 KB)
     constexpr int V = TM * TN * 4;
-    ks_f4* slab = reinterpret_cast<ks_f4*>(p.ks_partial) + ((size_t)tile * S + range) * V * 256;
+    ks_f4* slab = reinterpret_cast<ks_f4*>(p.ks_partial) + ((size_t)tile * S + range) * V * (64 * NW);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          slab[((i * TN + j) * 4 + q) * 256 + tid] =
+          slab[((i * TN + j) * 4 + q) * (64 * NW) + tid] =
               ks_f4{acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
     return;                                                // the fold + epilogue: conv_ksplit_fold_kernel, next launch
   }
@@ -317,9 +321,10 @@ __global__ __launch_bounds__(64) void conv_ksplit_fold_kernel(ConvParams p) {
   constexpr int V = TM * TN * 4;
   constexpr int LDS_BYTES = 32 * (WN + 4) * 4;
   __shared__ __attribute__((aligned(16))) u16 smem16[LDS_BYTES / 2];
+  constexpr int NW = WAVES_M * WAVES_N;                    // waves of the GEMM workgroup (4 or 8)
   const int lane = threadIdx.x;
-  const int wave = blockIdx.x & 3;                         // the wave of the GEMM kernel whose sub-tile this is
-  const int wg = blockIdx.x >> 2;
+  const int wave = blockIdx.x % NW;                        // the wave of the GEMM kernel whose sub-tile this is
+  const int wg = blockIdx.x / NW;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int nby = p.Cout_pad / BN;
   const int slot = wg >> 3;
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(64) void conv_ksplit_fold_kernel(ConvParams p) {
   const int tid = wave * 64 + lane;                        // thread index inside the GEMM workgroup
   // slab loads as raw buffer loads: the thread's offset in ONE register, the (range, element-group) offset in an SGPR --
   // with flat 64-bit addresses the compiler kept all 16 x S of them live and spilled
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.ks_partial + (size_t)tile * S * V * 1024, 0, S * V * 4096, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.ks_partial + (size_t)tile * S * V * (NW * 256), 0, S * V * (NW * 1024), 0x00020000);
   const int vo = tid * 16;
   // two ranges per pass of a real loop (2 x V loads in flight, then their additions in range order): unrolled over all S
   // ranges the compiler put every load up front and spilled; one range per pass is a chain of S memory round trips
@@ -341,8 +346,8 @@ __global__ __launch_bounds__(64) void conv_ksplit_fold_kernel(ConvParams p) {
     const bool two = r0 + 1 < S;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-      u0[v] = __builtin_bit_cast(ks_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (r0 * V + v) * 4096, 0));
-      u1[v] = __builtin_bit_cast(ks_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (two ? (r0 + 1) * V + v : r0 * V + v) * 4096, 0));
+      u0[v] = __builtin_bit_cast(ks_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (r0 * V + v) * (NW * 1024), 0));
+      u1[v] = __builtin_bit_cast(ks_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (two ? (r0 + 1) * V + v : r0 * V + v) * (NW * 1024), 0));
     }
 #pragma unroll
     for (int v = 0; v < V; ++v) {
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(64) void conv_ksplit_fold_kernel(ConvParams p) {
 
 template <int BN, int WAVES_M, int WAVES_N>
 static int launch_fold(const ConvParams& p, int64_t tiles, hipStream_t s) {
-  const dim3 g((unsigned)(tiles * 4));
+  const dim3 g((unsigned)(tiles * WAVES_M * WAVES_N));
   switch (p.ksplit) {
     case 2: hipLaunchKernelGGL((conv_ksplit_fold_kernel<BN, WAVES_M, WAVES_N, 2>), g, dim3(64), 0, s, p); break;
     case 3: hipLaunchKernelGGL((conv_ksplit_fold_kernel<BN, WAVES_M, WAVES_N, 3>), g, dim3(64), 0, s, p); break;
@@ -382,13 +387,17 @@ static int launch_fold(const ConvParams& p, int64_t tiles, hipStream_t s) {
 
 template <int BN, int WAVES_M, int WAVES_N, int NSPLIT, bool PARALLEL, int NT>
 static int launch_ks(const ConvParams& p, hipStream_t s) {
+  if constexpr (BN == 128 && WAVES_M * WAVES_N == 4 && NSPLIT == 3) {
+    static const bool w8 = !(getenv("XDET_KSPLIT_W8") && !strcmp(getenv("XDET_KSPLIT_W8"), "0"));    // A/B runs
+    if (w8) return launch_ks<BN, 2, 4, NSPLIT, PARALLEL, NT>(p, s);
+  }
   constexpr size_t lds = (size_t)4 * (2 * 128 + 2 * BN) * 32 * sizeof(u16);
   auto kern = conv_dma_ksplit_kernel<BN, WAVES_M, WAVES_N, NSPLIT, PARALLEL, NT>;
   static DeviceOnce once;
   XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
   const int64_t tiles = cdiv(cdiv(p.M, 128), 8) * 8 * (p.Cout_pad / BN);
   dim3 grid((unsigned)(tiles * (PARALLEL ? p.ksplit : 1)));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, p);
   XDET_LAUNCH_CHECK();
   if (PARALLEL) return launch_fold<BN, WAVES_M, WAVES_N>(p, tiles, s);
   return XDET_OK;
