@@ -489,16 +489,21 @@ __device__ __forceinline__ f16x8 cd_ds_read_b128(unsigned addr) {
   return r;
 }
 
-template <int NSPLIT, bool PW = false>
-__global__ __launch_bounds__(256) void conv_dma_deep_kernel(ConvParams p_in) {
-  constexpr int BM = 128, BN = 64, NW = 4;
+// W8 (round 5): eight waves as 4 x 2 wave tiles of 32 x 32 -- two waves per SIMD, each with one accumulator block, three DMA pieces
+// (16 rows of A hi and lo, one 16-row group of one weight plane) and half the fragment reads of a step: with one wave per SIMD
+// nothing runs under a wave's DMA issue and fragment waits (the split-K ring kernel gained 4 % on the ResNet trunk from the same
+// change).  Same K order and product order per accumulator: bit-identical.
+template <int NSPLIT, bool PW = false, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256) void conv_dma_deep_kernel(ConvParams p_in) {
+  constexpr int BM = 128, BN = 64, NW = W8 ? 8 : 4;
+  static_assert(!W8 || NSPLIT == 3, "eight waves: the f16x3 form");
   constexpr int PAIR = 2;                          // K steps per barrier
   constexpr int NSTAGE = 3 * PAIR;                 // ring: the pair being read + two pairs in flight
-  constexpr int TN = 2;                            // wave tile 32 x 64
-  constexpr int A_IT = BM / (16 * NW), B_IT = BN / (16 * NW);
+  constexpr int TN = W8 ? 1 : 2;                   // wave tile 32 x 64 (eight waves: 32 x 32)
+  constexpr int A_IT = BM / (16 * NW), B_IT = W8 ? 1 : BN / (16 * NW);   // (eight waves: ONE weight piece per wave, hi or lo)
   constexpr int ROWB = 32;
   constexpr int STAGE = (2 * BM + 2 * BN) * ROWB;  // halves per stage (24 KB)
-  constexpr int PIECES = (A_IT + B_IT) * (NSPLIT > 1 ? 2 : 1);
+  constexpr int PIECES = W8 ? 3 : (A_IT + B_IT) * (NSPLIT > 1 ? 2 : 1);
   extern __shared__ __attribute__((aligned(16))) u16 smem16[];
 
   const int tid = threadIdx.x;
@@ -552,7 +557,7 @@ __global__ __launch_bounds__(256) void conv_dma_deep_kernel(ConvParams p_in) {
   size_t boff[B_IT];
 #pragma unroll
   for (int q = 0; q < B_IT; ++q) {
-    const int rt = (wave * B_IT + q) * 16 + lr;
+    const int rt = (W8 ? (wave >> 1) : wave * B_IT + q) * 16 + lr;
     boff[q] = (size_t)(n0 + rt) * 32 + (pos ^ ((rt >> 2) & 3)) * 8;
   }
   const int nk = p.Kp / 32;
@@ -594,11 +599,16 @@ __global__ __launch_bounds__(256) void conv_dma_deep_kernel(ConvParams p_in) {
         if (NSPLIT > 1)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(r_al, (__attribute__((address_space(3))) void*)(Al + (wave * A_IT + q) * 16 * ROWB), 16, (int)a_vo[q], (int)a_so, 0, 0);
       }
+      if constexpr (W8) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds((wave & 1) ? r_bl : r_bh, (__attribute__((address_space(3))) void*)(((wave & 1) ? Bl : Bh) + (wave >> 1) * 16 * ROWB), 16,
+                                                 (int)b_vo[0], (int)b_so, 0, 0);
+      } else {
 #pragma unroll
       for (int q = 0; q < B_IT; ++q) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r_bh, (__attribute__((address_space(3))) void*)(Bh + (wave * B_IT + q) * 16 * ROWB), 16, (int)b_vo[q], (int)b_so, 0, 0);
         if (NSPLIT > 1)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(r_bl, (__attribute__((address_space(3))) void*)(Bl + (wave * B_IT + q) * 16 * ROWB), 16, (int)b_vo[q], (int)b_so, 0, 0);
+      }
       }
     } else {
     const int cc = kt / ntaps;
@@ -615,10 +625,14 @@ __global__ __launch_bounds__(256) void conv_dma_deep_kernel(ConvParams p_in) {
       XDET_GLDS16(ok ? p.in_hi + off : p.zeros, Ah + (wave * A_IT + q) * 16 * ROWB);
       if (NSPLIT > 1) XDET_GLDS16(ok ? p.in_lo + off : p.zeros, Al + (wave * A_IT + q) * 16 * ROWB);
     }
+    if constexpr (W8) {
+      XDET_GLDS16(live ? ((wave & 1) ? p.wt_lo : p.wt_hi) + boff[0] + k0 : p.zeros, ((wave & 1) ? Bl : Bh) + (wave >> 1) * 16 * ROWB);
+    } else {
 #pragma unroll
     for (int q = 0; q < B_IT; ++q) {
       XDET_GLDS16(live ? p.wt_hi + boff[q] + k0 : p.zeros, Bh + (wave * B_IT + q) * 16 * ROWB);
       if (NSPLIT > 1) XDET_GLDS16(live ? p.wt_lo + boff[q] + k0 : p.zeros, Bl + (wave * B_IT + q) * 16 * ROWB);
+    }
     }
     }
   };
@@ -636,11 +650,11 @@ __global__ __launch_bounds__(256) void conv_dma_deep_kernel(ConvParams p_in) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     const int c = ks * 2 + fh;
-    const int ra = wave * 32 + frow;
+    const int ra = (W8 ? (wave >> 1) : wave) * 32 + frow;
     a_off[ks] = (unsigned)(ra * ROWB + ((c ^ ((ra >> 2) & 3)) << 3)) * 2u;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int rb = j * 32 + frow;
+      const int rb = (W8 ? (wave & 1) : j) * 32 + frow;
       b_off[ks][j] = (unsigned)(2 * BM * ROWB + rb * ROWB + ((c ^ ((rb >> 2) & 3)) << 3)) * 2u;
     }
   }
@@ -672,13 +686,16 @@ __global__ __launch_bounds__(256) void conv_dma_deep_kernel(ConvParams p_in) {
           if (NSPLIT > 1) bl[ks][j] = cd_ds_read_b128<BN * ROWB * 2>(sb + b_off[ks][j]);
         }
       }
-      if (NSPLIT > 1)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(ah[0]), "+v"(ah[1]), "+v"(al[0]), "+v"(al[1]), "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]),
-                       "+v"(bh[1][1]), "+v"(bl[0][0]), "+v"(bl[0][1]), "+v"(bl[1][0]), "+v"(bl[1][1])::"memory");
-      else
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(ah[0]), "+v"(ah[1]), "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]), "+v"(bh[1][1])::"memory");
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (NSPLIT > 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[ks]), "+v"(al[ks])::"memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[ks])::"memory");
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          asm volatile("" : "+v"(bh[ks][j]));
+          if (NSPLIT > 1) asm volatile("" : "+v"(bl[ks][j]));
+        }
+      }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         if (NSPLIT > 1) {
@@ -694,8 +711,8 @@ __global__ __launch_bounds__(256) void conv_dma_deep_kernel(ConvParams p_in) {
     ring = ring + PAIR >= NSTAGE ? ring + PAIR - NSTAGE : ring + PAIR;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy tail steps write LDS too
-  if (m0 + 128 <= p.M) conv_epilogue_full<32, 64, 1, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wave, 0, m0, n0);
-  else conv_epilogue<32, 64, 1, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wave, 0, m0, n0);
+  if (m0 + 128 <= p.M) conv_epilogue_full<32, 32 * TN, 1, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, W8 ? (wave >> 1) : wave, W8 ? (wave & 1) : 0, m0, n0);
+  else conv_epilogue<32, 32 * TN, 1, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, W8 ? (wave >> 1) : wave, W8 ? (wave & 1) : 0, m0, n0);
 }
 
 // pointwise layers whose planes and weights stay below 4 GiB (32-bit buffer offsets) take the buffer-load form
@@ -707,11 +724,15 @@ static bool pw_eligible(const ConvParams& p) {
   return a_bytes < ((size_t)1 << 32) && b_bytes < ((size_t)1 << 32) && p.Cin_p == p.Kp;
 }
 
-template <int NSPLIT, bool PW = false>
+template <int NSPLIT, bool PW = false, bool W8 = false>
 static int launch_deep(const ConvParams& p, hipStream_t s) {
-  if (!PW && pw_eligible(p)) return launch_deep<NSPLIT, true>(p, s);
+  if (!PW && pw_eligible(p)) return launch_deep<NSPLIT, true, W8>(p, s);
+  if constexpr (!W8 && NSPLIT == 3) {
+    static const bool w8 = !(getenv("XDET_CONV_DEEP_W8") && !strcmp(getenv("XDET_CONV_DEEP_W8"), "0"));   // A/B runs
+    if (w8) return launch_deep<NSPLIT, PW, true>(p, s);
+  }
   constexpr size_t lds = (size_t)6 * (2 * 128 + 2 * 64) * 32 * sizeof(u16);
-  auto kern = conv_dma_deep_kernel<NSPLIT, PW>;
+  auto kern = conv_dma_deep_kernel<NSPLIT, PW, W8>;
   static DeviceOnce once;
   XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
   dim3 grid((unsigned)(cdiv(cdiv(p.M, 128), 8) * 8 * (p.Cout_pad / 64)));
@@ -719,7 +740,7 @@ static int launch_deep(const ConvParams& p, hipStream_t s) {
     const int64_t groups = p.M / p.group_rows, tpg = (int64_t)(p.group_rows / 128) * (p.Cout_pad / 64);
     grid = dim3((unsigned)(cdiv(groups, 8) * 8 * tpg));
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL(kern, grid, dim3(W8 ? 512 : 256), lds, s, p);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }
