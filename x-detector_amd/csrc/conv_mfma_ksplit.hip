@@ -69,14 +69,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_ksplit_kernel
   // a wave's DMA issue and fragment waits, and a step took ~1,800 clocks for 768 of MFMAs.  Same K order, same product
   // order per accumulator: bit-identical to the four-wave form.
   constexpr int BM = 128, NW = WAVES_M * WAVES_N;
-  static_assert(NW == 4 || (NW == 8 && BN == 128), "four waves; eight for the 128-wide tile");
+  static_assert(NW == 4 || NW == 8, "four or eight waves");
+  constexpr bool HALFB = NW == 8 && BN == 64;               // eight waves on the 64-wide tile: ONE weight piece per wave (hi or lo)
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int NSTAGE = 4;
-  constexpr int A_IT = BM / (16 * NW), B_IT = BN / (16 * NW);
+  constexpr bool HALFB_ = WAVES_M * WAVES_N == 8 && BN == 64;
+  constexpr int A_IT = BM / (16 * NW), B_IT = HALFB_ ? 1 : BN / (16 * NW);
   constexpr int ROWB = 32;
   constexpr int STAGE = (2 * BM + 2 * BN) * ROWB;          // halves per stage
-  constexpr int PIECES = (A_IT + B_IT) * (NSPLIT > 1 ? 2 : 1);
+  constexpr int PIECES = HALFB_ ? 3 : (A_IT + B_IT) * (NSPLIT > 1 ? 2 : 1);
+  static_assert(!HALFB_ || NSPLIT == 3, "eight waves on the 64-wide tile: the f16x3 form");
   extern __shared__ __attribute__((aligned(16))) u16 smem16[];
 
   const int tid = threadIdx.x;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_ksplit_kernel
   }
 #pragma unroll
   for (int q = 0; q < B_IT; ++q) {
-    const int rt = (wave * B_IT + q) * 16 + lr;
+    const int rt = (HALFB ? (wave >> 1) : wave * B_IT + q) * 16 + lr;
     b_vo[q] = (unsigned)(((n0 + rt) * 32 + (pos ^ ((rt >> 2) & 3)) * 8) * 2);
   }
   const unsigned a_bytes = (unsigned)((((size_t)p.N * p.H * p.W + 15) >> 4) * c32n << 10);
@@ -158,6 +161,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_ksplit_kernel
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r_al, (__attribute__((address_space(3))) void*)(Al + (wave * A_IT + q) * 16 * ROWB), 16,
                                                  (int)a_vo[tap][q], (int)a_so, 0, 0);
     }
+    if constexpr (HALFB) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds((wave & 1) ? r_bl : r_bh, (__attribute__((address_space(3))) void*)(((wave & 1) ? Bl : Bh) + (wave >> 1) * 16 * ROWB), 16,
+                                               (int)b_vo[0], (int)b_so, 0, 0);
+    } else {
 #pragma unroll
     for (int q = 0; q < B_IT; ++q) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(r_bh, (__attribute__((address_space(3))) void*)(Bh + (wave * B_IT + q) * 16 * ROWB), 16,
@@ -165,6 +172,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_ksplit_kernel
       if (NSPLIT > 1)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r_bl, (__attribute__((address_space(3))) void*)(Bl + (wave * B_IT + q) * 16 * ROWB), 16,
                                                  (int)b_vo[q], (int)b_so, 0, 0);
+    }
     }
   };
 
@@ -387,9 +395,10 @@ static int launch_fold(const ConvParams& p, int64_t tiles, hipStream_t s) {
 
 template <int BN, int WAVES_M, int WAVES_N, int NSPLIT, bool PARALLEL, int NT>
 static int launch_ks(const ConvParams& p, hipStream_t s) {
-  if constexpr (BN == 128 && WAVES_M * WAVES_N == 4 && NSPLIT == 3) {
-    static const bool w8 = !(getenv("XDET_KSPLIT_W8") && !strcmp(getenv("XDET_KSPLIT_W8"), "0"));    // A/B runs
-    if (w8) return launch_ks<BN, 2, 4, NSPLIT, PARALLEL, NT>(p, s);
+  if constexpr (WAVES_M * WAVES_N == 4 && NSPLIT == 3) {
+    static const char* e = getenv("XDET_KSPLIT_W8");       // A/B runs: 0 = four waves everywhere, 128 = eight for the 128-wide tile only
+    const bool w8 = !(e && !strcmp(e, "0")) && (BN == 128 || !(e && !strcmp(e, "128")));
+    if (w8) return launch_ks<BN, BN == 128 ? 2 : 4, BN == 128 ? 4 : 2, NSPLIT, PARALLEL, NT>(p, s);
   }
   constexpr size_t lds = (size_t)4 * (2 * 128 + 2 * BN) * 32 * sizeof(u16);
   auto kern = conv_dma_ksplit_kernel<BN, WAVES_M, WAVES_N, NSPLIT, PARALLEL, NT>;
