@@ -49,6 +49,46 @@ def test_fused_blocks_are_bit_identical_to_three_launches(size, batch, n):
     assert np.array_equal(to_host(fused._out.ptr, (n,) + fused.out_shape, np.float32), a)
 
 
+@pytest.mark.parametrize('size,batch,n', [(480, 2, 2), (160, 3, 3), (96, 4, 3), (224, 1, 1)])
+def test_projection_folded_into_the_closing_conv(size, batch, n):
+    """XDET_RESNET_PROJCAT: a projection block's output as ONE contraction [3x3 output | block input] x [w_c ; w_proj]
+    (net/resnet_v2.py:160-184) against projection GEMM + closing GEMM + residual add.  One f32 accumulation instead of two
+    roundings and an add: not the same bits, the same numbers to f32 rounding of a 4-block-deep difference (the oracle bar
+    of tests/test_gpu_resnet.py is 1e-4 of the output's scale)."""
+    from xdet import weights as W
+    from xdet.resnet import ResNet50Trunk
+    from xdet.runtime import set_precision, to_host
+    w = W.make_resnet50_weights(4321)
+    imgs = W.synthetic_images(n, size, seed=11 + size)
+    outs = {}
+    for flag in ('1', '0'):
+        old = os.environ.get('XDET_RESNET_PROJCAT')
+        os.environ['XDET_RESNET_PROJCAT'] = flag
+        set_precision('f16x3')
+        try:
+            t = ResNet50Trunk(w, image_size=size, max_batch=batch)
+        finally:
+            set_precision('f32')
+            if old is None:
+                del os.environ['XDET_RESNET_PROJCAT']
+            else:
+                os.environ['XDET_RESNET_PROJCAT'] = old
+        outs[flag] = t.forward(imgs)
+        if flag == '1':
+            t.set_images(imgs)
+            t.forward_device(n, use_graph=True)
+            t.stream.synchronize()
+            assert np.array_equal(to_host(t._out.ptr, (n,) + t.out_shape, np.float32), outs['1'])
+            # batch invariance of the folded form: one image alone gives the bits it has inside the batch
+            one = t.forward(imgs[:1])
+            assert np.array_equal(one[0], outs['1'][0])
+    a, b = outs['1'], outs['0']
+    assert np.isfinite(a).all()
+    scale = float(np.abs(b).max())
+    assert float(np.abs(a - b).max()) <= 2e-5 * scale, (float(np.abs(a - b).max()), scale)
+    assert not np.array_equal(a, b)      # (the two forms do differ in the last bits: the switch is live)
+
+
 def _planes_to_f32(hi_buf, lo_buf, n_pix, ld):
     """[pix/16][ld/32][16][32] f16 hi / lo planes -> f32 [n_pix][ld] of hi + lo"""
     from xdet.runtime import to_host

@@ -77,7 +77,8 @@ int launch_maxpool3x3s2_add(const float* in, const float* res, float* out, int N
 // pool -> bn + ReLU -> split planes only (the ResNet stem tail in front of the first block's pre-activation)
 int launch_maxpool3x3s2_bn_planes(const float* in, const float* scale, const float* shift, unsigned short* hi, unsigned short* lo,
                                   int N, int H, int W, int C, int ld, int Ho, int Wo, int pad_t, int pad_l, float mul,
-                                  hipStream_t s);
+                                  hipStream_t s, unsigned short* hi2 = nullptr, unsigned short* lo2 = nullptr, int c32_2 = 0,
+                                  float mul2 = 1.f);
 // vertical half only, over rows the producer already pooled horizontally (sepconv_fused.hip HPOOL)
 int launch_maxpool_v3s2_add(const float* in_hpooled, const float* res, float* out, int N, int H, int Wo, int C, int ld,
                             int Ho, int pad_t, hipStream_t s, unsigned short* sub_hi = nullptr, unsigned short* sub_lo = nullptr,
@@ -96,8 +97,11 @@ int launch_stem_conv3x3s2(const float* in_nchw, const float* w27x32, const float
 // mul: the planes' activation pre-scale 2^-e (a power of two; 1 = none): hi + lo = x * mul
 int launch_split_f32(const float* in, unsigned short* hi, unsigned short* lo, int64_t n_pix, int ld, int relu,
                      hipStream_t s, float mul = 1.f, int x8 = 0, int x8_exp = 0);
+int launch_planes_copy_blocks(const unsigned short* shi, const unsigned short* slo, unsigned short* dhi, unsigned short* dlo,
+                              int64_t n_pix, int ld_src, int c32_dst, float r, hipStream_t s);
 int launch_split_f32_subsample2(const float* in, unsigned short* hi, unsigned short* lo, int N, int H, int W, int ld,
-                                hipStream_t s, const float* scale = nullptr, const float* shift = nullptr, float mul = 1.f);
+                                hipStream_t s, const float* scale = nullptr, const float* shift = nullptr, float mul = 1.f,
+                                int c32_dst = 0);
 // range calibration: largest |hi| of a plane (f16 bits) / largest |x| or max(x, 0) of an f32 tensor (f32 bits), atomicMax'ed into *out
 int launch_absmax_planes(const unsigned short* hi, int64_t n_halves, unsigned* out, hipStream_t s);
 int launch_absmax_f32(const float* x, int64_t n, int relu, unsigned* out, hipStream_t s);

@@ -99,7 +99,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, ep_f32x16 (&a
           ep_f16x4 hv = {h0, h1, h2, h3};
           ep_f16x4 lv = {(_Float16)(t.x - (float)h0), (_Float16)(t.y - (float)h1), (_Float16)(t.z - (float)h2),
                       (_Float16)(t.w - (float)h3)};
-          const size_t o = ((((size_t)m >> 4) * (size_t)(p.ldo >> 5) + (size_t)(co4 >> 5)) << 9) + ((m & 15) << 5) + (co4 & 31);
+          const size_t o = ((((size_t)m >> 4) * (size_t)(p.pl_c32 ? p.pl_c32 : p.ldo >> 5) + (size_t)(co4 >> 5)) << 9) + ((m & 15) << 5) + (co4 & 31);
           *reinterpret_cast<uint2*>(p.out_hi + o) = *reinterpret_cast<uint2*>(&hv);
           *reinterpret_cast<uint2*>(p.out_lo + o) = *reinterpret_cast<uint2*>(&lv);
         }
@@ -157,7 +157,7 @@ __device__ __forceinline__ void conv_epilogue_full(const ConvParams& p, ep_f32x1
       const_cast<float*>(p.out ? p.out + (size_t)row0 * p.ldo : nullptr), 0, p.out ? WM * p.ldo * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.res ? p.res + (size_t)row0 * p.ldr : nullptr), 0, p.res ? WM * p.ldr * 4 : 0, 0x00020000);
-  const int c32 = p.ldo >> 5;
+  const int c32 = p.pl_c32 ? p.pl_c32 : p.ldo >> 5;
   const int pl_bytes = p.out_hi ? (WM / 16) * c32 * 1024 : 0;
   const __amdgpu_buffer_rsrc_t r_hi = __builtin_amdgcn_make_buffer_rsrc(
       p.out_hi ? p.out_hi + (((size_t)(row0 >> 4) * c32) << 9) : nullptr, 0, pl_bytes, 0x00020000);

@@ -20,6 +20,10 @@ struct ConvParams {
   unsigned short* out_hi;
   unsigned short* out_lo;
   int planes_relu;
+  // channel blocks per 16-pixel group of the planes destination when that is WIDER than this conv's output: the conv fills
+  // blocks [0, ldo/32) of a concatenated operand [pix/16][pl_c32][16][32] whose other blocks another producer writes (ResNet:
+  // the closing 1x1 of a projection block reads [3x3 output | block input] against [w_c ; w_proj]); 0 = ldo / 32
+  int pl_c32 = 0;
   // optional per-channel affine applied to the planes copy before its ReLU (a following inference BN:
   // planes = relu(out * pl_scale + pl_shift)); NULL = none
   const float* pl_scale;

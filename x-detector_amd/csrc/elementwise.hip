@@ -481,7 +481,9 @@ __global__ __launch_bounds__(256) void split_f32_subsample2_kernel(const float* 
                                                                    unsigned short* __restrict__ hi,
                                                                    unsigned short* __restrict__ lo, int N, int H, int W,
                                                                    int Ho, int Wo, int ld, const float* __restrict__ scale,
-                                                                   const float* __restrict__ shift, float mul) {
+                                                                   const float* __restrict__ shift, float mul, int c32_dst) {
+  // c32_dst: channel blocks per 16-pixel group of the DESTINATION (= ld / 32, or more when hi / lo point at this tensor's first
+  // block inside a wider concatenated operand)
   const int c32n = ld >> 5;
   const int64_t n_pix = (int64_t)N * Ho * Wo;
   const int64_t n8 = ((n_pix + 15) >> 4) * c32n * 64;
@@ -510,21 +512,24 @@ __global__ __launch_bounds__(256) void split_f32_subsample2_kernel(const float* 
     b.x *= mul; b.y *= mul; b.z *= mul; b.w *= mul;
     f16x8e h, l;
     split8(a, b, &h, &l);
-    *reinterpret_cast<f16x8e*>(hi + i * 8) = h;
-    *reinterpret_cast<f16x8e*>(lo + i * 8) = l;
+    const int64_t o = ((grp * c32_dst + cc) << 6) + (i & 63);
+    *reinterpret_cast<f16x8e*>(hi + o * 8) = h;
+    *reinterpret_cast<f16x8e*>(lo + o * 8) = l;
   }
 }
 
 int launch_split_f32_subsample2(const float* in, unsigned short* hi, unsigned short* lo, int N, int H, int W, int ld,
-                                hipStream_t s, const float* scale, const float* shift, float mul) {
+                                hipStream_t s, const float* scale, const float* shift, float mul, int c32_dst) {
   XDET_REQUIRE(ld > 0 && ld % 32 == 0, "split: channel stride must be a multiple of 32");
+  if (c32_dst == 0) c32_dst = ld >> 5;
+  XDET_REQUIRE(c32_dst >= (ld >> 5), "split: the destination has fewer channel blocks than the source");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int64_t n_pix = (int64_t)N * Ho * Wo;
   if (n_pix == 0) return XDET_OK;
   const int64_t n = cdiv(n_pix, 16) * 16 * ld;
   const int blocks = (int)std::min<int64_t>(cdiv(n / 8, 256), 256 * 32);
   hipLaunchKernelGGL(split_f32_subsample2_kernel, dim3(blocks), dim3(256), 0, s, in, hi, lo, N, H, W, Ho, Wo, ld, scale,
-                     shift, mul);
+                     shift, mul, c32_dst);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }
@@ -605,6 +610,40 @@ int launch_maxpool3x3s2_add(const float* in, const float* res, float* out, int N
   return XDET_OK;
 }
 
+// Channel blocks of one planes tensor [pix/16][c32_src][16][32] into a wider one [pix/16][c32_dst][16][32] (the pointers address
+// the first destination block inside a 16-pixel group), scaled by the power of two r = ratio of the two tensors' activation
+// pre-scales (exact for both halves short of f16 overflow / underflow; 1 unless a calibration moved one of them).
+__global__ __launch_bounds__(256) void planes_copy_blocks_kernel(const unsigned short* __restrict__ shi, const unsigned short* __restrict__ slo,
+                                                                 unsigned short* __restrict__ dhi, unsigned short* __restrict__ dlo,
+                                                                 int64_t groups, int c32_src, int c32_dst, float r) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  const int64_t n = groups * c32_src * 64;             // 16-byte pieces per plane
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t blk = i >> 6;
+    const int64_t grp = blk / c32_src;
+    const int cc = (int)(blk - grp * c32_src);
+    const int64_t o = ((grp * c32_dst + cc) << 6) + (i & 63);
+    h8 h = *reinterpret_cast<const h8*>(shi + i * 8), l = *reinterpret_cast<const h8*>(slo + i * 8);
+    if (r != 1.f) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { h[k] = (_Float16)((float)h[k] * r); l[k] = (_Float16)((float)l[k] * r); }
+    }
+    *reinterpret_cast<h8*>(dhi + o * 8) = h;
+    *reinterpret_cast<h8*>(dlo + o * 8) = l;
+  }
+}
+
+int launch_planes_copy_blocks(const unsigned short* shi, const unsigned short* slo, unsigned short* dhi, unsigned short* dlo,
+                              int64_t n_pix, int ld_src, int c32_dst, float r, hipStream_t s) {
+  XDET_REQUIRE(shi && slo && dhi && dlo && ld_src > 0 && ld_src % 32 == 0 && c32_dst >= ld_src / 32, "planes copy: bad arguments");
+  if (n_pix == 0) return XDET_OK;
+  const int64_t groups = cdiv(n_pix, 16), n = groups * (ld_src >> 5) * 64;
+  const int blocks = (int)std::min<int64_t>(cdiv(n, 256), 256 * 32);
+  hipLaunchKernelGGL(planes_copy_blocks_kernel, dim3(blocks), dim3(256), 0, s, shi, slo, dhi, dlo, groups, ld_src >> 5, c32_dst, r);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
 // ResNet v2 stem tail (net/resnet_v2.py:311-330 initial_max_pool, then the first block's batch_norm_relu :142-156): the pooled
 // tensor has ONE reader, the first block's pre-activation, and that one is read as split planes only (its shortcut is a
 // projection of the pre-activation).  Same window walk as maxpool3x3s2_add_kernel; the result goes through bn + ReLU and
@@ -614,7 +653,11 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bn_planes_kernel(const float
                                                                      const float* __restrict__ shift,
                                                                      unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
                                                                      int H, int W, int ld, int Ho, int Wo, int pad_t, int pad_l,
-                                                                     int nbands, int bands_per_image, float mul) {
+                                                                     int nbands, int bands_per_image, float mul,
+                                                                     unsigned short* __restrict__ hi2, unsigned short* __restrict__ lo2,
+                                                                     int c32_2, float mul2) {
+  // hi2 / lo2 (optional): a second copy, scaled by mul2, into channel blocks of a wider concatenated operand
+  // [pix/16][c32_2][16][32] (the pointers address this tensor's first block in it)
   const int c4n = ld >> 2;
   const int item = blockIdx.y * 256 + threadIdx.x;
   if (item >= Wo * c4n) return;
@@ -648,6 +691,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bn_planes_kernel(const float
     const float4 m = mp_max4(mp_max4(carry, a), b);
     carry = b;
     float v[4] = {fmaf(m.x, sc.x, sh.x), fmaf(m.y, sc.y, sh.y), fmaf(m.z, sc.z, sh.z), fmaf(m.w, sc.w, sh.w)};
+    const float m4[4] = {v[0], v[1], v[2], v[3]};
     _Float16 h[4], l[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -660,18 +704,32 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bn_planes_kernel(const float
     const size_t po = ((size_t)((pix >> 4) * (ld >> 5) + (c >> 5)) << 9) + ((size_t)(pix & 15) << 5) + (size_t)(c & 31);
     *reinterpret_cast<uint2*>(hi + po) = *reinterpret_cast<const uint2*>(h);
     *reinterpret_cast<uint2*>(lo + po) = *reinterpret_cast<const uint2*>(l);
+    if (hi2) {
+      if (mul2 != mul) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float u = (!(m4[k] <= 0.f) ? m4[k] : 0.f) * mul2;
+          h[k] = (_Float16)u;
+          l[k] = (_Float16)(u - (float)h[k]);
+        }
+      }
+      const size_t p2 = ((size_t)((pix >> 4) * c32_2 + (c >> 5)) << 9) + ((size_t)(pix & 15) << 5) + (size_t)(c & 31);
+      *reinterpret_cast<uint2*>(hi2 + p2) = *reinterpret_cast<const uint2*>(h);
+      *reinterpret_cast<uint2*>(lo2 + p2) = *reinterpret_cast<const uint2*>(l);
+    }
   }
 }
 
 int launch_maxpool3x3s2_bn_planes(const float* in, const float* scale, const float* shift, unsigned short* hi, unsigned short* lo,
                                   int N, int H, int W, int C, int ld, int Ho, int Wo, int pad_t, int pad_l, float mul,
-                                  hipStream_t s) {
+                                  hipStream_t s, unsigned short* hi2, unsigned short* lo2, int c32_2, float mul2) {
   XDET_REQUIRE(ld % 32 == 0 && ld >= C && in && scale && shift && hi && lo, "maxpool + bn planes: channel stride must be a multiple of 32");
+  XDET_REQUIRE(!hi2 || (lo2 && c32_2 >= ld / 32), "maxpool + bn planes: bad second destination");
   if ((int64_t)N * Ho == 0) return XDET_OK;
   const int bpi = (int)cdiv(Ho, MP_ROWS), nbands = N * bpi;
   const dim3 grid((unsigned)(cdiv(nbands, 8) * 8), (unsigned)cdiv((int64_t)Wo * (ld / 4), 256));
   hipLaunchKernelGGL(maxpool3x3s2_bn_planes_kernel, grid, dim3(256), 0, s, in, scale, shift, hi, lo, H, W, ld, Ho, Wo, pad_t, pad_l,
-                     nbands, bpi, mul);
+                     nbands, bpi, mul, hi2, lo2, c32_2, mul2);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }

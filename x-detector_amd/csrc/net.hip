@@ -145,6 +145,7 @@ struct ConvLayer : LayerBase {
   // layer runs on that kernel at every batch size (its two modes are bit-identical), so results never depend on the batch.
   int ksplit = 0;                      // 0 = the layer is not on the split-K kernel
   int ks_mode = 0;                     // 0 = by grid size, 1 = parallel ranges, 2 = one workgroup per tile (tests)
+  int pl_c32 = 0;                      // planes destination wider than the output (conv_params.h pl_c32); 0: its own planes tensor
   bool ks_narrow = false;              // 128 x 64 tiles although the layer is a multiple of 128 wide (one range, twice the workgroups)
   int64_t ks_tiles = 0;                // tiles the scratch below was sized for
   float* d_ks_partial = nullptr;
@@ -364,7 +365,7 @@ struct ConvLayer : LayerBase {
     p.relu_in = relu_in; p.relu_out = relu_out;
     p.in_hi = in_hi; p.in_lo = in_lo; p.zeros = zeros;
     p.out_hi = precision == PREC_F32 ? nullptr : out_hi; p.out_lo = out_lo; p.planes_relu = planes_relu;
-    p.pl_scale = pl_scale; p.pl_shift = pl_shift;
+    p.pl_scale = pl_scale; p.pl_shift = pl_shift; p.pl_c32 = pl_c32;
     p.group_rows = 0; p.group_wt_stride = 0;
     if (groups > 1) {
       XDET_REQUIRE(in_hi && group_rows > 0 && group_rows % 128 == 0 && (int64_t)group_rows * groups == p.M,
@@ -772,6 +773,9 @@ struct Plan {
   // With emit_bn_scale/shift set (device arrays, ld floats) the planes copy is relu(out*scale+shift):
   // a following BN+ReLU pre-activation folded into this conv's epilogue.
   int emit_planes_next = 0;
+  // With emit_planes_next = 3: the planes go into channel blocks [0, ld_out/32) of THIS wider planes tensor (same pixels) instead
+  // of a tensor of their own -- the left part of a concatenated operand [this conv's output | what another op wrote]
+  const Buf* emit_planes_into = nullptr;
   std::vector<float> emit_bn_scale, emit_bn_shift;   // host, ld floats each (empty: no folded BN)
   // Set by a builder right before add_conv: the planes copy of this conv's output is only read by the three-launch form of
   // the next block -- a forward in which planes_dropped() says that block runs fused (resnet_bneck.hip makes its own
@@ -853,6 +857,8 @@ struct Plan {
     const bool folded_bn = emit && !emit_bn_scale.empty();
     if (folded_bn) XDET_TRY(L->set_planes_bn(emit_bn_scale, emit_bn_shift));
     emit_planes_next = 0;
+    const Buf* planes_into = emit_planes_into;
+    emit_planes_into = nullptr;
     emit_bn_scale.clear();
     emit_bn_shift.clear();
     // split path: big stride-1 contractions take their A operand as f16 planes through the LDS DMA;
@@ -883,11 +889,23 @@ struct Plan {
     XDET_TRY(new_buf(Ho, Wo, L->cout, out));
     XDET_REQUIRE(in.ld == L->ld_in() && out->ld == L->ld_out(), "plan: conv channel strides do not match");
     if (in.hi) XDET_TRY(maybe_ksplit(L, in.H, in.W, Ho, Wo)); else ksplit_next = false;
+    XDET_REQUIRE(!planes_into || emit == 3, "plan: a concatenated planes destination needs a planes-only output");
     if (emit) {
-      XDET_TRY(new_planes(out));
+      if (planes_into) {
+        XDET_REQUIRE(planes_into->hi && planes_into->pidx >= 0 && planes_into->H == Ho && planes_into->W == Wo &&
+                         planes_into->ld % 32 == 0 && planes_into->ld > out->ld && !folded_bn,
+                     "plan: the concatenated planes destination does not match this conv's output");
+        out->hi = planes_into->hi;
+        out->lo = planes_into->lo;
+        out->pidx = planes_into->pidx;
+        L->pl_c32 = planes_into->ld >> 5;
+        pscales[out->pidx].op_index = (int)ops.size();     // complete (and measured) behind this op, its last producer
+      } else {
+        XDET_TRY(new_planes(out));
+      }
       out->planes_relu = emit == 2;
       out->no_f32 = emit == 3;
-      pscales[out->pidx].name = name + " (planes of the output)";
+      if (!planes_into) pscales[out->pidx].name = name + " (planes of the output)";
       pscales[out->pidx].apply.push_back([L](int e) { return L->set_out_exp(e); });
     }
     if (in.hi && in.pidx >= 0) pscales[in.pidx].apply.push_back([L](int e) { return L->set_in_exp(e); });
@@ -1776,6 +1794,10 @@ struct ResNetTrunk : Plan {
   bool stem_pool_bn = true;                        // XDET_RESNET_STEM_POOL=0: pool and pre-activation as two passes (A/B runs, tests)
   bool bneck_enabled = true;                       // identity blocks the fused kernel supports run as one launch
   bool bneck_fused_now = false;                    // set by a block's first op for its other two (ops run in order on one stream)
+  bool projcat_enabled = true;                     // XDET_RESNET_PROJCAT=0: projection shortcuts as their own GEMM + a residual add (A/B runs, tests)
+  unsigned short *stem_cat_hi = nullptr, *stem_cat_lo = nullptr;   // second destination of the stem's pool + pre-activation pass
+  float stem_cat_mul = 1.f;
+  int stem_cat_c32 = 0, stem_cat_pidx = -1;        // (stage 1's projection block reads the block input inside a concatenated operand)
   bool preconv_enabled = true;                     // XDET_RESNET_PRECONV=0: stage 2's opening 1x1 convs read planes (A/B runs, tests)
   struct PreconvLayers { ConvLayer *Lprev, *La; };  // a conv1x1 that makes its pre-activation from the raw input (resnet_preconv.hip)
   std::vector<PreconvLayers> preconv_layers;
@@ -1921,7 +1943,7 @@ int ResNetTrunk::build() {
     const Buf i = x, o = stem_pre;
     ops.push_back({"initial_max_pool + " + bn0, 0, 0.0, [=](int N, hipStream_t s) {
                      return launch_maxpool3x3s2_bn_planes(i.p, dsc, dsh, o.hi, o.lo, N, i.H, i.W, i.C, i.ld, Ho, Wo, pt, pl,
-                                                          pmul(o.pidx), s);
+                                                          pmul(o.pidx), s, stem_cat_hi, stem_cat_lo, stem_cat_c32, pmul(stem_cat_pidx) * stem_cat_mul);
                    }});
     stem_pre_fused = true;
     // block 0 takes its shortcut from a projection of the pre-activation: the pooled tensor has no f32 reader.  `x` keeps the
@@ -1954,13 +1976,66 @@ int ResNetTrunk::build() {
         XDET_TRY(add_bn_relu(bname(), x, &pre));
       }
       have_fused = false;
-      if (b == 0) {
+      // A projection shortcut folded into the block's closing GEMM (net/resnet_v2.py:160-184: shortcut = projection(pre), output =
+      // conv3(...) + shortcut, neither followed by a BN): [y2 | pre'] x [w_c ; w_proj] is ONE contraction over cmid + cin
+      // channels -- no projection launch, no 4f-channel shortcut tensor written and read back (118 / 59 / 29 / 15 MB each way at
+      // batch 8).  The operand is one planes tensor: the 3x3 conv's epilogue writes its channel blocks [0, cmid/32), the pass that
+      // makes pre' (the stem's pool + pre-activation pass / the stride-2 subsample of relu(bn(x))) the blocks behind them.  One f32
+      // accumulation over both parts instead of two roundings and an add: not bit-identical to the two-GEMM form, same tolerance
+      // against the oracle (tests/test_gpu_resnet.py).
+      const bool cat_s1 = s == 1 && st == 0 && pre.hi && pre.pidx >= 0 && !pre.planes_relu;
+      const bool cat_s2 = s == 2 && pre.no_f32 && x.p && fused_sc && x.ld % 32 == 0;
+      const bool cat_on = projcat_enabled && b == 0 && g_default_precision == PREC_F16X3 && (cat_s1 || cat_s2) && f % 32 == 0 &&
+                          pre.ld % 32 == 0 && pre.ld == pre.C;
+      const std::string cproj = b == 0 ? cname() : std::string();
+      Buf cat;
+      int cat_d = 0;
+      if (cat_on) {
+        cat.H = (pre.H + s - 1) / s; cat.W = (pre.W + s - 1) / s; cat.C = f + pre.C; cat.ld = f + pre.ld; cat.no_f32 = true;
+        XDET_TRY(new_planes(&cat));
+        pscales[cat.pidx].name = cproj + " + closing conv: [3x3 output | block input] operand";
+        const size_t off = (size_t)(f >> 5) << 9;          // halves: the block input's first channel block inside a 16-pixel group
+        // The two parts share one weight pre-scale per output channel and one activation pre-scale: balance them.  The block-input
+        // part is stored as pre * 2^-cat_d and w_proj enters as w_proj * 2^cat_d (exact), cat_d = the binade distance of the two
+        // matrices' largest magnitudes -- a projection whose weights are 2^17 below the closing conv's (and whose input is 2^17
+        // above: test_trunk_pre_activations_beyond_the_f16_range) would otherwise lose its lo plane to f16 underflow.
+        {
+          const HostTensor *kc0, *kp0;
+          XDET_TRY(need("conv2d_" + std::to_string(ci + 2) + "/kernel", &kc0, {1, 1, f, 4 * f}));   // (c3: three names after cproj)
+          XDET_TRY(need(cproj + "/kernel", &kp0, {1, 1, pre.C, 4 * f}));
+          float mc = 0.f, mp = 0.f;
+          for (float v : kc0->v) mc = std::max(mc, std::fabs(v));
+          for (float v : kp0->v) mp = std::max(mp, std::fabs(v));
+          int ec = 0, ep = 0;
+          if (mc > 0.f && mp > 0.f && std::isfinite(mc) && std::isfinite(mp)) { (void)frexpf(mc, &ec); (void)frexpf(mp, &ep); }
+          cat_d = ec - ep;
+        }
+        const float part_mul = ldexpf(1.f, -cat_d);
+        if (cat_s1 && stem_pre_fused) {               // the stem's pool + pre-activation pass writes the block input twice
+          stem_cat_hi = cat.hi + off; stem_cat_lo = cat.lo + off; stem_cat_c32 = cat.ld >> 5; stem_cat_pidx = cat.pidx;
+          stem_cat_mul = part_mul;
+        } else if (cat_s1) {                          // (two-pass stem, XDET_RESNET_STEM_POOL=0: a copy of the pre-activation planes)
+          const Buf i = pre, o = cat;
+          ops.push_back({cproj + "/copy of the block input [into the closing conv's operand]", 0, 0.0, [=](int N, hipStream_t s_) {
+                           return launch_planes_copy_blocks(i.hi, i.lo, o.hi + off, o.lo + off, (int64_t)N * i.H * i.W, i.ld, o.ld >> 5,
+                                                            pmul(o.pidx) * part_mul / pmul(i.pidx), s_);
+                         }});
+        } else {
+          const Buf i = x, o = cat;
+          const float *psc = fused_sc, *psh = fused_sh;
+          ops.push_back({cproj + "/subsample_split [into the closing conv's operand]", 0, 0.0, [=](int N, hipStream_t s_) {
+                           return launch_split_f32_subsample2(i.p, o.hi + off, o.lo + off, N, i.H, i.W, i.ld, s_, psc, psh, pmul(o.pidx) * part_mul,
+                                                              o.ld >> 5);
+                         }});
+        }
+        shortcut = Buf();
+      } else if (b == 0) {
         if (pre.no_f32 && s > 1) {
           // the pre-activation exists as full-resolution planes only (conv1 reads those); the stride-2 projection
           // takes the raw block input and applies the BN + ReLU to the quarter of the pixels it reads
-          XDET_TRY(conv_bn(cname(), "", 0.f, 0, x, 1, 4 * f, s, 2, 0, nullptr, 0, &shortcut, 0, fused_sc, fused_sh));
+          XDET_TRY(conv_bn(cproj, "", 0.f, 0, x, 1, 4 * f, s, 2, 0, nullptr, 0, &shortcut, 0, fused_sc, fused_sh));
         } else {
-          XDET_TRY(conv_bn(cname(), "", 0.f, 0, pre, 1, 4 * f, s, s > 1 ? 2 : 1, 0, nullptr, 0, &shortcut, 0));
+          XDET_TRY(conv_bn(cproj, "", 0.f, 0, pre, 1, 4 * f, s, s > 1 ? 2 : 1, 0, nullptr, 0, &shortcut, 0));
         }
       }
       const std::string c1 = cname(), b1 = bname(), c2 = cname(), b2 = bname(), c3 = cname();
@@ -1993,7 +2068,9 @@ int ResNetTrunk::build() {
         ops[op_first].name += " [pre-activation on the CU]";
       }
       emit_planes_next = 3;                       // the closing 1x1 always does
+      if (cat_on) emit_planes_into = &cat;
       XDET_TRY(conv_bn(c2, b2, 1e-5f, 0, y1, 3, f, s, s > 1 ? 2 : 1, 1, nullptr, 0, &y2, 1));
+      XDET_REQUIRE(!cat_on || (y2.hi == cat.hi && y2.H == cat.H && y2.W == cat.W), "plan: the 3x3 conv did not take the concatenated operand");
       ConvLayer* Lb = static_cast<ConvLayer*>(layers.back().get());
       // The next block opens with BN+ReLU of this block's output.  Fold it in: the closing conv writes its f32
       // output (the identity shortcut) AND relu(bn_next(output)) as planes, and the separate element-wise pass
@@ -2019,7 +2096,18 @@ int ResNetTrunk::build() {
       // (the planes copy of this block's output has one reader, the next block's opening conv: if that block turns out to run on
       //  a kernel that makes its own pre-activation, it marks this conv's planes as droppable)
       planes_optional_next = g_default_precision == PREC_F16X3 && nsc != nullptr;
-      XDET_TRY(conv_bn(c3, "", 0.f, 0, y2, 1, 4 * f, 1, 1, 0, &shortcut, 0, &y3));
+      if (cat_on) {
+        const HostTensor *kc, *kp;
+        XDET_TRY(need(c3 + "/kernel", &kc, {1, 1, f, 4 * f}));
+        XDET_TRY(need(cproj + "/kernel", &kp, {1, 1, pre.C, 4 * f}));
+        std::vector<float> kcat(kc->v);                                   // HWIO, 1 x 1: rows = input channels
+        for (float v : kp->v) kcat.push_back(ldexpf(v, cat_d));             // (the block-input part is stored * 2^-cat_d)
+        ConvLayer* L = keep(new ConvLayer());
+        XDET_TRY(L->init(1, 1, f + pre.C, 4 * f, 1, 1, 1, 0, 0, kcat.data(), nullptr, nullptr, 0));
+        XDET_TRY(add_conv(c3 + " + " + cproj + " [shortcut projection folded into the reduction]", 0, cat, L, nullptr, 0, &y3));
+      } else {
+        XDET_TRY(conv_bn(c3, "", 0.f, 0, y2, 1, 4 * f, 1, 1, 0, &shortcut, 0, &y3));
+      }
       ConvLayer* Lc = static_cast<ConvLayer*>(layers.back().get());
       const int my_drop_idx = last_optional_idx;  // this block's closing conv, if its planes copy is optional
       // An identity block as ONE kernel (resnet_bneck.hip), reading the raw block input (it applies the pre-activation BN +
@@ -2694,6 +2782,7 @@ int xdet_resnet_create(void** net, int image_size, int max_batch) {
   if (const char* e = getenv("XDET_RESNET_STEM7")) r->stem7_enabled = strcmp(e, "0") != 0;
   if (const char* e = getenv("XDET_RESNET_STEM_POOL")) r->stem_pool_bn = strcmp(e, "0") != 0;
   if (const char* e = getenv("XDET_RESNET_BNECK")) r->bneck_enabled = strcmp(e, "0") != 0;
+  if (const char* e = getenv("XDET_RESNET_PROJCAT")) r->projcat_enabled = strcmp(e, "0") != 0;     // 0: projection shortcuts as their own GEMM (A/B runs, tests)
   if (const char* e = getenv("XDET_RESNET_PRECONV")) r->preconv_enabled = strcmp(e, "0") != 0;     // 0: three launches per block (A/B runs, tests)
   XDET_HIP(hipGetDevice(&r->device));
   *net = r;
