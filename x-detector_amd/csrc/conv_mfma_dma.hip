@@ -493,13 +493,19 @@ __device__ __forceinline__ f16x8 cd_ds_read_b128(unsigned addr) {
 // (16 rows of A hi and lo, one 16-row group of one weight plane) and half the fragment reads of a step: with one wave per SIMD
 // nothing runs under a wave's DMA issue and fragment waits (the split-K ring kernel gained 4 % on the ResNet trunk from the same
 // change).  Same K order and product order per accumulator: bit-identical.
-template <int NSPLIT, bool PW = false, bool W8 = false>
+// H64 (round 5): 64 x 64 tiles on four waves (2 x 2 wave tiles of 32 x 32) for grids that leave more than half of the CUs without a
+// 128 x 64 tile (a single image's middle flow: 900 rows x 768 columns = 96 tiles -> 180): a workgroup's K loop runs at the rate its CU
+// takes operand bytes in (~20 B/clk: 24.6 KB per 128 x 64 step), so spreading the same reduction over more CUs with less per step
+// (16 KB) shortens it.  Same K order and product order per accumulator: bit-identical.
+template <int NSPLIT, bool PW = false, bool W8 = false, bool H64 = false>
 __global__ __launch_bounds__(W8 ? 512 : 256) void conv_dma_deep_kernel(ConvParams p_in) {
-  constexpr int BM = 128, BN = 64, NW = W8 ? 8 : 4;
+  constexpr int BM = H64 ? 64 : 128, BN = 64, NW = W8 ? 8 : 4;
   static_assert(!W8 || NSPLIT == 3, "eight waves: the f16x3 form");
+  static_assert(!(W8 && H64), "64 x 64 tiles: four waves");
+  constexpr bool WT = W8 || H64;                   // wave tiles of 32 x 32 in two columns (else 32 x 64 in one)
   constexpr int PAIR = 2;                          // K steps per barrier
   constexpr int NSTAGE = 3 * PAIR;                 // ring: the pair being read + two pairs in flight
-  constexpr int TN = W8 ? 1 : 2;                   // wave tile 32 x 64 (eight waves: 32 x 32)
+  constexpr int TN = WT ? 1 : 2;                   // wave tile 32 x 64 (eight waves / 64 x 64 tiles: 32 x 32)
   constexpr int A_IT = BM / (16 * NW), B_IT = W8 ? 1 : BN / (16 * NW);   // (eight waves: ONE weight piece per wave, hi or lo)
   constexpr int ROWB = 32;
   constexpr int STAGE = (2 * BM + 2 * BN) * ROWB;  // halves per stage (24 KB)
@@ -650,11 +656,11 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void conv_dma_deep_kernel(ConvParam
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     const int c = ks * 2 + fh;
-    const int ra = (W8 ? (wave >> 1) : wave) * 32 + frow;
+    const int ra = (WT ? (wave >> 1) : wave) * 32 + frow;
     a_off[ks] = (unsigned)(ra * ROWB + ((c ^ ((ra >> 2) & 3)) << 3)) * 2u;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int rb = (W8 ? (wave & 1) : j) * 32 + frow;
+      const int rb = (WT ? (wave & 1) : j) * 32 + frow;
       b_off[ks][j] = (unsigned)(2 * BM * ROWB + rb * ROWB + ((c ^ ((rb >> 2) & 3)) << 3)) * 2u;
     }
   }
@@ -711,8 +717,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void conv_dma_deep_kernel(ConvParam
     ring = ring + PAIR >= NSTAGE ? ring + PAIR - NSTAGE : ring + PAIR;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy tail steps write LDS too
-  if (m0 + 128 <= p.M) conv_epilogue_full<32, 32 * TN, 1, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, W8 ? (wave >> 1) : wave, W8 ? (wave & 1) : 0, m0, n0);
-  else conv_epilogue<32, 32 * TN, 1, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, W8 ? (wave >> 1) : wave, W8 ? (wave & 1) : 0, m0, n0);
+  if (m0 + BM <= p.M) conv_epilogue_full<32, 32 * TN, 1, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, WT ? (wave >> 1) : wave, WT ? (wave & 1) : 0, m0, n0);
+  else conv_epilogue<32, 32 * TN, 1, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, WT ? (wave >> 1) : wave, WT ? (wave & 1) : 0, m0, n0);
 }
 
 // pointwise layers whose planes and weights stay below 4 GiB (32-bit buffer offsets) take the buffer-load form
@@ -724,20 +730,24 @@ static bool pw_eligible(const ConvParams& p) {
   return a_bytes < ((size_t)1 << 32) && b_bytes < ((size_t)1 << 32) && p.Cin_p == p.Kp;
 }
 
-template <int NSPLIT, bool PW = false, bool W8 = false>
+template <int NSPLIT, bool PW = false, bool W8 = false, bool H64 = false>
 static int launch_deep(const ConvParams& p, hipStream_t s) {
-  if (!PW && pw_eligible(p)) return launch_deep<NSPLIT, true, W8>(p, s);
-  if constexpr (!W8 && NSPLIT == 3) {
+  if (!PW && pw_eligible(p)) return launch_deep<NSPLIT, true, W8, H64>(p, s);
+  if constexpr (!W8 && !H64 && NSPLIT == 3) {
+    // 128 x 64 tiles on at most half of the CUs: 64 x 64 tiles (XDET_CONV_DEEP_H64=0: off, A/B runs)
+    static const bool h64 = !(getenv("XDET_CONV_DEEP_H64") && !strcmp(getenv("XDET_CONV_DEEP_H64"), "0"));
+    if (h64 && !p.group_rows && cdiv(p.M, 128) * (p.Cout_pad / 64) <= 128) return launch_deep<NSPLIT, PW, false, true>(p, s);
     static const bool w8 = !(getenv("XDET_CONV_DEEP_W8") && !strcmp(getenv("XDET_CONV_DEEP_W8"), "0"));   // A/B runs
     if (w8) return launch_deep<NSPLIT, PW, true>(p, s);
   }
-  constexpr size_t lds = (size_t)6 * (2 * 128 + 2 * 64) * 32 * sizeof(u16);
-  auto kern = conv_dma_deep_kernel<NSPLIT, PW, W8>;
+  constexpr int BM = H64 ? 64 : 128;
+  constexpr size_t lds = (size_t)6 * (2 * BM + 2 * 64) * 32 * sizeof(u16);
+  auto kern = conv_dma_deep_kernel<NSPLIT, PW, W8, H64>;
   static DeviceOnce once;
   XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), (int)lds));
-  dim3 grid((unsigned)(cdiv(cdiv(p.M, 128), 8) * 8 * (p.Cout_pad / 64)));
+  dim3 grid((unsigned)(cdiv(cdiv(p.M, BM), 8) * 8 * (p.Cout_pad / 64)));
   if (p.group_rows) {
-    const int64_t groups = p.M / p.group_rows, tpg = (int64_t)(p.group_rows / 128) * (p.Cout_pad / 64);
+    const int64_t groups = p.M / p.group_rows, tpg = (int64_t)(p.group_rows / BM) * (p.Cout_pad / 64);
     grid = dim3((unsigned)(cdiv(groups, 8) * 8 * tpg));
   }
   hipLaunchKernelGGL(kern, grid, dim3(W8 ? 512 : 256), lds, s, p);
