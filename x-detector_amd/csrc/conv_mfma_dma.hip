@@ -822,10 +822,14 @@ int launch_conv_mfma_dma(const ConvParams& p_in, int n_tile, int nsplit, hipStre
     const int64_t b256 = cdiv(p.M, 256) * (p.Cout_pad / 256), b128n = cdiv(p.M, 256) * (p.Cout_pad / 128);
     const int nk = p.Kp / 32;
     int tile = 0;
+    // (round 5: the 256 x 128 tile lost every same-box A/B against 128 x 128 tiles at two workgroups per CU -- ResNet-50 trunk at
+    //  batch 8 1.715 -> 1.683 ms, detector at batch 8 3.045 -> 2.860 ms, default bench neutral: its one-round grids run prologue,
+    //  K loop and a store-bound epilogue strictly in sequence on every CU.  XDET_CONV_T1_NK=<n>: use it for layers of >= n K steps)
+    static const int t1_nk = getenv("XDET_CONV_T1_NK") ? atoi(getenv("XDET_CONV_T1_NK")) : (1 << 30);
     // ...or when the 256x256 grid fills whole rounds of the 256 CUs (within 6 %)
     const bool full_rounds = b256 >= 240 && (b256 % 256 == 0 || b256 % 256 >= 240);
     if (p.Cout_pad % 256 == 0 && (b256 >= 512 || full_rounds || (b256 >= 200 && nk >= 40))) tile = 2;
-    else if (b128n >= 170) tile = 1;
+    else if (b128n >= 170 && nk >= t1_nk) tile = 1;
     if (p.group_rows && p.group_rows % 256 != 0) tile = 0;      // a group must be whole M tiles
     if (tile == 2) return launch_d<256, 256, 2, 4, 3>(p, s);
     if (tile == 1) return launch_d<256, 128, 4, 2, 3>(p, s);
