@@ -834,6 +834,21 @@ int launch_conv_mfma_dma(const ConvParams& p_in, int n_tile, int nsplit, hipStre
     if (tile == 2) return launch_d<256, 256, 2, 4, 3>(p, s);
     if (tile == 1) return launch_d<256, 128, 4, 2, 3>(p, s);
   }
+  if (n_tile == 128 && nsplit == 3 && !p.group_rows && !p.x8) {
+    // about one round of 128 x 128 tiles with a long K loop (a single image's block4_sepconv2, the middle flow at batches 3-5):
+    // the split-K kernel's four-stage ring with ONE range -- the same reduction, bit-identical -- runs a 32-deep step in ~0.65 us
+    // where the two-stage kernel pays ~1.2 (the rule of Plan::maybe_ksplit for ResNet-50's stage 2, here per call: one range
+    // changes no summation tree, so the choice may depend on the batch).  XDET_CONV_ONE_RING=0: off (A/B runs)
+    static const bool one_ring = !(getenv("XDET_CONV_ONE_RING") && !strcmp(getenv("XDET_CONV_ONE_RING"), "0"));
+    const int64_t b128 = cdiv(p.M, 128) * (p.Cout_pad / 128);
+    if (one_ring && b128 > 128 && b128 <= 256 && p.Kp / 32 >= 16 && p.Kp == p.Cin_p * p.KH * p.KW && p.ldi % 32 == 0 &&
+        conv_ksplit_supported(p.KH, p.KW, (int64_t)p.N * p.H * p.W, p.ldi, p.Cin_p, p.Cout_pad)) {
+      ConvParams q = p;
+      q.ksplit = 1;
+      q.ks_partial = nullptr;
+      return launch_conv_mfma_ksplit(q, 128, 3, 2, 0, s);
+    }
+  }
   if (n_tile == 128) {
     // small batches: 128 x 128 tiles leave most of the 256 CUs idle (a 900-row layer is 8 x 4..6 workgroups); halve
     // the N tile to double the workgroup count -- per-element K order is unchanged, so results stay bit-identical
