@@ -69,6 +69,20 @@ __device__ __forceinline__ u64 readlane_u64d(u64 v, int src) {
   return ((u64)hi << 32) | lo;
 }
 
+// the same decision from pre-normalised corners (y0, x0, y1, x1 with y0 <= y1, x0 <= x1) and pre-computed areas
+__device__ __forceinline__ bool iou_norm_gt_d(const float4 a, const float aa, const float4 b, const float ab, float thr) {
+  const float ih = fminf(a.z, b.z) - fmaxf(a.x, b.x);
+  const float iw = fminf(a.w, b.w) - fmaxf(a.y, b.y);
+  if (ih <= 0.f || iw <= 0.f) return false;
+  if (aa <= 0.f || ab <= 0.f) return false;
+  const float inter = ih * iw;
+  const float uni = (aa + ab) - inter;
+  const float t = thr * uni;
+  if (inter > t * 1.00001f) return true;
+  if (inter < t * 0.99999f) return false;
+  return inter / uni > thr;
+}
+
 constexpr int EV_MAXR = 1024;   // ROIs per image supported by one workgroup
 constexpr int EV_MAXS = 512;    // 2*nms_topk upper bound (sorted candidates)
 constexpr int EV_W = EV_MAXS / 64;
@@ -90,6 +104,14 @@ __global__ __launch_bounds__(EV_T) void bboxes_eval_kernel(const float* __restri
   __shared__ float4 sbox[EV_MAXS];
   __shared__ float sscore[EV_MAXS];
   __shared__ u64 mask[EV_MAXS * EV_W];
+  __shared__ u64 s_removed[EV_W];
+  // (aliases, so that two workgroups still share a CU: the sorted boxes with min/max-normalised corners -- what iou_gt_fast_d
+  //  makes of its arguments -- and their areas live in `bx`, dead once the sorted copies exist; the rank counters in `mask`,
+  //  which is not written before they are dead)
+  float4* const snorm = bx;
+  float* const sarea = reinterpret_cast<float*>(bx + EV_MAXS);
+  int* const s_rank = reinterpret_cast<int*>(mask);
+  static_assert(EV_MAXS * 16 + EV_MAXS * 4 <= EV_MAXR * 16 && EV_MAXR * 4 <= EV_MAXS * EV_W * 8, "aliases fit");
   __shared__ int s_nvalid;
   __shared__ int s_keptidx[EV_MAXS];
   __shared__ int s_nkeep;
@@ -149,35 +171,72 @@ __global__ __launch_bounds__(EV_T) void bboxes_eval_kernel(const float* __restri
 
   const int max_sorted = min(2 * nms_topk, EV_MAXS);
   const int n_sorted = min(s_nvalid, max_sorted);            // bboxes_sort: top_k(min(n, 2*topk))
-  // rank sort (descending score, ties -> lower ROI index)
-  for (int r = tid; r < R; r += EV_T) {
-    const u64 mine = keys[r];
-    if (mine == 0ull) continue;
-    int rank = 0;
-    for (int j = 0; j < R; ++j) rank += keys[j] > mine;
+  // rank sort (descending score, ties -> lower ROI index).  The R x R comparisons are spread over the whole workgroup: P threads
+  // per ROI count a slice of the keys each (a single image has 300 ROIs for 1024 threads)
+  for (int r = tid; r < R; r += EV_T) s_rank[r] = 0;
+  __syncthreads();
+  {
+    const int P = max(1, EV_T / R);
+    const int slice = (R + P - 1) / P;
+    for (int t = tid; t < R * P; t += EV_T) {
+      const int part = t / R, r = t - part * R;
+      const u64 mine = keys[r];
+      if (mine == 0ull) continue;
+      const int j0 = part * slice, j1 = min(R, j0 + slice);
+      int cnt = 0;
+#pragma unroll 8
+      for (int j = j0; j < j1; ++j) cnt += keys[j] > mine;
+      if (cnt) atomicAdd(&s_rank[r], cnt);
+    }
+  }
+  __syncthreads();
+  {
+    // R <= EV_T: one ROI per thread.  Read everything first: the sorted copies overwrite `bx`
+    const bool have = tid < R && keys[tid] != 0ull;
+    const u64 mine = have ? keys[tid] : 0ull;
+    const int rank = have ? s_rank[tid] : max_sorted;
+    const float4 b = have ? bx[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
     if (rank < max_sorted) {
-      sbox[rank] = bx[r];
+      sbox[rank] = b;
       sscore[rank] = __uint_as_float((unsigned)(mine >> 32));
+      const float y0 = fminf(b.x, b.z), y1 = fmaxf(b.x, b.z), x0 = fminf(b.y, b.w), x1 = fmaxf(b.y, b.w);
+      snorm[rank] = make_float4(y0, x0, y1, x1);
+      sarea[rank] = (y1 - y0) * (x1 - x0);
     }
+    if (tid < EV_W) s_removed[tid] = 0ull;
   }
   __syncthreads();
 
-  // NMS bitmask: bit (i,j) for j > i
+  // NMS bitmask: bit (i,j) for j > i.  One wave per (row i, 64-column block): a lane keeps ITS column's box in registers across
+  // the rows, the row's box is a broadcast read, the word is a ballot -- no per-lane loop over 64 columns with divergent exits,
+  // and the blocks left of the diagonal (no j > i in them) are written as zeros without an IoU.  iou_norm_gt_d is iou_gt_fast_d
+  // on the pre-normalised corners and areas: the same comparisons on the same values.
   const int w64 = (n_sorted + 63) / 64;
-  for (int t = tid; t < n_sorted * w64; t += EV_T) {
-    const int i = t / w64, wq = t - i * w64;
-    u64 bits = 0ull;
-    const float4 me = sbox[i];
-    const int jend = min(64, n_sorted - wq * 64);
-    for (int j = 0; j < jend; ++j) {
-      const int col = wq * 64 + j;
-      if (col > i && iou_gt_fast_d(me, sbox[col], nms_thr)) bits |= 1ull << j;
+  {
+    const int wv = tid >> 6, ln = tid & 63;
+    for (int wq = 0; wq < w64; ++wq) {
+      const int col = wq * 64 + ln;
+      const bool col_ok = col < n_sorted;
+      const float4 cb = col_ok ? snorm[col] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float ca = col_ok ? sarea[col] : 0.f;
+      for (int i = wv; i < n_sorted; i += EV_T / 64) {
+        u64 bits = 0ull;
+        if (i < wq * 64 + 63) {                       // (wave-uniform) some column of this block is right of the diagonal
+          const float4 me = snorm[i];
+          const float ma = sarea[i];
+          bits = __ballot(col_ok && col > i && iou_norm_gt_d(me, ma, cb, ca, nms_thr));
+        }
+        if (ln == 0) mask[i * EV_W + wq] = bits;
+      }
     }
-    mask[i * EV_W + wq] = bits;
   }
   __syncthreads();
 
-  // ordered scan by wave 0 (lane q < EV_W holds removed word q)
+  // ordered scan by wave 0 (lane q < EV_W holds removed word q).  Inside a 64-box chunk only the boxes that SURVIVE are visited
+  // (lowest bit still available, then its row's bits leave the set): the same sequence as a walk over all 64 bits, in as many
+  // steps as boxes are kept.  The rows of the kept boxes then go into the later chunks' removed words in parallel (each kept
+  // lane ORs its own row in), not one LDS round trip per kept box.
   if (tid < 64) {
     const int lane = tid;
     u64 removed = 0ull;
@@ -185,21 +244,29 @@ __global__ __launch_bounds__(EV_T) void bboxes_eval_kernel(const float* __restri
     for (int cch = 0; cch < w64 && n_keep < nms_topk; ++cch) {
       const int i = cch * 64 + lane;
       const u64 diag = i < n_sorted ? mask[i * EV_W + cch] : 0ull;
-      u64 cur = readlane_u64d(removed, cch);                   // scalar chain: cur, keepmask, row b are wave-uniform
+      const u64 cur = readlane_u64d(removed, cch);             // scalar chain: cur, avail, keepmask are wave-uniform
       const int lim = __builtin_amdgcn_readfirstlane(min(64, n_sorted - cch * 64));
+      u64 avail = ~cur & (lim == 64 ? ~0ull : ((1ull << lim) - 1ull));
       u64 keepmask = 0ull;
       int kc = n_keep;
-      for (int b = 0; b < lim && kc < nms_topk; ++b) {
-        const u64 d = readlane_u64d(diag, b);
-        if (!((cur >> b) & 1ull)) { keepmask |= 1ull << b; cur |= d; ++kc; }
+      while (avail != 0ull && kc < nms_topk) {
+        const int b = __ffsll((long long)avail) - 1;
+        keepmask |= 1ull << b;
+        ++kc;
+        avail &= ~(readlane_u64d(diag, b) | (1ull << b));
       }
-      if ((keepmask >> lane) & 1ull) s_keptidx[n_keep + __popcll(keepmask & ((1ull << lane) - 1ull))] = i;
+      const bool kept = (keepmask >> lane) & 1ull;
+      if (kept) s_keptidx[n_keep + __popcll(keepmask & ((1ull << lane) - 1ull))] = i;
       n_keep = kc;
-      u64 km = keepmask;
-      while (km) {
-        const int b = __ffsll((long long)km) - 1;
-        km &= km - 1ull;
-        if (lane < EV_W) removed |= mask[(cch * 64 + b) * EV_W + lane];
+      if (cch + 1 < w64 && n_keep < nms_topk) {
+        if (kept)
+          for (int q = cch + 1; q < w64; ++q) {
+            const u64 row = mask[i * EV_W + q];
+            if (row) atomicOr(&s_removed[q], row);
+          }
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        removed = lane < EV_W ? *reinterpret_cast<volatile u64*>(&s_removed[lane]) : 0ull;
       }
     }
     if (lane == 0) s_nkeep = n_keep;
