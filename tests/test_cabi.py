@@ -38,7 +38,7 @@ def test_header_ctypes_and_exports_agree(built):
 def test_library_has_gfx950_code_objects(built):
     blob = open(built, 'rb').read()
     assert b'gfx950' in blob
-    for kern in (b'conv_mfma_f32_kernel', b'psroialign_fwd_kernel', b'nms_greedy_kernel', b'depthwise3x3_tile_kernel', b'conv_dma_f16_kernel', b'bboxes_eval_kernel'):
+    for kern in (b'conv_mfma_f32_kernel', b'psroialign_fwd_kernel', b'nms_panel_kernel', b'depthwise3x3_tile_kernel', b'conv_dma_f16_kernel', b'bboxes_eval_kernel'):
         assert kern in blob
 
 

@@ -69,6 +69,63 @@ def test_get_proposals_long_candidate_list(tied, oracle):
     assert np.array_equal(rois, ref)
 
 
+def _clustered(rng, n, cnt, centres=40, jitter=0.02, scale=0.3):
+    """boxes in tight groups: many IoU > thr pairs and long suppression chains (what a real RPN emits)"""
+    c = rng.uniform(0.1, 0.9, (n, centres, 2))
+    hw = rng.uniform(0.08, scale, (n, centres, 2))
+    k = rng.integers(0, centres, (n, cnt))
+    cy = np.take_along_axis(c[..., 0], k, 1) + rng.normal(0, jitter, (n, cnt))
+    cx = np.take_along_axis(c[..., 1], k, 1) + rng.normal(0, jitter, (n, cnt))
+    h = np.take_along_axis(hw[..., 0], k, 1) * np.exp(rng.normal(0, 0.1, (n, cnt)))
+    w = np.take_along_axis(hw[..., 1], k, 1) * np.exp(rng.normal(0, 0.1, (n, cnt)))
+    boxes = np.stack([cy - h / 2, cx - w / 2, cy + h / 2, cx + w / 2], -1).astype(np.float32)
+    return rng.uniform(0.001, 0.999, (n, cnt)).astype(np.float32), boxes
+
+
+@pytest.mark.parametrize('n', [1, 3, 12, 20, 40, 70])
+@pytest.mark.parametrize('post', [300, 1000])
+def test_get_proposals_overlap_heavy_every_cluster_size(n, post, oracle):
+    """The proposal NMS runs as clusters of 16 / 8 / 4 / 2 / 1 workgroups per image depending on the batch
+    (proposals.hip nms_cluster_size); every form must make the reference's decisions (net/xception_body.py:57-67) on
+    inputs where most candidates ARE suppressed (all pre_n candidates get visited, the kept list never fills at 1000),
+    and an image's result must not depend on the batch it ran in."""
+    from xdet import ops
+    rng = np.random.default_rng(100 * n + post)
+    scores, boxes = _clustered(rng, n, 19800)
+    rois, counts = ops.get_proposals(scores, boxes, None, 5000, post, 0.7, 16. / 480, False, 'channels_first',
+                                     return_counts=True)
+    m = min(n, 2)
+    traces = []
+    ref = oracle.get_proposals(scores[:m], boxes[:m], 5000, post, 0.7, 16. / 480, traces)
+    assert np.array_equal(rois[:m], ref)
+    for i in range(m):
+        assert counts[i, 2] == min(traces[i]['n_keep'], post)
+    if post == 1000:
+        assert counts[:, 2].max() < 1000 and counts[:, 1].min() == 5000      # suppression-bound, as intended
+    if n > 2:
+        alone = ops.get_proposals(scores[n - 1:], boxes[n - 1:], None, 5000, post, 0.7, 16. / 480, False, 'channels_first')
+        assert np.array_equal(alone[0], rois[n - 1])
+
+
+def test_get_proposals_suppression_chain(oracle):
+    """A staircase of boxes, each overlapping only its neighbours above the threshold: candidate j's fate depends on
+    j-1's, whose fate depends on j-2's ... -- the longest dependency chain the panel resolve can meet (one fixed-point
+    round per link).  Greedy keeps every second box."""
+    from xdet import ops
+    n_box = 1500
+    step = 0.0004
+    y0 = 0.05 + step * np.arange(n_box)
+    # IoU(j, j+1) = (0.003 - 0.0004) / (0.003 + 0.0004) = 0.765 > 0.7; IoU(j, j+2) = 0.58
+    boxes = np.stack([y0, np.full(n_box, 0.1), y0 + 0.003, np.full(n_box, 0.9)], -1).astype(np.float32)
+    scores = np.linspace(0.99, 0.5, n_box).astype(np.float32)[None]
+    boxes = boxes[None]
+    rois, counts = ops.get_proposals(scores, boxes, None, 1500, 1000, 0.7, 0.001, False, 'channels_first', return_counts=True)
+    traces = []
+    ref = oracle.get_proposals(scores, boxes, 1500, 1000, 0.7, 0.001, traces)
+    assert traces[0]['n_keep'] == n_box // 2 and counts[0, 2] == n_box // 2
+    assert np.array_equal(rois, ref)
+
+
 def test_get_proposals_few_and_none(oracle):
     """fewer survivors than post_n -> tiled upsample; none -> the [.2,.2,.8,.8] fallback (:196-213)."""
     from xdet import ops

@@ -183,6 +183,9 @@ struct ProposalWorkspace {
   int* bad;                   // [N] set when an objectness score / box of the image is not finite (read by bboxes_eval)
   int* tbin;                  // [N] threshold bin
   int* kept;                  // [N][post_n]
+  unsigned* nms_ctl;          // [N][4] cluster barrier of the proposal NMS: arrival counter, give-up flag (zeroed with hist)
+  unsigned long long* nms_sup;  // [N][ceil(pre_n / 256)][8] per panel: candidates suppressed by the kept list (zeroed with hist)
+  unsigned long long* nms_col;  // [min(N, 64)][3][36][64] a cluster's exchange of the panel's own IoU bits
 };
 size_t proposal_workspace_bytes(int N, int n_anchor, int pre_n, int post_n);
 void proposal_workspace_carve(void* base, int N, int n_anchor, int pre_n, int post_n, ProposalWorkspace* ws);

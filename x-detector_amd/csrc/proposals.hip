@@ -29,6 +29,24 @@ typedef unsigned long long u64;
 
 constexpr int HIST_BINS = 16384;     // key >> 48 = score float bits >> 16 (scores are in (0, 1])
 
+// proposal NMS (nms_panel_kernel below): panels of 64 * NBLK candidates, clusters of G workgroups per image
+constexpr int NMS_THREADS = 1024, NMS_WAVES = NMS_THREADS / 64;
+constexpr int NMS_SUP_PANEL = 256;            // the granularity ws.nms_sup is sized by (the smallest panel)
+constexpr int NMS_MAX_CLUSTER = 16;
+constexpr int NMS_LDS_MAX = 159 * 1024;      // dynamic LDS a workgroup may ask for (160 KB per CU less the static part)
+constexpr int NMS_CLUSTER_NBLK = 8;           // a cluster's panel: 512 candidates
+constexpr int NMS_CLUSTER_IMAGES = 64;        // only batches up to this many images ever run clusters (ws.nms_col is sized by it)
+constexpr unsigned NMS_SPIN_LIMIT = 1u << 20; // ~1 s of polling: a cluster whose members are not co-resident gives up, loudly
+template <int NBLK> struct NmsPanel {
+  static constexpr int S = 64 * NBLK;                  // candidates per panel
+  static constexpr int TRI = NBLK * (NBLK + 1) / 2;    // 64 x 64 blocks (I <= J) of the panel's triangle
+};
+// int words zeroed by prop_zero_kernel at the start of every forward: hist[N][HIST_BINS], bad[round_up(N,4)],
+// nms_ctl[N][4] (cluster barrier counter, give-up flag), nms_sup[N][panels][8] as 64-bit words
+static inline size_t prop_zeroed_words(int N, int pre_n) {
+  return (size_t)N * HIST_BINS + (size_t)round_up(N, 4) + (size_t)N * 4 + (size_t)N * cdiv(pre_n, NMS_SUP_PANEL) * 16;
+}
+
 size_t proposal_workspace_bytes(int N, int n_anchor, int pre_n, int post_n) {
   size_t b = 0;
   auto add = [&](size_t x) { b += (x + 255) / 256 * 256; };
@@ -39,9 +57,10 @@ size_t proposal_workspace_bytes(int N, int n_anchor, int pre_n, int post_n) {
   add((size_t)N * pre_n * 16);
   add((size_t)N * pre_n * 4);
   add((size_t)N * n_anchor * 8);
-  add(((size_t)N * HIST_BINS + (size_t)round_up(N, 4)) * 4);   // hist + bad (zeroed together)
+  add(prop_zeroed_words(N, pre_n) * 4);                        // hist + bad + the NMS cluster words (zeroed together)
   add((size_t)N * 4);
   add((size_t)N * post_n * 4);
+  add((size_t)std::min(N, NMS_CLUSTER_IMAGES) * 3 * NmsPanel<NMS_CLUSTER_NBLK>::TRI * 64 * 8);
   return b;
 }
 
@@ -55,10 +74,13 @@ void proposal_workspace_carve(void* base, int N, int n_anchor, int pre_n, int po
   ws->sboxes = reinterpret_cast<float*>(take((size_t)N * pre_n * 16));
   ws->sscores = reinterpret_cast<float*>(take((size_t)N * pre_n * 4));
   ws->cand = reinterpret_cast<u64*>(take((size_t)N * n_anchor * 8));
-  ws->hist = reinterpret_cast<int*>(take(((size_t)N * HIST_BINS + (size_t)round_up(N, 4)) * 4));
+  ws->hist = reinterpret_cast<int*>(take(prop_zeroed_words(N, pre_n) * 4));
   ws->bad = ws->hist + (size_t)N * HIST_BINS;
+  ws->nms_ctl = reinterpret_cast<unsigned*>(ws->bad + round_up(N, 4));
+  ws->nms_sup = reinterpret_cast<u64*>(ws->nms_ctl + (size_t)N * 4);
   ws->tbin = reinterpret_cast<int*>(take((size_t)N * 4));
   ws->kept = reinterpret_cast<int*>(take((size_t)N * post_n * 4));
+  ws->nms_col = reinterpret_cast<u64*>(take((size_t)std::min(N, NMS_CLUSTER_IMAGES) * 3 * NmsPanel<NMS_CLUSTER_NBLK>::TRI * 64 * 8));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -327,129 +349,229 @@ __global__ void prop_scatter_kernel(const u64* __restrict__ cand, const int* __r
   sscores[(int64_t)n * pre_n + r] = __uint_as_float((unsigned)(key >> 32));
 }
 
-// IoU as tf.image.non_max_suppression computes it (NonMaxSuppressionV2): corners min/max
-// normalised, zero when either area is <= 0.
-__device__ __forceinline__ bool iou_gt(const float4 a, const float4 b, float thr) {
-  const float ay0 = fminf(a.x, a.z), ay1 = fmaxf(a.x, a.z), ax0 = fminf(a.y, a.w), ax1 = fmaxf(a.y, a.w);
-  const float by0 = fminf(b.x, b.z), by1 = fmaxf(b.x, b.z), bx0 = fminf(b.y, b.w), bx1 = fmaxf(b.y, b.w);
-  const float aa = (ay1 - ay0) * (ax1 - ax0);
-  const float ab = (by1 - by0) * (bx1 - bx0);
-  if (aa <= 0.f || ab <= 0.f) return false;
-  const float ih = fmaxf(fminf(ay1, by1) - fmaxf(ay0, by0), 0.f);
-  const float iw = fmaxf(fminf(ax1, bx1) - fmaxf(ax0, bx0), 0.f);
-  const float inter = ih * iw;
-  return inter / ((aa + ab) - inter) > thr;
-}
-
-// value of lane `src` (wave-uniform) as a scalar: v_readlane_b32, a few cycles, where __shfl() is a ds_bpermute round
-// trip through the LDS crossbar (~50 cycles) -- the serial resolve below is a 64-step dependent chain of these, and it,
-// not the IoU tests, was what the kernel's time went into (124 us per image on the single-image critical path)
-__device__ __forceinline__ u64 readlane_u64(u64 v, int src) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
-  return ((u64)hi << 32) | lo;
-}
-__device__ __forceinline__ u64 readfirstlane_u64(u64 v) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-  return ((u64)hi << 32) | lo;
-}
-
-// IoU(a,b) > thr with the reference's rounding, but without a division on the fast path: the
-// correctly rounded quotient can only disagree with a product test inside a 1e-5 relative band
-// around the threshold; only there is the division actually evaluated.
-__device__ __forceinline__ bool iou_gt_fast(const float4 a, const float4 b, float thr) {
-  const float ay0 = fminf(a.x, a.z), ay1 = fmaxf(a.x, a.z), ax0 = fminf(a.y, a.w), ax1 = fmaxf(a.y, a.w);
-  const float by0 = fminf(b.x, b.z), by1 = fmaxf(b.x, b.z), bx0 = fminf(b.y, b.w), bx1 = fmaxf(b.y, b.w);
-  const float ih = fminf(ay1, by1) - fmaxf(ay0, by0);
-  const float iw = fminf(ax1, bx1) - fmaxf(ax0, bx0);
-  if (ih <= 0.f || iw <= 0.f) return false;          // no overlap: IoU = 0 <= thr (thr >= 0)
-  const float aa = (ay1 - ay0) * (ax1 - ax0);
-  const float ab = (by1 - by0) * (bx1 - bx0);
-  if (aa <= 0.f || ab <= 0.f) return false;
-  const float inter = ih * iw;
-  const float uni = (aa + ab) - inter;
-  const float t = thr * uni;
-  if (inter > t * 1.00001f) return true;
-  if (inter < t * 0.99999f) return false;
-  return inter / uni > thr;
-}
-
 // ---------------------------------------------------------------------------------------
-// Greedy NMS against the KEPT list (one workgroup of NMS_WAVES waves per image).  tf.image.non_max_suppression
-// only ever compares a candidate with boxes that were kept before it, and stops at max_output_size: with
-// R = 300 kept boxes that is <= 64 x 300 IoUs per 64-candidate chunk and a few dozen chunks.  (The first
-// version built the full upper-triangular IoU bit matrix chip-wide -- 5000^2 / 2 IoUs per image, 200 MB of
-// mask for 64 images -- and scanned it: ~25x the CU time.)  Per chunk of 64 candidates (score order):
-//   1. every wave tests the chunk against a strided 1/NMS_WAVES of the kept boxes (kept box broadcast from
-//      LDS, candidate b in lane b), one ballot per wave -> bits of candidates already suppressed;
-//   2. the 64 x 64 intra-chunk matrix, NMS_WAVES column-strided parts OR-ed through LDS;
-//   3. wave 0 resolves the chunk serially (wave-uniform shuffles) and appends the survivors to the
-//      kept list.
-// Comparisons are iou_gt_fast(earlier, later, thr), strict >, visited in score order.
+// Greedy NMS (tf.image.non_max_suppression: visit in score order, keep a candidate unless a box kept before it has
+// IoU > thr with it, stop at max_output_size), in PANELS of 64 * NBLK candidates:
+//   A. every candidate of the panel against every box kept so far                  -> one "suppressed" bit per candidate
+//   B. the panel against itself: column j of the strict upper triangle as bits     -> col_j = { i < j : IoU(i, j) > thr }
+//   C. resolve: keep_j = ok_j & !sup_j & !(col_j & keep).  keep_j only depends on keep_i for i < j, so the equation has ONE
+//      solution -- the greedy one -- and iterating it from any start fixes at least one more leading candidate per round:
+//      a handful of rounds of (NBLK AND/ORs + one ballot) instead of a 64 * NBLK-step serial chain.
+// A and B are one inner loop (a wave holds 64 candidates, one per lane, and walks 64 reference boxes broadcast from LDS,
+// ~16 VALU operations per pair); their units of 64 x 64 pairs are dealt round-robin to every wave of the image's CLUSTER
+// of G workgroups.  With G > 1 (few images: the proposal stage of a single image is on the critical path of the forward,
+// and the reference's own operating point is rpn_post_nms_top_n = 1000 at batch 1, light_head_rfcn_eval.py:109-111,212)
+// the workgroups exchange the panel's bits through global memory behind ONE cluster barrier per panel and then each
+// resolves the panel redundantly, appending the same boxes to its own LDS copy of the kept list: no second barrier.
+// The previous form -- one workgroup per image, 64 candidates per step -- spent 1,029 us per image at R = 1000 on the
+// VALU of one CU (r05d_R1000_kernel_stats.csv).
+// Pair decisions are those of NonMaxSuppressionV2: corners min/max normalised, IoU = 0 when either area <= 0, strict >.
 // ---------------------------------------------------------------------------------------
-constexpr int NMS_WAVES = 16;   // the kept-list test of a chunk (64 candidates x n_keep boxes) is split over this many waves
-__global__ __launch_bounds__(64 * NMS_WAVES) void nms_greedy_kernel(const float* __restrict__ sboxes, int* __restrict__ counts,
-                                                         int pre_n, int post_n, float thr, int* __restrict__ kept) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char nmsg_smem[];
-  float4* kbox = reinterpret_cast<float4*>(nmsg_smem);          // [post_n] boxes kept so far
-  __shared__ float4 cb[64];
-  __shared__ u64 part_sup[NMS_WAVES];
-  __shared__ u64 part_diag[NMS_WAVES][64];
-  __shared__ int s_keep;
-  const int n = blockIdx.x;
+__host__ __device__ inline size_t nms_lds_bytes(int post_n, int nblk) {
+  const size_t p4 = (size_t)(post_n + 3) / 4 * 4;
+  return p4 * 20 + (size_t)64 * nblk * 20 + (size_t)nblk * (nblk + 1) / 2 * 64 * 8 + 64 + 2 * NMS_WAVES * 8 + 16;
+}
+
+// bit i of the result: IoU(ref[i], me) > thr.  Boxes are normalised (y0 <= y1, x0 <= x1) with their areas beside them; an
+// area <= 0 is stored as +inf, which makes every IoU with that box compare false below exactly as the reference's
+// "either area <= 0 -> 0" does, at no cost per pair.
+// Two product tests decide every pair outside a 1e-5 relative band around the threshold (~16 VALU operations per pair, no
+// division); a lane that met a pair inside the band (or a NaN from thr = 0) redoes its 64 pairs with the reference's own
+// expression: separately rounded product, difference and quotient.
+__device__ __noinline__ u64 nms_pair_bits_exact(const float4* ref, const float* ref_area, int cnt, const float4 me,
+                                                const float ma, const float thr) {
+  u64 bits = 0ull;
+  for (int i = 0; i < cnt; ++i) {
+    const float4 r = ref[i];
+    const float ih = fmaxf(fminf(r.z, me.z) - fmaxf(r.x, me.x), 0.f);
+    const float iw = fmaxf(fminf(r.w, me.w) - fmaxf(r.y, me.y), 0.f);
+    const float inter = __fmul_rn(ih, iw);
+    if (__fdiv_rn(inter, __fsub_rn(__fadd_rn(ref_area[i], ma), inter)) > thr) bits |= 1ull << i;
+  }
+  return bits;
+}
+// v_min_f32 / v_max_f32 as they are: fminf / fmaxf put a canonicalising v_max_f32 x, x, x in front of every operand (IEEE
+// minNum of a signalling NaN) -- eight more VALU operations per pair for inputs that are finite by construction
+__device__ __forceinline__ float vmin(float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float vmax(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ u64 nms_pair_bits(const float4* __restrict__ ref, const float* __restrict__ ref_area, int cnt,
+                                             const float4 me, const float ma, const float thr, const float thr_hi,
+                                             const float thr_lo) {
+  unsigned lo = 0u, hi = 0u;
+  bool band = false;
+  auto one = [&](int i) -> bool {
+    const float4 r = ref[i];
+    const float ih = vmax(vmin(r.z, me.z) - vmax(r.x, me.x), 0.f);
+    const float iw = vmin(r.w, me.w) - vmax(r.y, me.y);
+    const float inter = ih * iw;                      // <= 0 unless the boxes overlap
+    const float uni = (ref_area[i] + ma) - inter;
+    const bool h = fmaf(-thr_hi, uni, inter) > 0.f;
+    band |= !h && !(fmaf(-thr_lo, uni, inter) < 0.f);
+    return h;
+  };
+  const int c0 = min(cnt, 32);
+#pragma unroll 4
+  for (int i = 0; i < c0; ++i) lo |= one(i) ? (1u << i) : 0u;
+#pragma unroll 4
+  for (int i = 32; i < cnt; ++i) hi |= one(i) ? (1u << (i - 32)) : 0u;
+  u64 bits = ((u64)hi << 32) | lo;
+  if (band) bits = nms_pair_bits_exact(ref, ref_area, cnt, me, ma, thr);
+  return bits;
+}
+
+// Barrier of the G workgroups of one cluster: everything the cluster's workgroups stored before it is visible to every one
+// of them after it (cdna_hip_programming.md Guideline 16: stores drained by every wave, one agent-scope release, a relaxed
+// arrival on a monotonic counter, ONE relaxed poller, one agent-scope acquire, then the workgroup barrier).
+// Returns false when the poll gave up (the other workgroups of the cluster never arrived).
+__device__ __forceinline__ bool nms_cluster_barrier(unsigned* ctl, unsigned target, int* s_fail) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > NMS_SPIN_LIMIT || __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_fail = 1;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  return *s_fail == 0;
+}
+
+template <bool CLUSTER, int NBLK>
+__global__ __launch_bounds__(NMS_THREADS) void nms_panel_kernel(const float* __restrict__ sboxes, int* __restrict__ counts,
+                                                                int pre_n, int post_n, float thr, int* __restrict__ kept,
+                                                                int G, u64* nms_sup, int n_sup, u64* nms_col,
+                                                                unsigned* nms_ctl, int* __restrict__ bad) {
+  constexpr int S = NmsPanel<NBLK>::S, TRI = NmsPanel<NBLK>::TRI;
+  extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
+  const int p4 = (post_n + 3) / 4 * 4;
+  float4* kbox = reinterpret_cast<float4*>(nms_smem);                       // [p4]  boxes kept so far, normalised
+  float4* cb = kbox + p4;                                                   // [S]   the panel's candidates, normalised
+  u64* colL = reinterpret_cast<u64*>(cb + S);                               // [TRI][64]  (a single workgroup's exchange)
+  u64* supL = colL + TRI * 64;                                              // [8]
+  u64* Kb = supL + 8;                                                       // [2][NMS_WAVES] keep words of the resolve
+  float* karea = reinterpret_cast<float*>(Kb + 2 * NMS_WAVES);              // [p4]
+  float* ca = karea + p4;                                                   // [S]
+  int& s_fail = *reinterpret_cast<int*>(ca + S);                           // (no static LDS: it would shift the dynamic base off 16 B)
+  const int n = CLUSTER ? blockIdx.x / G : blockIdx.x, g = CLUSTER ? blockIdx.x % G : 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n_cand = counts[n * 4 + 1];
+  const int T = (CLUSTER ? G : 1) * NMS_WAVES, t = g * NMS_WAVES + wave;   // the cluster's waves
+  const int n_cand = __builtin_amdgcn_readfirstlane(counts[n * 4 + 1]);
   const float4* B = reinterpret_cast<const float4*>(sboxes) + (int64_t)n * pre_n;
   int* K = kept + (int64_t)n * post_n;
-  if (tid == 0) s_keep = 0;
-  __syncthreads();
-  const int n_chunk = (n_cand + 63) / 64;
-  for (int c = 0; c < n_chunk; ++c) {
-    const int n_keep = s_keep;                               // uniform: only changes between barriers
-    if (n_keep >= post_n) break;
-    const int rows = min(64, n_cand - c * 64);
-    if (tid < 64) cb[tid] = tid < rows ? B[c * 64 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+  u64* supG = nms_sup + (int64_t)n * n_sup * 8;
+  u64* colG = CLUSTER ? nms_col + (int64_t)n * 3 * TRI * 64 : nullptr;
+  unsigned* ctl = nms_ctl + n * 4;
+  const float thr_hi = thr * 1.00001f, thr_lo = thr * 0.99999f;
+  if (tid == 0) s_fail = 0;
+  int n_keep = 0;                                            // uniform over the workgroup AND over the cluster
+  for (int s = 0; s * S < n_cand && n_keep < post_n; ++s) {
+    const int base = s * S, rows = min(S, n_cand - base), nb = (rows + 63) >> 6;
+    if (tid < S) {
+      const float4 b = tid < rows ? B[base + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 nbx = make_float4(fminf(b.x, b.z), fminf(b.y, b.w), fmaxf(b.x, b.z), fmaxf(b.y, b.w));
+      cb[tid] = nbx;
+      const float area = (nbx.z - nbx.x) * (nbx.w - nbx.y);
+      ca[tid] = area > 0.f ? area : __builtin_inff();    // (a padding lane's zero box: never suppresses, never kept)
+    }
+    if (tid < 8) supL[tid] = 0ull;
     __syncthreads();
-    const float4 me = cb[lane];
-    // 1. against the kept list
-    bool hit = false;
-    if (lane < rows)
-      for (int k = wave; k < n_keep; k += NMS_WAVES)
-        if (iou_gt_fast(kbox[k], me, thr)) { hit = true; break; }
-    const u64 hb = __ballot(hit);
-    if (lane == 0) part_sup[wave] = hb;
-    // 2. intra-chunk: does candidate `lane` suppress a later candidate j of the chunk?
-    u64 bits = 0ull;
-    if (lane < rows)
-      for (int j = lane + 1 + wave; j < rows; j += NMS_WAVES)
-        if (iou_gt_fast(me, cb[j], thr)) bits |= 1ull << j;
-    part_diag[wave][lane] = bits;
-    __syncthreads();
-    // 3. serial resolve of the chunk
-    if (wave == 0) {
-      u64 cur_v = 0ull, diag = 0ull;
-#pragma unroll
-      for (int w = 0; w < NMS_WAVES; ++w) { cur_v |= part_sup[w]; diag |= part_diag[w][lane]; }
-      // the chain runs on the scalar unit: `cur`, `keepmask` and the row of candidate b are wave-uniform
-      u64 cur = readfirstlane_u64(cur_v);
-      u64 keepmask = 0ull;
-      int kc = n_keep;
-      const int rows_u = __builtin_amdgcn_readfirstlane(rows);
-      for (int b = 0; b < rows_u && kc < post_n; ++b) {
-        const u64 d = readlane_u64(diag, b);
-        if (!((cur >> b) & 1ull)) { keepmask |= 1ull << b; cur |= d; ++kc; }
+    // ---- A + B: units of (64 candidates) x (<= 64 reference boxes), round-robin over the cluster's waves
+    const int n_slice = (n_keep + 63) >> 6, nA = nb * n_slice, nB = nb * (nb + 1) / 2;
+    u64* colW = CLUSTER ? colG + (s % 3) * (TRI * 64) : colL;
+    for (int u = t; u < nA + nB; u += T) {
+      if (u < nA) {
+        const int J = u % nb, ks = (u / nb) << 6;
+        const u64 bits = nms_pair_bits(kbox + ks, karea + ks, min(64, n_keep - ks), cb[J * 64 + lane], ca[J * 64 + lane],
+                                       thr, thr_hi, thr_lo);
+        const u64 hit = __ballot(bits != 0ull);
+        if (lane == 0 && hit) atomicOr(&supL[J], hit);
+      } else {
+        const int v = u - nA;
+        int J = 0;
+        while ((J + 1) * (J + 2) / 2 <= v) ++J;
+        const int I = v - J * (J + 1) / 2;
+        u64 bits = nms_pair_bits(cb + I * 64, ca + I * 64, 64, cb[J * 64 + lane], ca[J * 64 + lane], thr, thr_hi, thr_lo);
+        if (I == J) bits &= (1ull << lane) - 1ull;           // strict upper triangle: only earlier candidates suppress
+        colW[v * 64 + lane] = bits;
       }
-      if ((keepmask >> lane) & 1ull) {
-        const int slot = n_keep + __popcll(keepmask & ((1ull << lane) - 1ull));
-        K[slot] = c * 64 + lane;
-        kbox[slot] = me;
-      }
-      if (lane == 0) s_keep = kc;
     }
     __syncthreads();
+    if (CLUSTER) {
+      if (tid < nb && supL[tid]) __hip_atomic_fetch_or(&supG[s * 8 + tid], supL[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!nms_cluster_barrier(ctl, (unsigned)G * (unsigned)(s + 1), &s_fail)) {
+        if (tid == 0) bad[n] = 1;                            // bboxes_eval turns it into a NaN the host raises on
+        return;
+      }
+    }
+    // ---- C: resolve the panel (threads 0 .. S-1 own one candidate each; every wave takes part in the barriers)
+    const int Jm = tid >> 6;
+    u64 col[NBLK];
+    bool ok = false;
+    if (tid < S) {
+      const u64 sw = CLUSTER ? __hip_atomic_load(&supG[s * 8 + Jm], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : supL[Jm];
+      ok = tid < rows && !((sw >> lane) & 1ull);
+#pragma unroll
+      for (int I = 0; I < NBLK; ++I) col[I] = I <= Jm && Jm < nb ? colW[(Jm * (Jm + 1) / 2 + I) * 64 + lane] : 0ull;
+    }
+    {
+      const u64 k0 = __ballot(ok);
+      if (lane == 0) Kb[wave] = k0;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int round = 0; round < S + 1; ++round) {
+      bool nk = false;
+      u64 old = 0ull;
+      if (tid < S) {
+        u64 acc = 0ull;
+#pragma unroll
+        for (int I = 0; I < NBLK; ++I) acc |= col[I] & Kb[cur * NMS_WAVES + I];
+        nk = ok && acc == 0ull;
+        old = Kb[cur * NMS_WAVES + Jm];
+      }
+      const u64 kw = __ballot(nk);
+      if (lane == 0) Kb[(cur ^ 1) * NMS_WAVES + wave] = kw;
+      cur ^= 1;
+      if (!__syncthreads_or(tid < S && kw != old)) break;
+    }
+    // ---- append the survivors (in candidate order) to the kept list, up to post_n
+    int before = 0, total = 0;
+#pragma unroll
+    for (int I = 0; I < NBLK; ++I) {
+      const int c = __popcll(Kb[cur * NMS_WAVES + I]);
+      before += I < Jm ? c : 0;
+      total += c;
+    }
+    if (tid < S && ((Kb[cur * NMS_WAVES + Jm] >> lane) & 1ull)) {
+      const int slot = n_keep + before + __popcll(Kb[cur * NMS_WAVES + Jm] & ((1ull << lane) - 1ull));
+      if (slot < post_n) {
+        kbox[slot] = cb[tid];
+        karea[slot] = ca[tid];
+        if (g == 0) K[slot] = base + tid;
+      }
+    }
+    n_keep = __builtin_amdgcn_readfirstlane(min(post_n, n_keep + total));
+    __syncthreads();
   }
-  if (tid == 0) counts[n * 4 + 2] = s_keep;
+  if (g == 0 && tid == 0) counts[n * 4 + 2] = n_keep;
+}
+
+// workgroups per image: a cluster only where the images alone cannot fill the chip; its members must all be resident
+// (they wait for each other), so images x G stays within half of the 256 CUs
+int nms_cluster_size(int N) {
+  if (N > NMS_CLUSTER_IMAGES) return 1;
+  int G = NMS_MAX_CLUSTER;
+  while (G > 1 && N * G > 128) G >>= 1;
+  return G;
 }
 
 __global__ void prop_gather_kernel(const float* __restrict__ sboxes, const int* __restrict__ kept,
@@ -470,8 +592,9 @@ int launch_get_proposals(const float* objectness, const float* boxes, int N, int
                          float nms_thr, float min_size, const ProposalWorkspace& ws, float* rois, hipStream_t s) {
   XDET_REQUIRE(N > 0 && n_anchor > 0 && pre_n > 0 && post_n > 0, "get_proposals: sizes must be positive");
   // one launch instead of three hipMemsetAsync (which the runtime splits into ~12 fill kernels per forward)
+  XDET_REQUIRE(nms_thr >= 0.f, "get_proposals: the NMS threshold must be >= 0");
   hipLaunchKernelGGL(prop_zero_kernel, dim3(512), dim3(256), 0, s, reinterpret_cast<uint4*>(ws.hist),
-                     ((int64_t)N * HIST_BINS + round_up(N, 4)) * 4 / 16, reinterpret_cast<uint4*>(ws.sboxes), (int64_t)N * pre_n,
+                     (int64_t)(prop_zeroed_words(N, pre_n) / 4), reinterpret_cast<uint4*>(ws.sboxes), (int64_t)N * pre_n,
                      reinterpret_cast<unsigned*>(ws.sscores), (int64_t)N * pre_n);
   XDET_LAUNCH_CHECK();
   const unsigned gb = (unsigned)cdiv(n_anchor, 256);
@@ -501,11 +624,26 @@ int launch_get_proposals(const float* objectness, const float* boxes, int N, int
                      ws.counts, ws.sboxes, ws.sscores, sort_max);
   XDET_LAUNCH_CHECK();
   {
-    XDET_REQUIRE((size_t)post_n * 16 <= 96 * 1024, "get_proposals: rpn_post_nms_top_n too large (max 6144)");
-    static DeviceOnce once;
-    XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(nms_greedy_kernel), 96 * 1024));
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3(N), dim3(64 * NMS_WAVES), (size_t)post_n * 16, s, ws.sboxes, ws.counts, pre_n, post_n,
-                       nms_thr, ws.kept);
+    const int G = nms_cluster_size(N);
+    u64* sup = ws.nms_sup;
+    const int n_sup = (int)cdiv(pre_n, NMS_SUP_PANEL);
+    if (G > 1) {
+      constexpr int NB = NMS_CLUSTER_NBLK;
+      const size_t lds = nms_lds_bytes(post_n, NB);
+      XDET_REQUIRE(lds <= NMS_LDS_MAX, "get_proposals: rpn_post_nms_top_n too large (max 6144)");
+      static DeviceOnce once;
+      XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(nms_panel_kernel<true, NB>), NMS_LDS_MAX));
+      hipLaunchKernelGGL((nms_panel_kernel<true, NB>), dim3(N * G), dim3(NMS_THREADS), lds, s, ws.sboxes, ws.counts, pre_n,
+                         post_n, nms_thr, ws.kept, G, sup, n_sup, ws.nms_col, ws.nms_ctl, ws.bad);
+    } else {
+      constexpr int NB = 4;
+      const size_t lds = nms_lds_bytes(post_n, NB);
+      XDET_REQUIRE(lds <= NMS_LDS_MAX, "get_proposals: rpn_post_nms_top_n too large (max 6144)");
+      static DeviceOnce once;
+      XDET_TRY(ensure_dynamic_lds(once, reinterpret_cast<const void*>(nms_panel_kernel<false, NB>), NMS_LDS_MAX));
+      hipLaunchKernelGGL((nms_panel_kernel<false, NB>), dim3(N), dim3(NMS_THREADS), lds, s, ws.sboxes, ws.counts, pre_n,
+                         post_n, nms_thr, ws.kept, 1, sup, n_sup, ws.nms_col, ws.nms_ctl, ws.bad);
+    }
     XDET_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(prop_gather_kernel, dim3((unsigned)cdiv(post_n, 256), N), dim3(256), 0, s, ws.sboxes, ws.kept,
