@@ -202,4 +202,12 @@ int launch_bboxes_eval(const float* cls, int ld_cls, const float* boxes, int N, 
                        float nms_thr, int nms_topk, float* det_scores, float* det_boxes, hipStream_t s,
                        const int* bad_per_image = nullptr);
 
+// the whole forward's form: A11 + the head's class probabilities (class-major [N][num_classes][R]) in one pass over the ROIs,
+// then A12 reading its class's column instead of redoing the softmax in each of the 20 class workgroups
+int launch_head_decode_probs(const float* rois, const float* cls_reg, int ld, int num_classes, int R, int64_t n, float* out,
+                             float* probs, int* bad, hipStream_t s);
+int launch_bboxes_eval_probs(const float* probs, const float* boxes, int N, int R, int num_classes, const int* image_shapes,
+                             const float* bbox_img, int net_h, int net_w, float select_thr, float nms_thr, int nms_topk,
+                             float* det_scores, float* det_boxes, hipStream_t s, const int* bad_per_image = nullptr);
+
 }  // namespace xdet

@@ -33,33 +33,63 @@ __global__ void ext_decode_rois_kernel(const float* __restrict__ rois, const flo
   }
 }
 
+// softmax probability of class c of one ROI's logits, and whether any logit is non-finite (tf.nn.softmax, eval.py:265)
+__device__ __forceinline__ void class_probs_begin(const float* __restrict__ lg, int num_classes, float* m_out, float* sum_out,
+                                                  bool* bad) {
+  float m = lg[0];
+  float lsum = lg[0];
+  for (int k = 1; k < num_classes; ++k) { m = fmaxf(m, lg[k]); lsum += lg[k]; }
+  *bad = !(fabsf(lsum) <= FLT_MAX);
+  float sum = 0.f;
+  for (int k = 0; k < num_classes; ++k) sum += expf(lg[k] - m);
+  *m_out = m;
+  *sum_out = sum;
+}
+
+// A11 + the class probabilities A12 starts from, once per ROI (the whole forward): bboxes_eval runs one workgroup per
+// (image, class), and each of the 20 used to redo the 21-way softmax of every ROI from row-strided logits -- 430 of the
+// kernel's 580 us per 128 images at R = 1000.  probs is class-major [N][num_classes][R]: the class workgroup reads its
+// column coalesced.  A non-finite logit marks the image in `bad` (bboxes_eval makes it a NaN the host raises on).
+__global__ void head_decode_probs_kernel(const float* __restrict__ rois, const float* __restrict__ cls_reg, int ld, int num_classes,
+                                         int R, int64_t n, float* __restrict__ out, float* __restrict__ probs,
+                                         int* __restrict__ bad) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 r = *reinterpret_cast<const float4*>(rois + i * 4);
+    const float* lg = cls_reg + i * ld;
+    const float* p = lg + num_classes;
+    const float href = r.z - r.x, wref = r.w - r.y;
+    const float yref = r.x + href / 2.f, xref = r.y + wref / 2.f;
+    const float ph = expf(p[2]) * href;
+    const float pw = expf(p[3]) * wref;
+    const float pcy = p[0] * href + yref;
+    const float pcx = p[1] * wref + xref;
+    *reinterpret_cast<float4*>(out + i * 4) =
+        make_float4(pcy - ph / 2.f, pcx - pw / 2.f, pcy + ph / 2.f, pcx + pw / 2.f);
+    float m, sum;
+    bool isbad;
+    class_probs_begin(lg, num_classes, &m, &sum, &isbad);
+    const int64_t img = i / R;
+    const int ri = (int)(i - img * R);
+    for (int k = 0; k < num_classes; ++k) probs[(img * num_classes + k) * R + ri] = expf(lg[k] - m) / sum;
+    if (isbad) bad[img] = 1;
+  }
+}
+
+int launch_head_decode_probs(const float* rois, const float* cls_reg, int ld, int num_classes, int R, int64_t n, float* out,
+                             float* probs, int* bad, hipStream_t s) {
+  if (n == 0) return XDET_OK;
+  hipLaunchKernelGGL(head_decode_probs_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 2048)), dim3(256), 0, s, rois,
+                     cls_reg, ld, num_classes, R, n, out, probs, bad);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
 int launch_ext_decode_rois(const float* rois, const float* reg, int ld_reg, int64_t n, float* out, hipStream_t s) {
   if (n == 0) return XDET_OK;
   hipLaunchKernelGGL(ext_decode_rois_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 2048)), dim3(256), 0, s,
                      rois, reg, ld_reg, n, out);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
-}
-
-// IoU(a, b) > thr as tf.image.non_max_suppression decides it (corners min/max-normalised, zero when either area is <= 0,
-// strict >), without a division on the fast path (as proposals.hip's iou_gt_fast): the correctly rounded
-// quotient can only disagree with the product test inside a 1e-5 relative band around the threshold, and only there
-// is the division evaluated.  The per-class NMS mask is ~45,000 IoUs per (image, class) workgroup.
-__device__ __forceinline__ bool iou_gt_fast_d(const float4 a, const float4 b, float thr) {
-  const float ay0 = fminf(a.x, a.z), ay1 = fmaxf(a.x, a.z), ax0 = fminf(a.y, a.w), ax1 = fmaxf(a.y, a.w);
-  const float by0 = fminf(b.x, b.z), by1 = fmaxf(b.x, b.z), bx0 = fminf(b.y, b.w), bx1 = fmaxf(b.y, b.w);
-  const float ih = fminf(ay1, by1) - fmaxf(ay0, by0);
-  const float iw = fminf(ax1, bx1) - fmaxf(ax0, bx0);
-  if (ih <= 0.f || iw <= 0.f) return false;          // no overlap: IoU = 0 <= thr (thr >= 0)
-  const float aa = (ay1 - ay0) * (ax1 - ax0);
-  const float ab = (by1 - by0) * (bx1 - bx0);
-  if (aa <= 0.f || ab <= 0.f) return false;
-  const float inter = ih * iw;
-  const float uni = (aa + ab) - inter;
-  const float t = thr * uni;
-  if (inter > t * 1.00001f) return true;
-  if (inter < t * 0.99999f) return false;
-  return inter / uni > thr;
 }
 
 // lane `src` (wave-uniform) of a 64-bit value as a scalar: v_readlane, not a ds_bpermute round trip (proposals.hip)
@@ -69,18 +99,26 @@ __device__ __forceinline__ u64 readlane_u64d(u64 v, int src) {
   return ((u64)hi << 32) | lo;
 }
 
-// the same decision from pre-normalised corners (y0, x0, y1, x1 with y0 <= y1, x0 <= x1) and pre-computed areas
-__device__ __forceinline__ bool iou_norm_gt_d(const float4 a, const float aa, const float4 b, const float ab, float thr) {
-  const float ih = fminf(a.z, b.z) - fmaxf(a.x, b.x);
-  const float iw = fminf(a.w, b.w) - fmaxf(a.y, b.y);
-  if (ih <= 0.f || iw <= 0.f) return false;
-  if (aa <= 0.f || ab <= 0.f) return false;
-  const float inter = ih * iw;
+// IoU(a, b) > thr as tf.image.non_max_suppression decides it (corners min/max-normalised, zero when either area is <= 0,
+// strict >), from pre-normalised corners (y0, x0, y1, x1 with y0 <= y1, x0 <= x1) and pre-computed areas, without a
+// division on the fast path (as proposals.hip's nms_pair_bits): the correctly rounded quotient can only disagree with the
+// product tests inside a 1e-5 relative band around the threshold, and only there is the reference's expression evaluated.
+// An area <= 0 is passed as +inf: every test below is then false, which is the reference's "IoU = 0".
+// The per-class NMS mask is up to ~80,000 IoUs per (image, class) workgroup.
+__device__ __forceinline__ float vmin_d(float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float vmax_d(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ bool iou_norm_gt_d(const float4 a, const float aa, const float4 b, const float ab, float thr,
+                                              float thr_hi, float thr_lo) {
+  const float ih = vmax_d(vmin_d(a.z, b.z) - vmax_d(a.x, b.x), 0.f);
+  const float iw = vmin_d(a.w, b.w) - vmax_d(a.y, b.y);
+  const float inter = ih * iw;                        // <= 0 unless the boxes overlap
   const float uni = (aa + ab) - inter;
-  const float t = thr * uni;
-  if (inter > t * 1.00001f) return true;
-  if (inter < t * 0.99999f) return false;
-  return inter / uni > thr;
+  bool h = fmaf(-thr_hi, uni, inter) > 0.f;
+  if (!h && !(fmaf(-thr_lo, uni, inter) < 0.f)) {     // the band (or NaN from thr = 0): the reference's own rounding
+    const float in2 = __fmul_rn(ih, vmax_d(iw, 0.f));
+    h = __fdiv_rn(in2, __fsub_rn(__fadd_rn(aa, ab), in2)) > thr;
+  }
+  return h;
 }
 
 constexpr int EV_MAXR = 1024;   // ROIs per image supported by one workgroup
@@ -91,6 +129,8 @@ constexpr int EV_T = 1024;      // threads per workgroup
 // grid (num_classes-1, N), EV_T threads.  One workgroup per (image, class) is all the parallelism a single image offers
 // (20 workgroups on 256 CUs), so the workgroup is as wide as it can be: the rank sort and the IoU mask are spread over
 // 16 waves instead of 4 (single-image latency; at large batches the total work is what counts and is unchanged).
+// PRE: `cls` holds the class-major probabilities [N][num_classes][R] instead of the logits rows
+template <bool PRE>
 __global__ __launch_bounds__(EV_T) void bboxes_eval_kernel(const float* __restrict__ cls, int ld_cls,
                                                           const float* __restrict__ boxes, int R, int num_classes,
                                                           const int* __restrict__ image_shapes,
@@ -129,60 +169,71 @@ __global__ __launch_bounds__(EV_T) void bboxes_eval_kernel(const float* __restri
   const float min_size = fmaxf(0.0001f, 0.03f * sqrtf(area / (float)(net_h * net_w)));
   const float sx = ref.z - ref.x, sy = ref.w - ref.y;   // bboxes_resize scale (h, w)
 
-  int local_valid = 0, local_bad = bad_per_image ? bad_per_image[n] : 0;   // (proposal stage: non-finite RPN outputs)
-  for (int r = tid; r < R; r += EV_T) {
-    const float* lg = cls + ((int64_t)n * R + r) * ld_cls;
-    float m = lg[0];
-    float lsum = lg[0];
-    for (int k = 1; k < num_classes; ++k) { m = fmaxf(m, lg[k]); lsum += lg[k]; }
-    // A non-finite logit (an activation that left the f16 range of the split-precision convs upstream, or a broken
-    // checkpoint) would otherwise vanish here: its score compares false against the threshold and the image simply
-    // has no detections.  It is made loud instead: the (image, class) slot is marked NaN below, the host raises.
-    local_bad |= !(fabsf(lsum) <= FLT_MAX);
-    float sum = 0.f, ec = 0.f;
-    for (int k = 0; k < num_classes; ++k) {
-      const float e = expf(lg[k] - m);
-      sum += e;
-      if (k == c) ec = e;
+  int local_bad = bad_per_image ? bad_per_image[n] : 0;     // (proposal stage: non-finite RPN outputs)
+  for (int r0 = 0; r0 < R; r0 += EV_T) {
+    const int r = r0 + tid;
+    bool valid = false;
+    float s = 0.f;
+    if (r < R) {
+      if (PRE) {
+        s = cls[((int64_t)n * num_classes + c) * R + r];        // class-major probabilities (head_decode_probs_kernel)
+      } else {
+        // A non-finite logit (an activation that left the f16 range of the split-precision convs upstream, or a broken
+        // checkpoint) would otherwise vanish here: its score compares false against the threshold and the image simply
+        // has no detections.  It is made loud instead: the (image, class) slot is marked NaN below, the host raises.
+        const float* lg = cls + ((int64_t)n * R + r) * ld_cls;
+        float m, sum;
+        bool isbad;
+        class_probs_begin(lg, num_classes, &m, &sum, &isbad);
+        local_bad |= isbad;
+        s = expf(lg[c] - m) / sum;
+      }
+      const float fmask = s > select_thr ? 1.f : 0.f;          // tf_bboxes_select_layer :581-585
+      s = s * fmask;
+      float4 b = *reinterpret_cast<const float4*>(boxes + ((int64_t)n * R + r) * 4);
+      b.x *= fmask; b.y *= fmask; b.z *= fmask; b.w *= fmask;
+      // bboxes_clip(bbox_img, .)
+      float ymin = fmaxf(b.x, ref.x), xmin = fmaxf(b.y, ref.y);
+      const float ymax = fminf(b.z, ref.z), xmax = fminf(b.w, ref.w);
+      ymin = fminf(ymin, ymax);
+      xmin = fminf(xmin, xmax);
+      // filter_boxes
+      const float ws = xmax - xmin, hs = ymax - ymin;
+      const float xc = xmin + ws / 2.f, yc = ymin + hs / 2.f;
+      // zero-score survivors only ever act as zero padding downstream -> drop them here
+      valid = ws > min_size && hs > min_size && xc > 0.f && yc > 0.f && xc < 1.f && yc < 1.f && s > 0.f;
+      // bboxes_resize
+      bx[r] = make_float4((ymin - ref.x) / sx, (xmin - ref.y) / sy, (ymax - ref.x) / sx, (xmax - ref.y) / sy);
     }
-    float s = ec / sum;
-    const float fmask = s > select_thr ? 1.f : 0.f;          // tf_bboxes_select_layer :581-585
-    s = s * fmask;
-    float4 b = *reinterpret_cast<const float4*>(boxes + ((int64_t)n * R + r) * 4);
-    b.x *= fmask; b.y *= fmask; b.z *= fmask; b.w *= fmask;
-    // bboxes_clip(bbox_img, .)
-    float ymin = fmaxf(b.x, ref.x), xmin = fmaxf(b.y, ref.y);
-    const float ymax = fminf(b.z, ref.z), xmax = fminf(b.w, ref.w);
-    ymin = fminf(ymin, ymax);
-    xmin = fminf(xmin, xmax);
-    // filter_boxes
-    const float ws = xmax - xmin, hs = ymax - ymin;
-    const float xc = xmin + ws / 2.f, yc = ymin + hs / 2.f;
-    // zero-score survivors only ever act as zero padding downstream -> drop them here
-    const bool valid = ws > min_size && hs > min_size && xc > 0.f && yc > 0.f && xc < 1.f && yc < 1.f && s > 0.f;
-    // bboxes_resize
-    bx[r] = make_float4((ymin - ref.x) / sx, (xmin - ref.y) / sy, (ymax - ref.x) / sx, (xmax - ref.y) / sy);
-    keys[r] = valid ? (((u64)__float_as_uint(s) << 32) | (u64)(0xFFFFFFFFu - (unsigned)r)) : 0ull;
-    local_valid += valid;
+    // Only the ROIs that pass (score above the class threshold: a few per cent of them) go on: their keys are packed at
+    // the front of `keys` (in any order -- the rank below is by key, and the key carries the ROI index), so the rank sort
+    // is V x V comparisons instead of R x R: at the reference's R = 1000 (light_head_rfcn_eval.py:111) the R x R form
+    // was 11x the R = 300 work in each of the 20 x N workgroups.
+    const u64 vb = __ballot(valid);
+    int base = 0;
+    if ((tid & 63) == 0 && vb) base = atomicAdd(&s_nvalid, __popcll(vb));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (valid)
+      keys[base + __popcll(vb & ((1ull << (tid & 63)) - 1ull))] =
+          ((u64)__float_as_uint(s) << 32) | (u64)(0xFFFFFFFFu - (unsigned)r);
   }
-  if (local_valid) atomicAdd(&s_nvalid, local_valid);
   if (local_bad) atomicOr(&s_bad, 1);
   __syncthreads();
 
+  const int V = s_nvalid;
   const int max_sorted = min(2 * nms_topk, EV_MAXS);
-  const int n_sorted = min(s_nvalid, max_sorted);            // bboxes_sort: top_k(min(n, 2*topk))
-  // rank sort (descending score, ties -> lower ROI index).  The R x R comparisons are spread over the whole workgroup: P threads
-  // per ROI count a slice of the keys each (a single image has 300 ROIs for 1024 threads)
-  for (int r = tid; r < R; r += EV_T) s_rank[r] = 0;
+  const int n_sorted = min(V, max_sorted);                   // bboxes_sort: top_k(min(n, 2*topk))
+  // rank sort (descending score, ties -> lower ROI index).  The V x V comparisons are spread over the whole workgroup: P
+  // threads per key count a slice of the keys each
+  for (int r = tid; r < V; r += EV_T) s_rank[r] = 0;
   __syncthreads();
-  {
-    const int P = max(1, EV_T / R);
-    const int slice = (R + P - 1) / P;
-    for (int t = tid; t < R * P; t += EV_T) {
-      const int part = t / R, r = t - part * R;
+  if (V > 0) {
+    const int P = max(1, EV_T / V);
+    const int slice = (V + P - 1) / P;
+    for (int t = tid; t < V * P; t += EV_T) {
+      const int part = t / V, r = t - part * V;
       const u64 mine = keys[r];
-      if (mine == 0ull) continue;
-      const int j0 = part * slice, j1 = min(R, j0 + slice);
+      const int j0 = part * slice, j1 = min(V, j0 + slice);
       int cnt = 0;
 #pragma unroll 8
       for (int j = j0; j < j1; ++j) cnt += keys[j] > mine;
@@ -191,18 +242,19 @@ __global__ __launch_bounds__(EV_T) void bboxes_eval_kernel(const float* __restri
   }
   __syncthreads();
   {
-    // R <= EV_T: one ROI per thread.  Read everything first: the sorted copies overwrite `bx`
-    const bool have = tid < R && keys[tid] != 0ull;
+    // V <= R <= EV_T: one key per thread.  Read everything first: the sorted copies overwrite `bx`
+    const bool have = tid < V;
     const u64 mine = have ? keys[tid] : 0ull;
     const int rank = have ? s_rank[tid] : max_sorted;
-    const float4 b = have ? bx[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b = have ? bx[0xFFFFFFFFu - (unsigned)mine] : make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     if (rank < max_sorted) {
       sbox[rank] = b;
       sscore[rank] = __uint_as_float((unsigned)(mine >> 32));
       const float y0 = fminf(b.x, b.z), y1 = fmaxf(b.x, b.z), x0 = fminf(b.y, b.w), x1 = fmaxf(b.y, b.w);
       snorm[rank] = make_float4(y0, x0, y1, x1);
-      sarea[rank] = (y1 - y0) * (x1 - x0);
+      const float ar = (y1 - y0) * (x1 - x0);
+      sarea[rank] = ar > 0.f ? ar : __builtin_inff();
     }
     if (tid < EV_W) s_removed[tid] = 0ull;
   }
@@ -213,19 +265,20 @@ __global__ __launch_bounds__(EV_T) void bboxes_eval_kernel(const float* __restri
   // and the blocks left of the diagonal (no j > i in them) are written as zeros without an IoU.  iou_norm_gt_d is iou_gt_fast_d
   // on the pre-normalised corners and areas: the same comparisons on the same values.
   const int w64 = (n_sorted + 63) / 64;
+  const float thr_hi = nms_thr * 1.00001f, thr_lo = nms_thr * 0.99999f;
   {
     const int wv = tid >> 6, ln = tid & 63;
     for (int wq = 0; wq < w64; ++wq) {
       const int col = wq * 64 + ln;
       const bool col_ok = col < n_sorted;
       const float4 cb = col_ok ? snorm[col] : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float ca = col_ok ? sarea[col] : 0.f;
+      const float ca = col_ok ? sarea[col] : __builtin_inff();
       for (int i = wv; i < n_sorted; i += EV_T / 64) {
         u64 bits = 0ull;
         if (i < wq * 64 + 63) {                       // (wave-uniform) some column of this block is right of the diagonal
           const float4 me = snorm[i];
           const float ma = sarea[i];
-          bits = __ballot(col_ok && col > i && iou_norm_gt_d(me, ma, cb, ca, nms_thr));
+          bits = __ballot(col_ok && col > i && iou_norm_gt_d(me, ma, cb, ca, nms_thr, thr_hi, thr_lo));
         }
         if (ln == 0) mask[i * EV_W + wq] = bits;
       }
@@ -290,19 +343,38 @@ __global__ __launch_bounds__(EV_T) void bboxes_eval_kernel(const float* __restri
   }
 }
 
+static int launch_bboxes_eval_any(bool pre, const float* cls, int ld_cls, const float* boxes, int N, int R, int num_classes,
+                                  const int* image_shapes, const float* bbox_img, int net_h, int net_w, float select_thr,
+                                  float nms_thr, int nms_topk, float* det_scores, float* det_boxes, hipStream_t s,
+                                  const int* bad_per_image) {
+  XDET_REQUIRE(R > 0 && R <= EV_MAXR, "bboxes_eval: 1 <= rois per image <= 1024");
+  XDET_REQUIRE(nms_topk > 0 && 2 * nms_topk <= EV_MAXS, "bboxes_eval: nms_topk must be in 1..256");
+  XDET_REQUIRE(num_classes >= 2 && (pre || num_classes <= ld_cls), "bboxes_eval: bad num_classes");
+  XDET_REQUIRE(nms_thr >= 0.f, "bboxes_eval: the NMS threshold must be >= 0");
+  if (N == 0) return XDET_OK;
+  if (pre)
+    hipLaunchKernelGGL(bboxes_eval_kernel<true>, dim3(num_classes - 1, N), dim3(EV_T), 0, s, cls, ld_cls, boxes, R, num_classes,
+                       image_shapes, bbox_img, net_h, net_w, select_thr, nms_thr, nms_topk, det_scores, det_boxes, bad_per_image);
+  else
+    hipLaunchKernelGGL(bboxes_eval_kernel<false>, dim3(num_classes - 1, N), dim3(EV_T), 0, s, cls, ld_cls, boxes, R, num_classes,
+                       image_shapes, bbox_img, net_h, net_w, select_thr, nms_thr, nms_topk, det_scores, det_boxes, bad_per_image);
+  XDET_LAUNCH_CHECK();
+  return XDET_OK;
+}
+
 int launch_bboxes_eval(const float* cls, int ld_cls, const float* boxes, int N, int R, int num_classes,
                        const int* image_shapes, const float* bbox_img, int net_h, int net_w, float select_thr,
                        float nms_thr, int nms_topk, float* det_scores, float* det_boxes, hipStream_t s,
                        const int* bad_per_image) {
-  XDET_REQUIRE(R > 0 && R <= EV_MAXR, "bboxes_eval: 1 <= rois per image <= 1024");
-  XDET_REQUIRE(nms_topk > 0 && 2 * nms_topk <= EV_MAXS, "bboxes_eval: nms_topk must be in 1..256");
-  XDET_REQUIRE(num_classes >= 2 && num_classes <= ld_cls, "bboxes_eval: bad num_classes");
-  if (N == 0) return XDET_OK;
-  hipLaunchKernelGGL(bboxes_eval_kernel, dim3(num_classes - 1, N), dim3(EV_T), 0, s, cls, ld_cls, boxes, R,
-                     num_classes, image_shapes, bbox_img, net_h, net_w, select_thr, nms_thr, nms_topk, det_scores,
-                     det_boxes, bad_per_image);
-  XDET_LAUNCH_CHECK();
-  return XDET_OK;
+  return launch_bboxes_eval_any(false, cls, ld_cls, boxes, N, R, num_classes, image_shapes, bbox_img, net_h, net_w, select_thr,
+                                nms_thr, nms_topk, det_scores, det_boxes, s, bad_per_image);
+}
+
+int launch_bboxes_eval_probs(const float* probs, const float* boxes, int N, int R, int num_classes, const int* image_shapes,
+                             const float* bbox_img, int net_h, int net_w, float select_thr, float nms_thr, int nms_topk,
+                             float* det_scores, float* det_boxes, hipStream_t s, const int* bad_per_image) {
+  return launch_bboxes_eval_any(true, probs, 0, boxes, N, R, num_classes, image_shapes, bbox_img, net_h, net_w, select_thr,
+                                nms_thr, nms_topk, det_scores, det_boxes, s, bad_per_image);
 }
 
 }  // namespace xdet

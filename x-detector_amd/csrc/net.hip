@@ -1211,6 +1211,7 @@ struct LightHeadNet : Plan {
   bool built = false;
   Buf in4, mid_x, out, rpn_out, feat, pooled, fc, cls_reg;
   float *objectness = nullptr, *rpn_boxes = nullptr, *proposals = nullptr, *head_boxes = nullptr;
+  float* class_probs = nullptr;   // [B][num_classes][R] softmax of the head's logits, class-major (head_decode_probs_kernel)
   float *anc_yx = nullptr, *anc_hw = nullptr;
   float* mid_relu = nullptr;   // materialised ReLU(x) ("mid_outputs", xception_body.py:339) for API users
   void* prop_ws_mem = nullptr;
@@ -1646,6 +1647,7 @@ struct LightHeadNet : Plan {
     XDET_TRY(alloc_bytes((size_t)B * n_anchor * 16, reinterpret_cast<void**>(&rpn_boxes)));
     XDET_TRY(alloc_bytes((size_t)B * R * 16, reinterpret_cast<void**>(&proposals)));
     XDET_TRY(alloc_bytes((size_t)B * R * 16, reinterpret_cast<void**>(&head_boxes)));
+    XDET_TRY(alloc_bytes((size_t)B * cfg.num_classes * R * 4, reinterpret_cast<void**>(&class_probs)));
     XDET_TRY(alloc_bytes((size_t)B * mid_x.per_image() * 4, reinterpret_cast<void**>(&mid_relu)));
     XDET_TRY(alloc_bytes(proposal_workspace_bytes(B, n_anchor, cfg.rpn_pre_nms_top_n, R), &prop_ws_mem));
     proposal_workspace_carve(prop_ws_mem, B, n_anchor, cfg.rpn_pre_nms_top_n, R, &prop_ws);
@@ -1706,6 +1708,19 @@ struct LightHeadNet : Plan {
     return launch_ext_decode_rois(proposals, cls_reg.p + cfg.num_classes, cls_reg.ld,
                                   (int64_t)N * cfg.rpn_post_nms_top_n, head_boxes, s);
   }
+  // the whole forward: A11 and the softmax A12 starts from in one pass over the ROIs, then A12 from the probabilities
+  int head_decode_probs(int N, hipStream_t s) {
+    XDET_TRY(check(N));
+    return launch_head_decode_probs(proposals, cls_reg.p, cls_reg.ld, cfg.num_classes, cfg.rpn_post_nms_top_n,
+                                    (int64_t)N * cfg.rpn_post_nms_top_n, head_boxes, class_probs, prop_ws.bad, s);
+  }
+  int bboxes_eval_probs(int N, const int* shapes, const float* bbox, float* ds, float* db, hipStream_t s) {
+    XDET_TRY(check(N));
+    return launch_bboxes_eval_probs(class_probs, head_boxes, N, cfg.rpn_post_nms_top_n, cfg.num_classes,
+                                    shapes ? shapes : def_shapes, bbox ? bbox : def_bbox, cfg.image_size, cfg.image_size,
+                                    cfg.select_threshold, cfg.nms_threshold, cfg.nms_topk, ds, db, s, prop_ws.bad);
+  }
+  // the stage entry points (xdet_net_head_decode / xdet_net_bboxes_eval): each complete on its own, from "cls_reg" / "head_boxes"
   int bboxes_eval(int N, const int* shapes, const float* bbox, float* ds, float* db, hipStream_t s) {
     XDET_TRY(check(N));
     return launch_bboxes_eval(cls_reg.p, cls_reg.ld, head_boxes, N, cfg.rpn_post_nms_top_n, cfg.num_classes,
@@ -1764,7 +1779,7 @@ struct LightHeadNet : Plan {
       XDET_HIP(hipStreamWaitEvent(s, ev_join, 0));   // join before the head consumes the proposals
     }
     XDET_TRY(get_head(N, s));
-    XDET_TRY(head_decode(N, s));
+    XDET_TRY(head_decode_probs(N, s));
     if (check_range && net_precision != PREC_F32) {
       for (const auto& b : f32_bufs) {
         float limit;
@@ -1775,7 +1790,7 @@ struct LightHeadNet : Plan {
       for (const auto& b : planes_bufs) XDET_TRY(launch_range_check_planes(b.hi, N, b.pix_per_image, b.ld, prop_ws.bad, s));
       for (const auto& f : extra_range_checks) XDET_TRY(f(N, s));
     }
-    return bboxes_eval(N, shapes, bbox, ds, db, s);
+    return bboxes_eval_probs(N, shapes, bbox, ds, db, s);
   }
 };
 

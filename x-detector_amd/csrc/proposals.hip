@@ -606,17 +606,15 @@ int launch_get_proposals(const float* objectness, const float* boxes, int N, int
   hipLaunchKernelGGL(prop_compact_kernel, dim3(gb, N), dim3(256), 0, s, ws.keys, n_anchor, ws.tbin, ws.cand, ws.ranks,
                      ws.counts);
   XDET_LAUNCH_CHECK();
-  // The order of the (distinct) keys, two ways with the same result: a bitonic sort in LDS by ONE workgroup per image
-  // (the cheapest in CU time: what a batch wants, its images sort side by side) or rank counting spread over the chip
-  // (160 workgroups per image: what one or two images want -- the sort is ~70 us on one of 256 CUs, on the critical path
-  // of a single-image forward).  Lists beyond the sort's LDS capacity always take the counting path.
-  static const int small_n = getenv("XDET_PROP_RANK_N") ? atoi(getenv("XDET_PROP_RANK_N")) : 0;     // A/B knob: measured at one image, 1.302 ms against 1.296 with the sort -- the sort is not on the critical path -- so off
-  const int sort_max = N <= small_n ? 0 : SORT_MAX;
-  if (sort_max > 0) {
-    hipLaunchKernelGGL(prop_sort_kernel, dim3(N), dim3(1024), 0, s, ws.cand, ws.cboxes, n_anchor, pre_n, ws.counts,
-                       ws.sboxes, ws.sscores, sort_max);
-    XDET_LAUNCH_CHECK();
-  }
+  // The order of the (distinct) keys: a bitonic sort in LDS by ONE workgroup per image (the cheapest in CU time; the images of
+  // a batch sort side by side).  Lists beyond the sort's LDS capacity (many keys sharing the threshold bin) take the
+  // rank-counting pair below, which exits at once otherwise.  (Rank counting for every list of a single image, 160 workgroups
+  // instead of one, was measured twice -- 1.302 against 1.296 ms, 1.158 against 1.152 ms per image: the sort is not on the
+  // critical path of a single-image forward.)
+  const int sort_max = SORT_MAX;
+  hipLaunchKernelGGL(prop_sort_kernel, dim3(N), dim3(1024), 0, s, ws.cand, ws.cboxes, n_anchor, pre_n, ws.counts, ws.sboxes,
+                     ws.sscores, sort_max);
+  XDET_LAUNCH_CHECK();
   hipLaunchKernelGGL(prop_rank_kernel, dim3((unsigned)cdiv(n_anchor, 256 * RANK_IPT), RANK_SPLITS, N), dim3(256), 0, s,
                      ws.cand, n_anchor, ws.counts, ws.ranks, sort_max);
   XDET_LAUNCH_CHECK();
