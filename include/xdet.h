@@ -169,7 +169,7 @@ int xdet_conv3x3_patch_forward(void* layer, const uint16_t* in_hi, const uint16_
  * out = x + branch.  With out_hi / out_lo given, relu(out * next_scale + next_shift) -- the NEXT block's pre-activation --
  * is also written as planes (xdet_split_f32 layout) for a successor that runs layer by layer.  Bit-identical to
  * xdet_split_f32 + three xdet_conv_forward_planes calls.  Inside xdet_resnet_*: the identity blocks of stage 1
- * (environment XDET_RESNET_BNECK=0 at create time: three launches per block). */
+ * (xdet_resnet_set_option "bneck" = "off": three launches per block). */
 int xdet_resnet_bneck_forward(void* conv_a, void* conv_b, void* conv_c, const float* pre_scale, const float* pre_shift,
                               const float* x, int N, int H, int W, float* out, const float* next_scale,
                               const float* next_shift, uint16_t* out_hi, uint16_t* out_lo, void* stream);
@@ -253,7 +253,7 @@ int xdet_net_set_weight(void* net, const char* name, const float* data_host, int
  *   "ksplit" = "on" | "off" | "all": the 2048 -> 25 head GEMM (a single image: 3 tiles against 64 K steps) on the fixed
  *   split-K kernel (on, the default; a layer constant: results identical at every batch size), nothing (off), or the RPN
  *   3x3 conv as well (all: 32 tiles against 207 K steps; faster for one image, 0.9 % slower at bench-size batches).
- *   "workspace" = "reuse" | "ssa": see xdet_net_memory.
+ *   "workspace" = "reuse" | "ssa" | "poison": see xdet_net_memory.
  *   "pool_sub" = "on" | "off": the vertical pool pass of blocks 2-3 also writes the split planes of the raw subsampled sum (the
  *   next block's 1x1 / stride-2 projection reads those) and stores the sum as relu(sum) (its first separable conv reads that)
  *   -- on (default) -- or leaves both to their own passes (off; the same values either way).
@@ -306,9 +306,13 @@ int xdet_net_x8_planes(void* net, int* n_on);
 int xdet_net_graph_count(void* net, int* count);
 /* Device memory of the net's workspace and weights in bytes (everything the plan allocated), and how many bytes of
  * tensors were placed into blocks recycled from dead tensors (option "workspace" = "reuse", the default: a builder hands a
- * tensor's block back once its last consumer is planned and a later tensor of exactly the same size takes it over --
- * the middle flow's 24 x 2 tensors live in a handful of blocks; "ssa": one block per tensor, which option check_range
- * selects by itself because its validation pass reads every tensor after the forward). */
+ * tensor's block back once its last consumer is planned and a later tensor takes it over -- a planes tensor only a block
+ * of exactly its own size, an f32 tensor the best-fitting free block of at most twice its size (NOT re-zeroed: what lies
+ * behind the tensor, its 128-float loader slack included, is the predecessor's bytes; no consumer may use them, which
+ * "poison" proves) -- the middle flow's 24 x 2 tensors live in a handful of blocks; "ssa": one block per tensor, which
+ * option check_range selects by itself because its validation pass reads every tensor after the forward; "poison"
+ * (tests): "reuse", with everything behind a recycled f32 tensor filled with NaN bits in front of its producer on every
+ * forward -- the detections must still be those of "ssa", bit for bit). */
 int xdet_net_memory(void* net, size_t* allocated_bytes, size_t* recycled_bytes);
 /* per-kernel accounting of the last build: total dense FLOPs (2*MAC, unpadded) of one image */
 int xdet_net_flops_per_image(void* net, double* backbone, double* rpn, double* large_sep, double* head);
@@ -330,6 +334,15 @@ int xdet_profile_mfma_flops(void* net, int net_kind, int max_ops, int* n_ops, do
 /* ---- A13: ResNet-50 v2 trunk (net/resnet_v2.py:311-345), BASELINE config 2 --------------- */
 int xdet_resnet_create(void** net, int image_size, int max_batch);
 int xdet_resnet_set_weight(void* net, const char* name, const float* data_host, int ndim, const int64_t* dims);
+/* Before xdet_resnet_build; every key takes "on" (default) | "off".  The off forms are the layer-by-layer plans the fused
+ * kernels are tested against (tests/test_gpu_resnet_bneck.py: same bits, or f32 rounding for "projcat"):
+ *   "bneck"     stage 1's identity blocks as one kernel (csrc/resnet_bneck.hip) | three launches per block
+ *   "preconv"   a block's opening 1x1 conv makes its own pre-activation (csrc/resnet_preconv.hip) | a split pass + the conv
+ *   "projcat"   a projection block's shortcut folded into its closing GEMM as extra K | projection GEMM + add
+ *   "stem7"     the 7x7 / stride-2 stem conv from the NCHW image (csrc/resnet_stem.hip) | the implicit-GEMM kernel
+ *   "stem_pool" the stem's max-pool writes the first block's pre-activation planes | pool, then a split pass
+ *   "ksplit"    fixed split-K / one-range ring kernels for stages 2-4 at small batches | the plain kernels */
+int xdet_resnet_set_option(void* net, const char* key, const char* value);
 int xdet_resnet_build(void* net);
 int xdet_resnet_forward(void* net, const float* images_nchw, int N, float* out_nhwc, void* stream);
 /* the same forward as a replayed hipGraph (captured on the first call with a given (N, images, out) tuple; needs an

@@ -42,6 +42,20 @@ def test_library_has_gfx950_code_objects(built):
         assert kern in blob
 
 
+def test_environment_switches_are_only_the_documented_ones():
+    """The product library reads the environment for the collective library (three: RCCL path override, its permission,
+    the collective timeout) and for diagnosis (three: op trace, calibration log, the bottleneck kernel's intermediate
+    dump) -- never to choose a kernel: every selectable form is an xdet_net_set_option / xdet_resnet_set_option key
+    (include/xdet.h) that a test runs."""
+    csrc = os.path.join(ROOT, 'x-detector_amd', 'csrc')
+    found = set()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(('.hip', '.h')):
+            found |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(os.path.join(csrc, f)).read()))
+    assert found == {'XDET_RCCL_LIB', 'XDET_ALLOW_RCCL_OVERRIDE', 'XDET_COMM_TIMEOUT_S',
+                     'XDET_TRACE_OPS', 'XDET_CALIBRATE_VERBOSE', 'XDET_BNECK_DEBUG'}, found
+
+
 def test_config_struct_layout():
     from xdet._lib import LightHeadConfig
     c = LightHeadConfig()

@@ -191,4 +191,5 @@ def test_bench_through_the_rank_launcher(tmp_path):
     assert c['devices'][0]['pci_bus_id'] and c['per_rank_images_per_sec'][0] > 0
     assert c['gathered_shape'] == [16, 20, 200, 5] and c['gathered_images_with_detections'] == 16
     r = d['roofline']
-    assert 0 < r['frac_executed'] <= r['frac'] <= r['frac_cap'] and r['frac_direct_only'] > 0
+    assert 0 < r['frac_executed'] <= r['frac_algorithmic_credit'] and r['frac_direct_only'] > 0
+    assert 0 < r['backbone_frac'] < r['frac'] <= r['frac_cap']       # frac: the dominant kernel alone, executed FLOPs

@@ -413,15 +413,23 @@ def test_workspace_reuse_changes_memory_not_results(lh_weights):
         reuse = LightHeadDetector(lh_weights, image_size=480, max_batch=3, rpn_post_nms_top_n=300)
         ssa = LightHeadDetector(lh_weights, image_size=480, max_batch=3, rpn_post_nms_top_n=300, workspace='ssa')
         checked = LightHeadDetector(lh_weights, image_size=480, max_batch=3, rpn_post_nms_top_n=300, check_range=True)
+        # 'poison': reuse, with NaN bits behind every recycled f32 tensor (its loader slack and the rest of the larger block
+        # it took over) in front of its producer, on every forward: no consumer may use a byte from behind its tensor
+        poison = LightHeadDetector(lh_weights, image_size=480, max_batch=3, rpn_post_nms_top_n=300, workspace='poison')
     finally:
         set_precision('f32')
     a = reuse.forward(imgs, use_graph=True)
     b = ssa.forward(imgs)
     c = checked.forward(imgs)
+    d = poison.forward(imgs)
+    d2 = poison.forward(imgs, use_graph=True)
     for i in range(3):
         for k in range(1, 21):
             assert np.array_equal(a[i][k][0], b[i][k][0]) and np.array_equal(a[i][k][1], b[i][k][1]), (i, k)
             assert np.array_equal(a[i][k][0], c[i][k][0]) and np.array_equal(a[i][k][1], c[i][k][1]), (i, k)
+            assert np.array_equal(d[i][k][0], b[i][k][0]) and np.array_equal(d[i][k][1], b[i][k][1]), ('poison', i, k)
+            assert np.array_equal(d2[i][k][0], b[i][k][0]) and np.array_equal(d2[i][k][1], b[i][k][1]), ('poison graph', i, k)
+    assert poison.memory()['recycled_bytes'] == reuse.memory()['recycled_bytes']
     for name in ('mid_x', 'out', 'feat'):                 # the named buffers are never recycled
         assert np.array_equal(reuse.buffer(name, 3).numpy(), ssa.buffer(name, 3).numpy()), name
     mr, ms, mc = reuse.memory(), ssa.memory(), checked.memory()
@@ -435,6 +443,31 @@ def test_workspace_reuse_changes_memory_not_results(lh_weights):
     ns = ssa.calibrate(imgs)
     assert nr == ns
     assert reuse.plane_scales() == ssa.plane_scales()
+
+
+def test_repeated_forwards_below_max_batch(lh_weights):
+    """A net built for 6 images runs 2, 2, 5, 1 and 6: the proposal stage's per-image control words (histogram, bad flag,
+    the NMS cluster barrier's arrival counter and suppressed bits) are laid out for max_batch and must be cleared for the
+    images of THIS call on every forward -- a counter left over from the previous forward lets a cluster's workgroups run
+    through their barrier unsynchronised (round 6: seen as one missing detection at 800 x 800).  Every image's detections
+    equal those of a max_batch = 1 net, bit for bit, at every cluster size the batches select (16, 16, 16, 16, 16)."""
+    from xdet import weights as W
+    from xdet.model import LightHeadDetector
+    from xdet.runtime import set_precision
+    imgs = W.synthetic_images(6, 256, seed=606)
+    set_precision('f16x3')
+    try:
+        big = LightHeadDetector(lh_weights, image_size=256, max_batch=6, rpn_post_nms_top_n=300)
+        one = LightHeadDetector(lh_weights, image_size=256, max_batch=1, rpn_post_nms_top_n=300)
+    finally:
+        set_precision('f32')
+    ref = [one.forward(imgs[i:i + 1])[0] for i in range(6)]
+    for lo, hi, graph in ((0, 2, False), (2, 4, True), (0, 5, False), (3, 4, True), (0, 6, True), (4, 6, False), (5, 6, False)):
+        for rep in range(2):
+            got = big.forward(imgs[lo:hi], use_graph=graph)
+            for i in range(hi - lo):
+                for c in range(1, 21):
+                    assert np.array_equal(got[i][c][0], ref[lo + i][c][0]) and np.array_equal(got[i][c][1], ref[lo + i][c][1]), (lo, hi, rep, i, c)
 
 
 def test_pool_pass_that_writes_the_next_projections_input(lh_weights):

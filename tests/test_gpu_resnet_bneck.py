@@ -3,7 +3,6 @@
 same blocks: same products in the same order, so the trunk's output must be the same BITS -- on whole tiles (120 x 120
 and 60 x 60 maps: 480 x 480 input), on ragged ones (40 x 40 / 20 x 20: 160 x 160 input; 24 x 24: 96 x 96) and for a batch
 tail -- and, through tests/test_gpu_resnet.py, within 1e-4 of the oracle."""
-import os
 
 import numpy as np
 import pytest
@@ -14,20 +13,12 @@ pytestmark = pytest.mark.gpu
 def _trunk(w, size, max_batch, fused):
     from xdet.resnet import ResNet50Trunk
     from xdet.runtime import set_precision
-    keys = ('XDET_RESNET_BNECK', 'XDET_RESNET_STEM_POOL', 'XDET_RESNET_STEM7', 'XDET_RESNET_PRECONV')     # read by xdet_resnet_create
-    old = {k: os.environ.get(k) for k in keys}
-    for k in keys:
-        os.environ[k] = '1' if fused else '0'
+    opts = {k: 'on' if fused else 'off' for k in ('bneck', 'stem_pool', 'stem7', 'preconv')}     # xdet_resnet_set_option
     set_precision('f16x3')
     try:
-        return ResNet50Trunk(w, image_size=size, max_batch=max_batch)
+        return ResNet50Trunk(w, image_size=size, max_batch=max_batch, options=opts)
     finally:
         set_precision('f32')
-        for k in keys:
-            if old[k] is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = old[k]
 
 
 @pytest.mark.parametrize('size,batch,n', [(480, 2, 2), (160, 3, 3), (96, 4, 3), (224, 1, 1)])
@@ -51,7 +42,7 @@ def test_fused_blocks_are_bit_identical_to_three_launches(size, batch, n):
 
 @pytest.mark.parametrize('size,batch,n', [(480, 2, 2), (160, 3, 3), (96, 4, 3), (224, 1, 1)])
 def test_projection_folded_into_the_closing_conv(size, batch, n):
-    """XDET_RESNET_PROJCAT: a projection block's output as ONE contraction [3x3 output | block input] x [w_c ; w_proj]
+    """option "projcat": a projection block's output as ONE contraction [3x3 output | block input] x [w_c ; w_proj]
     (net/resnet_v2.py:160-184) against projection GEMM + closing GEMM + residual add.  One f32 accumulation instead of two
     roundings and an add: not the same bits, the same numbers to f32 rounding of a 4-block-deep difference (the oracle bar
     of tests/test_gpu_resnet.py is 1e-4 of the output's scale)."""
@@ -62,17 +53,11 @@ def test_projection_folded_into_the_closing_conv(size, batch, n):
     imgs = W.synthetic_images(n, size, seed=11 + size)
     outs = {}
     for flag in ('1', '0'):
-        old = os.environ.get('XDET_RESNET_PROJCAT')
-        os.environ['XDET_RESNET_PROJCAT'] = flag
         set_precision('f16x3')
         try:
-            t = ResNet50Trunk(w, image_size=size, max_batch=batch)
+            t = ResNet50Trunk(w, image_size=size, max_batch=batch, options={'projcat': 'on' if flag == '1' else 'off'})
         finally:
             set_precision('f32')
-            if old is None:
-                del os.environ['XDET_RESNET_PROJCAT']
-            else:
-                os.environ['XDET_RESNET_PROJCAT'] = old
         outs[flag] = t.forward(imgs)
         if flag == '1':
             t.set_images(imgs)

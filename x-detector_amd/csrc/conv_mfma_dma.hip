@@ -723,8 +723,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void conv_dma_deep_kernel(ConvParam
 
 // pointwise layers whose planes and weights stay below 4 GiB (32-bit buffer offsets) take the buffer-load form
 static bool pw_eligible(const ConvParams& p) {
-  static const bool off = getenv("XDET_CONV_PW") && !strcmp(getenv("XDET_CONV_PW"), "0");   // A/B runs
-  if (off || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad_t != 0 || p.pad_l != 0 || p.H != p.Ho || p.W != p.Wo) return false;
+  if (p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad_t != 0 || p.pad_l != 0 || p.H != p.Ho || p.W != p.Wo) return false;
   const size_t a_bytes = ((size_t)((p.M + 15) >> 4) * (size_t)(p.ldi >> 5)) << 10;
   const size_t b_bytes = (size_t)(p.Kp / 32) * p.Cout_pad * 64;
   return a_bytes < ((size_t)1 << 32) && b_bytes < ((size_t)1 << 32) && p.Cin_p == p.Kp;
@@ -734,11 +733,9 @@ template <int NSPLIT, bool PW = false, bool W8 = false, bool H64 = false>
 static int launch_deep(const ConvParams& p, hipStream_t s) {
   if (!PW && pw_eligible(p)) return launch_deep<NSPLIT, true, W8, H64>(p, s);
   if constexpr (!W8 && !H64 && NSPLIT == 3) {
-    // 128 x 64 tiles on at most half of the CUs: 64 x 64 tiles (XDET_CONV_DEEP_H64=0: off, A/B runs)
-    static const bool h64 = !(getenv("XDET_CONV_DEEP_H64") && !strcmp(getenv("XDET_CONV_DEEP_H64"), "0"));
-    if (h64 && !p.group_rows && cdiv(p.M, 128) * (p.Cout_pad / 64) <= 128) return launch_deep<NSPLIT, PW, false, true>(p, s);
-    static const bool w8 = !(getenv("XDET_CONV_DEEP_W8") && !strcmp(getenv("XDET_CONV_DEEP_W8"), "0"));   // A/B runs
-    if (w8) return launch_deep<NSPLIT, PW, true>(p, s);
+    // 128 x 64 tiles on at most half of the CUs: 64 x 64 tiles; else eight waves per workgroup
+    if (!p.group_rows && cdiv(p.M, 128) * (p.Cout_pad / 64) <= 128) return launch_deep<NSPLIT, PW, false, true>(p, s);
+    return launch_deep<NSPLIT, PW, true>(p, s);
   }
   constexpr int BM = H64 ? 64 : 128;
   constexpr size_t lds = (size_t)6 * (2 * BM + 2 * 64) * 32 * sizeof(u16);
@@ -756,10 +753,9 @@ static int launch_deep(const ConvParams& p, hipStream_t s) {
 }
 
 // multi-tap layers (the 256 x 256 tile's: the RPN conv, the direct large-separable convs) below 4 GiB: the generic form with
-// buffer loads (GBUF); XDET_CONV_GBUF=0: the pointer form, for A/B runs
+// buffer loads (GBUF); beyond 4 GiB: the pointer form
 static bool gbuf_eligible(const ConvParams& p) {
-  static const bool off = getenv("XDET_CONV_GBUF") && !strcmp(getenv("XDET_CONV_GBUF"), "0");
-  if (off || p.group_rows != 0) return false;
+  if (p.group_rows != 0) return false;
   const size_t a_bytes = ((((size_t)p.N * p.H * p.W + 15) >> 4) * (size_t)(p.ldi >> 5)) << 10;
   const size_t b_bytes = (size_t)(p.Kp / 32) * p.Cout_pad * 64;
   return a_bytes < ((size_t)1 << 32) && b_bytes < ((size_t)1 << 32) && p.Kp == p.Cin_p * p.KH * p.KW;
@@ -805,9 +801,8 @@ int launch_conv_mfma_dma_fold(const ConvParams& p, hipStream_t s) {
 }
 
 int launch_conv_mfma_dma(const ConvParams& p_in, int n_tile, int nsplit, hipStream_t s) {
-  static const bool no_skip = getenv("XDET_CONV_SKIP_DEAD") && !strcmp(getenv("XDET_CONV_SKIP_DEAD"), "0");   // A/B runs
   ConvParams p = p_in;
-  p.skip_dead = no_skip ? 0 : 1;
+  p.skip_dead = 1;
   XDET_REQUIRE(p.Kp % 32 == 0 && p.Cin_p % 32 == 0 && p.ldi >= p.Cin_p && p.ldi % 8 == 0,
                "conv(dma): channel counts must be padded to 32");
   XDET_REQUIRE(p.Cout_pad % n_tile == 0, "conv(dma): Cout_pad must be a multiple of the N tile");
@@ -819,29 +814,25 @@ int launch_conv_mfma_dma(const ConvParams& p_in, int n_tile, int nsplit, hipStre
     // wins as long as the grid still covers the 256 CUs (measured on MI355X, tools/conv_bench.py --planes):
     // 256x256 once there are >= 2 workgroups per CU, or ~1 per CU with a long K loop to amortise its
     // prologue/epilogue; 256x128 from ~2/3 workgroup per CU; else 128x128 (two workgroups share a CU).
-    const int64_t b256 = cdiv(p.M, 256) * (p.Cout_pad / 256), b128n = cdiv(p.M, 256) * (p.Cout_pad / 128);
+    const int64_t b256 = cdiv(p.M, 256) * (p.Cout_pad / 256);
     const int nk = p.Kp / 32;
     int tile = 0;
     // (round 5: the 256 x 128 tile lost every same-box A/B against 128 x 128 tiles at two workgroups per CU -- ResNet-50 trunk at
     //  batch 8 1.715 -> 1.683 ms, detector at batch 8 3.045 -> 2.860 ms, default bench neutral: its one-round grids run prologue,
-    //  K loop and a store-bound epilogue strictly in sequence on every CU.  XDET_CONV_T1_NK=<n>: use it for layers of >= n K steps)
-    static const int t1_nk = getenv("XDET_CONV_T1_NK") ? atoi(getenv("XDET_CONV_T1_NK")) : (1 << 30);
+    //  K loop and a store-bound epilogue strictly in sequence on every CU; retired)
     // ...or when the 256x256 grid fills whole rounds of the 256 CUs (within 6 %)
     const bool full_rounds = b256 >= 240 && (b256 % 256 == 0 || b256 % 256 >= 240);
     if (p.Cout_pad % 256 == 0 && (b256 >= 512 || full_rounds || (b256 >= 200 && nk >= 40))) tile = 2;
-    else if (b128n >= 170 && nk >= t1_nk) tile = 1;
     if (p.group_rows && p.group_rows % 256 != 0) tile = 0;      // a group must be whole M tiles
     if (tile == 2) return launch_d<256, 256, 2, 4, 3>(p, s);
-    if (tile == 1) return launch_d<256, 128, 4, 2, 3>(p, s);
   }
   if (n_tile == 128 && nsplit == 3 && !p.group_rows && !p.x8) {
     // about one round of 128 x 128 tiles with a long K loop (a single image's block4_sepconv2, the middle flow at batches 3-5):
     // the split-K kernel's four-stage ring with ONE range -- the same reduction, bit-identical -- runs a 32-deep step in ~0.65 us
     // where the two-stage kernel pays ~1.2 (the rule of Plan::maybe_ksplit for ResNet-50's stage 2, here per call: one range
-    // changes no summation tree, so the choice may depend on the batch).  XDET_CONV_ONE_RING=0: off (A/B runs)
-    static const bool one_ring = !(getenv("XDET_CONV_ONE_RING") && !strcmp(getenv("XDET_CONV_ONE_RING"), "0"));
+    // changes no summation tree, so the choice may depend on the batch)
     const int64_t b128 = cdiv(p.M, 128) * (p.Cout_pad / 128);
-    if (one_ring && b128 > 128 && b128 <= 256 && p.Kp / 32 >= 16 && p.Kp == p.Cin_p * p.KH * p.KW && p.ldi % 32 == 0 &&
+    if (b128 > 128 && b128 <= 256 && p.Kp / 32 >= 16 && p.Kp == p.Cin_p * p.KH * p.KW && p.ldi % 32 == 0 &&
         conv_ksplit_supported(p.KH, p.KW, (int64_t)p.N * p.H * p.W, p.ldi, p.Cin_p, p.Cout_pad)) {
       ConvParams q = p;
       q.ksplit = 1;
@@ -854,10 +845,8 @@ int launch_conv_mfma_dma(const ConvParams& p_in, int n_tile, int nsplit, hipStre
     // the N tile to double the workgroup count -- per-element K order is unchanged, so results stay bit-identical
     const int64_t b128 = cdiv(p.M, 128) * (p.Cout_pad / 128);
     if (nsplit == 3 && b128 <= 128 && (!p.group_rows || p.group_rows % 128 == 0)) {
-      // few workgroups: the deep operand ring (XDET_CONV_SMALL=2stage: the two-stage kernel, for A/B runs)
-      static const bool two_stage = getenv("XDET_CONV_SMALL") && !strcmp(getenv("XDET_CONV_SMALL"), "2stage");
-      // (x8 planes: the two-stage kernel -- the deep ring has no x8 form yet)
-      return two_stage || p.x8 ? launch_d<128, 64, 4, 1, 3>(p, s) : launch_deep<3>(p, s);
+      // few workgroups: the deep operand ring (x8 planes: the two-stage kernel -- the deep ring has no x8 form)
+      return p.x8 ? launch_d<128, 64, 4, 1, 3>(p, s) : launch_deep<3>(p, s);
     }
     return nsplit == 1 ? launch_d<128, 128, 2, 2, 1>(p, s) : launch_d<128, 128, 2, 2, 3>(p, s);
   }

@@ -396,9 +396,8 @@ static int launch_fold(const ConvParams& p, int64_t tiles, hipStream_t s) {
 template <int BN, int WAVES_M, int WAVES_N, int NSPLIT, bool PARALLEL, int NT>
 static int launch_ks(const ConvParams& p, hipStream_t s) {
   if constexpr (WAVES_M * WAVES_N == 4 && NSPLIT == 3) {
-    static const char* e = getenv("XDET_KSPLIT_W8");       // A/B runs: 0 = four waves everywhere, 128 = eight for the 128-wide tile only
-    const bool w8 = !(e && !strcmp(e, "0")) && (BN == 128 || !(e && !strcmp(e, "128")));
-    if (w8) return launch_ks<BN, BN == 128 ? 2 : 4, BN == 128 ? 4 : 2, NSPLIT, PARALLEL, NT>(p, s);
+    // the f16x3 form always runs eight waves per workgroup (two per SIMD: profiles/NOTES_r05.md 10)
+    return launch_ks<BN, BN == 128 ? 2 : 4, BN == 128 ? 4 : 2, NSPLIT, PARALLEL, NT>(p, s);
   }
   constexpr size_t lds = (size_t)4 * (2 * 128 + 2 * BN) * 32 * sizeof(u16);
   auto kern = conv_dma_ksplit_kernel<BN, WAVES_M, WAVES_N, NSPLIT, PARALLEL, NT>;
@@ -450,8 +449,7 @@ int launch_conv_mfma_ksplit(const ConvParams& p, int n_tile, int nsplit, int mod
   if (mode == 1) XDET_REQUIRE(!par || (p.ks_partial && tiles <= scratch_tiles), "conv(ksplit): scratch too small for the parallel mode");
   else par = par && p.ks_partial && tiles <= scratch_tiles;
   // large grids: the same fold inside the 256 x 128 LDS-DMA kernel (needs the zero page: the generic addressing)
-  static const bool no_big = getenv("XDET_KSPLIT_BIG") && !strcmp(getenv("XDET_KSPLIT_BIG"), "0");    // A/B runs
-  if (!par && mode == 0 && !no_big && p.zeros && conv_dma_fold_applicable(p, n_tile, nsplit)) return launch_conv_mfma_dma_fold(p, s);
+  if (!par && mode == 0 && p.zeros && conv_dma_fold_applicable(p, n_tile, nsplit)) return launch_conv_mfma_dma_fold(p, s);
   if (n_tile == 128) return nsplit == 3 ? launch_ks_modes<128, 2, 2, 3>(p, par, s) : launch_ks_modes<128, 2, 2, 1>(p, par, s);
   return nsplit == 3 ? launch_ks_modes<64, 4, 1, 3>(p, par, s) : launch_ks_modes<64, 4, 1, 1>(p, par, s);
 }

@@ -793,7 +793,9 @@ __global__ __launch_bounds__(256) void maxpool_v3s2_add_kernel(const float* __re
         *reinterpret_cast<uint2*>(sub_hi + po) = *reinterpret_cast<const uint2*>(h);
         *reinterpret_cast<uint2*>(sub_lo + po) = *reinterpret_cast<const uint2*>(l);
       }
-      m.x = fmaxf(m.x, 0.f); m.y = fmaxf(m.y, 0.f); m.z = fmaxf(m.z, 0.f); m.w = fmaxf(m.w, 0.f);
+      // (the NaN-keeping ReLU of the other kernels: fmaxf would turn a non-finite block output into 0 at the pixels that are
+      //  not subsampled and hide it from the range check)
+      m.x = !(m.x <= 0.f) ? m.x : 0.f; m.y = !(m.y <= 0.f) ? m.y : 0.f; m.z = !(m.z <= 0.f) ? m.z : 0.f; m.w = !(m.w <= 0.f) ? m.w : 0.f;
     }
     *reinterpret_cast<float4*>(out + o) = m;
   }

@@ -383,9 +383,14 @@ struct ConvLayer : LayerBase {
       }
       if (ksplit >= 1 && groups == 1) {
         // a split-K layer's summation tree is part of its definition: a batch whose planes leave the kernel's 4 GiB
-        // addressing is an error, not a silent change of kernel family (results must not depend on the batch)
-        XDET_REQUIRE(conv_ksplit_supported(kh, kw, (int64_t)N * H * W, ldi, cin_p, cout_pad),
-                     "conv(ksplit): this batch's planes exceed the split-K kernel's 4 GiB addressing; run it in smaller batches");
+        // addressing is an error, not a silent change of kernel family (results must not depend on the batch).  ONE range
+        // is the plain kernels' reduction (bit-identical): such a layer just runs on them.
+        if (!conv_ksplit_supported(kh, kw, (int64_t)N * H * W, ldi, cin_p, cout_pad)) {
+          if (ksplit == 1 && !ks_narrow) return launch_conv_mfma_dma(p, n_tile, precision == PREC_F16X3 ? 3 : 1, s);
+          XDET_REQUIRE(ksplit == 1, "conv(ksplit): this batch's planes or weights exceed the split-K kernel's 4 GiB addressing (or the "
+                                    "filter is not 1x1 / 3x3); a split reduction cannot change kernel family: run smaller batches");
+          return launch_conv_mfma_dma(p, 64, precision == PREC_F16X3 ? 3 : 1, s);
+        }
         p.ksplit = ksplit; p.ks_partial = d_ks_partial;
         return launch_conv_mfma_ksplit(p, cout_pad % 128 == 0 && !ks_narrow ? 128 : 64, precision == PREC_F16X3 ? 3 : 1, ks_mode, ks_tiles, s);
       }
@@ -486,6 +491,13 @@ struct Plan {
   // pool.  Named buffers of the graph-builder API (mid_x, out, feat, ...) are never released.  Option "workspace" = "reuse"
   // (default) | "ssa"; check_range needs every tensor intact after the forward and turns reuse off.
   bool reuse_workspace = true;
+  // "workspace" = "poison" (tests): as "reuse", and in front of the first op planned after a recycled f32 block was handed
+  // out, everything of that block BEYOND the new tensor (its loader slack and the rest of the larger predecessor) is filled
+  // with NaN bits on every forward -- if any consumer used a byte from behind its tensor, the detections would differ from
+  // the one-block-per-tensor net's (tests/test_gpu_e2e.py)
+  bool poison_recycled = false;
+  struct PoisonRec { size_t op; float* at; size_t words; };
+  std::vector<PoisonRec> poison;
   std::map<void*, size_t> ws_bytes;                      // blocks handed out by take() that are live
   std::multimap<size_t, void*> ws_free[2][2];            // released blocks by size, per stream pool and kind (f32 / planes)
   std::map<void*, int> ws_kind;
@@ -496,7 +508,7 @@ struct Plan {
   // are written by every producer).  Planes: a released planes block of EXACTLY the same size only -- the last 16-pixel
   // group of a planes tensor has pixel slots nobody writes, which the calibration's measurement and the GEMM's discarded
   // tail rows do read: they must hold what a tensor of the same shape left there (finite f16), not another tensor's bytes.
-  int take(size_t bytes, void** out, int kind = 0) {
+  int take(size_t bytes, void** out, int kind = 0, size_t slack_bytes = 0) {
     bytes = std::max<size_t>(bytes, 256);
     if (reuse_workspace) {
       auto& fl = ws_free[ws_pool][kind];
@@ -507,6 +519,9 @@ struct Plan {
         fl.erase(it);
         ws_bytes[*out] = block;                          // (released again under its own size)
         ws_recycled_bytes += bytes;
+        if (poison_recycled && kind == 0 && bytes > slack_bytes)
+          poison.push_back({ops.size(), reinterpret_cast<float*>(static_cast<char*>(*out) + (bytes - slack_bytes)),
+                            (block - (bytes - slack_bytes)) / 4});
         return XDET_OK;
       }
     }
@@ -529,7 +544,7 @@ struct Plan {
     b->no_f32 = false;                             // (a Buf that was copied from a planes-only tensor must not keep that flag)
     b->ld = C <= 4 ? 4 : round_up(C, 32);
     // +128 floats of slack: the conv loader may read a full 32-channel slice of the last pixel
-    XDET_TRY(take(((size_t)max_batch * b->per_image() + 128) * sizeof(float), reinterpret_cast<void**>(&b->p)));
+    XDET_TRY(take(((size_t)max_batch * b->per_image() + 128) * sizeof(float), reinterpret_cast<void**>(&b->p), 0, 128 * sizeof(float)));
     f32_bufs.emplace_back(b->p, b->per_image());
     return XDET_OK;
   }
@@ -799,14 +814,13 @@ struct Plan {
     if (!conv_ksplit_supported(L->kh, L->kw, (int64_t)max_batch * Hi * Wi, L->ld_in(), L->cin_p, L->cout_pad)) return XDET_OK;
     const int bn = L->cout_pad % 128 == 0 ? 128 : 64, nk = L->kp / 32;
     const int64_t tiles = conv_ksplit_tiles((int64_t)ksplit_design_batch * Ho * Wo, L->cout_pad, bn);
-    static const int max_s = getenv("XDET_KSPLIT_MAX") ? atoi(getenv("XDET_KSPLIT_MAX")) : 8;      // A/B knobs
-    static const int max_tiles = getenv("XDET_KSPLIT_TILES") ? atoi(getenv("XDET_KSPLIT_TILES")) : 128;
+    constexpr int max_s = 8, max_tiles = 128;     // at most 8 ranges; only layers of at most half a round of tiles are split
     // A layer of about one round of 128 x 128 tiles with a long K loop (ResNet-50 stage 2 at batch 8: the 3x3 convs and the
     // opening 1x1 convs, 225 tiles, 36 / 16 steps) is not short of workgroups but of pipeline: the two-stage kernels pay
     // ~1.2 us per 32-deep step there; the split-K kernel's four-stage ring (taps unrolled at compile time) runs the same
     // reduction with ONE range -- bit-identical to the plain kernels -- at ~0.65 us per step (trunk 1.99 -> 1.92 ms, same-box
-    // A/B; XDET_KSPLIT_ONE_TILES=0: off)
-    static const int one_tiles = getenv("XDET_KSPLIT_ONE_TILES") ? atoi(getenv("XDET_KSPLIT_ONE_TILES")) : 256;
+    // A/B)
+    constexpr int one_tiles = 256;
     if (bn == 128 && tiles > max_tiles && tiles <= one_tiles && nk >= 16) {
       XDET_TRY(L->enable_ksplit(1, 1));
       return XDET_OK;
@@ -817,8 +831,7 @@ struct Plan {
     // A pointwise layer that two ranges of 128-wide tiles only just spread over the chip (ResNet-50 stage 3's opening 1x1 at
     // batch 8: 114 tiles, 32 steps -> 228 workgroups + a fold launch) runs as ONE range of 128 x 64 tiles instead: the same
     // 228 workgroups, no scratch traffic, no second launch
-    static const bool narrow_on = !(getenv("XDET_KSPLIT_NARROW") && !strcmp(getenv("XDET_KSPLIT_NARROW"), "0"));
-    if (narrow_on && S == 2 && bn == 128 && L->kh == 1 && tiles * 2 <= 256 && nk <= 32) {
+    if (S == 2 && bn == 128 && L->kh == 1 && tiles * 2 <= 256 && nk <= 32) {
       XDET_TRY(L->enable_ksplit(1, 1));
       L->ks_narrow = true;
       return XDET_OK;
@@ -1159,6 +1172,8 @@ struct Plan {
     for (size_t i = 0; i < ops.size(); ++i) {
       const Op& op = ops[i];
       if (op.stage != stage) continue;
+      for (const PoisonRec& pr : poison)                 // (option "workspace" = "poison": tests only)
+        if (pr.op == i) XDET_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(pr.at), 0x7fc00000, pr.words, s));
       if (profiling) {
         ProfRec r;
         r.op = (int)i;
@@ -1174,9 +1189,17 @@ struct Plan {
       if (after_op) XDET_TRY(after_op((int)i, s));
       static const bool trace = getenv("XDET_TRACE_OPS") != nullptr;   // diagnosis: name the op a device fault belongs to
       if (trace) {
+        // (a synchronise on a capturing stream would invalidate the capture: a graph forward is only named, not waited for)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
         fprintf(stderr, "xdet op %zu: %s ...", i, op.name.c_str());
-        const hipError_t e = hipStreamSynchronize(s);
-        fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e));
+        fflush(stderr);
+        if (cap == hipStreamCaptureStatusNone) {
+          const hipError_t e = hipStreamSynchronize(s);
+          fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e));
+        } else {
+          fprintf(stderr, " (captured)\n");
+        }
       }
     }
     return XDET_OK;
@@ -1802,18 +1825,20 @@ struct ResNetTrunk : Plan {
   bool built = false;
   Buf in4, outb;
   double flops = 0;
-  bool ksplit_enabled = true;                      // XDET_RESNET_KSPLIT=0: the round-3 launch plan (A/B measurements)
-  bool stem7_enabled = true;                       // XDET_RESNET_STEM7=0: the stem conv on the generic small-cin kernel (A/B runs, tests)
+  bool ksplit_enabled = true;                      // xdet_resnet_set_option "ksplit" = off: the round-3 launch plan (A/B measurements)
+  bool stem7_enabled = true;                       // option "stem7" = off: the stem conv on the generic small-cin kernel (A/B runs, tests)
   bool stem7_direct = false;                       // decided at build: the stem op reads the NCHW images itself
   const float* cur_images = nullptr;               // (graphs are keyed on this pointer)
-  bool stem_pool_bn = true;                        // XDET_RESNET_STEM_POOL=0: pool and pre-activation as two passes (A/B runs, tests)
+  bool stem_pool_bn = true;                        // option "stem_pool" = off: pool and pre-activation as two passes (A/B runs, tests)
   bool bneck_enabled = true;                       // identity blocks the fused kernel supports run as one launch
-  bool bneck_fused_now = false;                    // set by a block's first op for its other two (ops run in order on one stream)
-  bool projcat_enabled = true;                     // XDET_RESNET_PROJCAT=0: projection shortcuts as their own GEMM + a residual add (A/B runs, tests)
+  // ONE decision per forward, made at the top of xdet_resnet_forward and read by every op: the fused kernels run (and the
+  // planes they keep on the CU are not written).  Part of the graph key.  A trunk instance serves one stream at a time.
+  bool bneck_fused_now = false;
+  bool projcat_enabled = true;                     // option "projcat" = off: projection shortcuts as their own GEMM + a residual add (A/B runs, tests)
   unsigned short *stem_cat_hi = nullptr, *stem_cat_lo = nullptr;   // second destination of the stem's pool + pre-activation pass
   float stem_cat_mul = 1.f;
   int stem_cat_c32 = 0, stem_cat_pidx = -1;        // (stage 1's projection block reads the block input inside a concatenated operand)
-  bool preconv_enabled = true;                     // XDET_RESNET_PRECONV=0: stage 2's opening 1x1 convs read planes (A/B runs, tests)
+  bool preconv_enabled = true;                     // option "preconv" = off: stage 2's opening 1x1 convs read planes (A/B runs, tests)
   struct PreconvLayers { ConvLayer *Lprev, *La; };  // a conv1x1 that makes its pre-activation from the raw input (resnet_preconv.hip)
   std::vector<PreconvLayers> preconv_layers;
   struct BneckGroup {
@@ -1825,7 +1850,7 @@ struct ResNetTrunk : Plan {
   std::vector<BneckGroup> bneck_groups;
   // one decision per forward (the answer cannot change inside one): no calibration pass is measuring, and no planes tensor a
   // fused kernel keeps on the CU carries an activation pre-scale
-  bool planes_dropped() const override { return (!bneck_groups.empty() || !preconv_layers.empty()) && bneck_all_ok(); }
+  bool planes_dropped() const override { return (!bneck_groups.empty() || !preconv_layers.empty()) && bneck_fused_now; }
   bool bneck_all_ok() const {
     if (after_op) return false;
     for (const BneckGroup& g : bneck_groups)
@@ -1835,7 +1860,7 @@ struct ResNetTrunk : Plan {
       if (g.Lprev->out_exp != 0 || g.La->in_exp != 0 || g.La->out_exp != 0) return false;
     return true;
   }
-  typedef std::array<uintptr_t, 3> Key;            // (N, images, out): every pointer a captured graph bakes in
+  typedef std::array<uintptr_t, 4> Key;            // (N, images, out, fused forms or not): everything a captured graph bakes in
   std::map<Key, hipGraphExec_t> graphs;
   std::vector<Key> graph_order;
   ~ResNetTrunk() {
@@ -2029,7 +2054,7 @@ int ResNetTrunk::build() {
         if (cat_s1 && stem_pre_fused) {               // the stem's pool + pre-activation pass writes the block input twice
           stem_cat_hi = cat.hi + off; stem_cat_lo = cat.lo + off; stem_cat_c32 = cat.ld >> 5; stem_cat_pidx = cat.pidx;
           stem_cat_mul = part_mul;
-        } else if (cat_s1) {                          // (two-pass stem, XDET_RESNET_STEM_POOL=0: a copy of the pre-activation planes)
+        } else if (cat_s1) {                          // (two-pass stem, option "stem_pool" = off: a copy of the pre-activation planes)
           const Buf i = pre, o = cat;
           ops.push_back({cproj + "/copy of the block input [into the closing conv's operand]", 0, 0.0, [=](int N, hipStream_t s_) {
                            return launch_planes_copy_blocks(i.hi, i.lo, o.hi + off, o.lo + off, (int64_t)N * i.H * i.W, i.ld, o.ld >> 5,
@@ -2076,7 +2101,7 @@ int ResNetTrunk::build() {
         const int cin = pre.C, cm = f;
         const auto run_a = ops[op_first].run;
         ops[op_first].run = [=](int N, hipStream_t st) {
-          if (!bneck_all_ok()) return run_a(N, st);
+          if (!bneck_fused_now) return run_a(N, st);
           return launch_resnet_preconv(xi.p, Lp->d_pl_scale, Lp->d_pl_shift, La->d_wt_hi_b, La->d_wt_lo_b, La->d_scale, La->d_shift,
                                        yo.hi, yo.lo, (int64_t)N * xi.H * xi.W, cin, cm, st);
         };
@@ -2152,7 +2177,6 @@ int ResNetTrunk::build() {
         prev_group = (int)gi;
         const auto run_a = ops[op_first].run, run_b = ops[op_first + 1].run, run_c = ops[op_first + 2].run;
         ops[op_first].run = [=](int N, hipStream_t st) {
-          bneck_fused_now = bneck_all_ok();
           if (!bneck_fused_now) return run_a(N, st);
           const BneckGroup& G = bneck_groups[gi];
           BneckLaunch l = G.a;
@@ -2513,9 +2537,10 @@ int xdet_net_set_option(void* net, const char* key, const char* value) {
     return XDET_OK;
   }
   if (k == "workspace") {
-    XDET_REQUIRE(v == "reuse" || v == "ssa", "workspace: reuse | ssa");
-    XDET_REQUIRE(!(v == "reuse" && n->check_range), "workspace=reuse: check_range validates every tensor after the forward and needs workspace=ssa");
-    n->reuse_workspace = v == "reuse";
+    XDET_REQUIRE(v == "reuse" || v == "ssa" || v == "poison", "workspace: reuse | ssa | poison");
+    XDET_REQUIRE(!(v != "ssa" && n->check_range), "workspace=reuse: check_range validates every tensor after the forward and needs workspace=ssa");
+    n->reuse_workspace = v != "ssa";
+    n->poison_recycled = v == "poison";
     return XDET_OK;
   }
   if (k == "sepconv") {
@@ -2793,12 +2818,6 @@ int xdet_resnet_create(void** net, int image_size, int max_batch) {
   r->plan_kind = 1;
   r->image_size = image_size;
   r->max_batch = max_batch;
-  if (const char* e = getenv("XDET_RESNET_KSPLIT")) r->ksplit_enabled = strcmp(e, "0") != 0;
-  if (const char* e = getenv("XDET_RESNET_STEM7")) r->stem7_enabled = strcmp(e, "0") != 0;
-  if (const char* e = getenv("XDET_RESNET_STEM_POOL")) r->stem_pool_bn = strcmp(e, "0") != 0;
-  if (const char* e = getenv("XDET_RESNET_BNECK")) r->bneck_enabled = strcmp(e, "0") != 0;
-  if (const char* e = getenv("XDET_RESNET_PROJCAT")) r->projcat_enabled = strcmp(e, "0") != 0;     // 0: projection shortcuts as their own GEMM (A/B runs, tests)
-  if (const char* e = getenv("XDET_RESNET_PRECONV")) r->preconv_enabled = strcmp(e, "0") != 0;     // 0: three launches per block (A/B runs, tests)
   XDET_HIP(hipGetDevice(&r->device));
   *net = r;
   return XDET_OK;
@@ -2806,6 +2825,26 @@ int xdet_resnet_create(void** net, int image_size, int max_batch) {
 int xdet_resnet_set_weight(void* net, const char* name, const float* data, int ndim, const int64_t* dims) {
   XDET_NET_KIND(net, 1, "resnet_set_weight");
   return set_weight(static_cast<ResNetTrunk*>(net), name, data, ndim, dims);
+}
+int xdet_resnet_set_option(void* net, const char* key, const char* value) {
+  XDET_NET_KIND(net, 1, "resnet_set_option");
+  ResNetTrunk* r = static_cast<ResNetTrunk*>(net);
+  XDET_REQUIRE(r && key && value, "resnet_set_option: NULL argument");
+  XDET_REQUIRE(!r->built, "resnet_set_option: the trunk is already built");
+  const std::string k(key), v(value);
+  XDET_REQUIRE(v == "on" || v == "off", "resnet_set_option: the value must be on | off");
+  const bool on = v == "on";
+  if (k == "ksplit") r->ksplit_enabled = on;
+  else if (k == "stem7") r->stem7_enabled = on;
+  else if (k == "stem_pool") r->stem_pool_bn = on;
+  else if (k == "bneck") r->bneck_enabled = on;
+  else if (k == "projcat") r->projcat_enabled = on;
+  else if (k == "preconv") r->preconv_enabled = on;
+  else {
+    set_last_error("unknown option: " + k);
+    return XDET_ERR_INVALID_ARG;
+  }
+  return XDET_OK;
 }
 int xdet_resnet_build(void* net) {
   XDET_NET_KIND(net, 1, "resnet_build");
@@ -2821,6 +2860,7 @@ int xdet_resnet_forward(void* net, const float* images, int N, float* out_nhwc, 
   DeviceGuard guard(r->device);
   hipStream_t s = S(stream);
   r->cur_images = images;
+  r->bneck_fused_now = r->bneck_all_ok();
   if (!r->stem7_direct) XDET_TRY(launch_nchw_to_nhwc4(images, r->in4.p, N, 3, r->image_size, r->image_size, 4, s));
   XDET_TRY(r->run_stage(0, N, s));
   if (out_nhwc)
@@ -2836,7 +2876,7 @@ int xdet_resnet_forward_graph(void* net, const float* images, int N, float* out_
   hipStream_t s = S(stream);
   XDET_REQUIRE(s != nullptr, "graph replay needs an explicit (non-default) stream");
   DeviceGuard guard(r->device);
-  const ResNetTrunk::Key key = {{(uintptr_t)N, (uintptr_t)images, (uintptr_t)out_nhwc}};
+  const ResNetTrunk::Key key = {{(uintptr_t)N, (uintptr_t)images, (uintptr_t)out_nhwc, (uintptr_t)r->bneck_all_ok()}};
   auto it = r->graphs.find(key);
   if (it == r->graphs.end()) {
     if (r->graphs.size() >= 8) {

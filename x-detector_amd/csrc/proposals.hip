@@ -158,13 +158,17 @@ __global__ void prop_prepare_kernel(const float* __restrict__ score, const float
 
 // one 1024-thread workgroup per image: lowest histogram bin still needed to cover pre_n keys
 // clears the key histogram and the (zero-padded) sorted box / score arrays of one forward
-__global__ void prop_zero_kernel(uint4* __restrict__ a, int64_t na, uint4* __restrict__ b, int64_t nb,
-                                 unsigned* __restrict__ c, int64_t nc) {
+struct ZeroRanges {
+  static constexpr int MAX = 6;
+  uint4* p[MAX];       // 16-byte aligned
+  int64_t n[MAX];      // in uint4 units
+};
+__global__ void prop_zero_kernel(ZeroRanges z) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-  for (int64_t i = t0; i < na; i += stride) a[i] = z;
-  for (int64_t i = t0; i < nb; i += stride) b[i] = z;
-  for (int64_t i = t0; i < nc; i += stride) c[i] = 0u;
+  const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+  for (int r = 0; r < ZeroRanges::MAX; ++r)
+    for (int64_t i = t0; i < z.n[r]; i += stride) z.p[r][i] = zero;
 }
 
 __global__ __launch_bounds__(1024) void prop_select_kernel(const int* __restrict__ hist, int pre_n,
@@ -593,9 +597,18 @@ int launch_get_proposals(const float* objectness, const float* boxes, int N, int
   XDET_REQUIRE(N > 0 && n_anchor > 0 && pre_n > 0 && post_n > 0, "get_proposals: sizes must be positive");
   // one launch instead of three hipMemsetAsync (which the runtime splits into ~12 fill kernels per forward)
   XDET_REQUIRE(nms_thr >= 0.f, "get_proposals: the NMS threshold must be >= 0");
-  hipLaunchKernelGGL(prop_zero_kernel, dim3(512), dim3(256), 0, s, reinterpret_cast<uint4*>(ws.hist),
-                     (int64_t)(prop_zeroed_words(N, pre_n) / 4), reinterpret_cast<uint4*>(ws.sboxes), (int64_t)N * pre_n,
-                     reinterpret_cast<unsigned*>(ws.sscores), (int64_t)N * pre_n);
+  {
+    // (the workspace may be carved for more images than this call runs: every per-image array is cleared for ITS first N images)
+    const int n_sup = (int)cdiv(pre_n, NMS_SUP_PANEL);
+    ZeroRanges z;
+    z.p[0] = reinterpret_cast<uint4*>(ws.hist);    z.n[0] = (int64_t)N * HIST_BINS / 4;
+    z.p[1] = reinterpret_cast<uint4*>(ws.bad);     z.n[1] = round_up(N, 4) / 4;
+    z.p[2] = reinterpret_cast<uint4*>(ws.nms_ctl); z.n[2] = N;
+    z.p[3] = reinterpret_cast<uint4*>(ws.nms_sup); z.n[3] = (int64_t)N * n_sup * 4;
+    z.p[4] = reinterpret_cast<uint4*>(ws.sboxes);  z.n[4] = (int64_t)N * pre_n;
+    z.p[5] = reinterpret_cast<uint4*>(ws.sscores); z.n[5] = cdiv((int64_t)N * pre_n, 4);   // (allocations are 256-byte multiples)
+    hipLaunchKernelGGL(prop_zero_kernel, dim3(512), dim3(256), 0, s, z);
+  }
   XDET_LAUNCH_CHECK();
   const unsigned gb = (unsigned)cdiv(n_anchor, 256);
   hipLaunchKernelGGL(prop_prepare_kernel, dim3(gb, N), dim3(256), 0, s, objectness, boxes, n_anchor, min_size,

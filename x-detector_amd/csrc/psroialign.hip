@@ -117,11 +117,23 @@ __global__ __launch_bounds__(256, 4) void psroialign_fwd_kernel(const float* __r
   // straight through, every XCD ended up sampling every image's feature map (7x the map bytes over the fabric).
   // Here image n belongs to XCD n & 7: that XCD's workgroups walk the image's ROI blocks back to back, so a map
   // (1.8 MB at 30x30x490) crosses the fabric once and every further sample of it is an L2 hit.
+  // Fewer than 8 images: an image's ROI blocks are dealt to P = 8 / N XCDs (the map is read P times over the fabric, and
+  // all 256 CUs work -- with one XCD per image a single image's 1000 ROIs ran on 32 CUs: 90 us on the critical path).
   const int bpi = (R + 3) >> 2;                        // workgroups (4 ROIs each) per image
-  const int slot = blockIdx.x >> 3;
-  const int64_t n = (int64_t)(slot / bpi) * 8 + (blockIdx.x & 7);
-  const int r_roi = (slot % bpi) * 4 + (threadIdx.x >> 6);
-  if (n >= N || r_roi >= R) return;
+  const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+  int64_t n;
+  int rblk;
+  if (N >= 8) {
+    n = (int64_t)(slot / bpi) * 8 + xcd;
+    rblk = slot % bpi;
+  } else {
+    const int P = 8 / N;
+    n = xcd % N;
+    rblk = slot * P + xcd / N;
+    if (xcd >= N * P) return;
+  }
+  const int r_roi = rblk * 4 + (threadIdx.x >> 6);
+  if (n >= N || rblk >= bpi || r_roi >= R) return;
   const int64_t nr = n * R + r_roi;
   const float* roi = rois + nr * 4;
   float r0 = roi[0], r1 = roi[1], r2 = roi[2], r3 = roi[3];
@@ -397,13 +409,12 @@ int launch_psroialign(const float* feat, const float* rois, float* pooled, int32
   // NCHW (the reference op's layout, light_head_rfcn_eval.py:85): neighbouring channels are H * W floats apart, so every
   // lane of a gather touches its own cache line (553 us for 64 x 300 ROIs of the mixed set against 120 us for the NHWC
   // form).  With enough ROIs it pays to transpose the map once into a stream-ordered scratch allocation and run the NHWC
-  // two-channel kernel on it: same values, same arithmetic.  (XDET_PSROI=direct_nchw, an odd bank, a stream that is being
+  // two-channel kernel on it: same values, same arithmetic.  (An odd bank, a stream that is being
   // captured -- an allocation there would become a graph node, and a failed runtime call would invalidate the capture --
   // or a failed allocation keep the direct form.)
-  static const bool direct_nchw = getenv("XDET_PSROI") && !strcmp(getenv("XDET_PSROI"), "direct_nchw");
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
-  if (layout == 0 && !direct_nchw && cap == hipStreamCaptureStatusNone && (C / (gw * gh)) % 2 == 0 && C % 2 == 0 &&
+  if (layout == 0 && cap == hipStreamCaptureStatusNone && (C / (gw * gh)) % 2 == 0 && C % 2 == 0 &&
       (int64_t)R * C >= (int64_t)4 * H * W) {
     float* scratch = nullptr;
     const size_t bytes = (size_t)N * H * W * C * sizeof(float);
@@ -419,13 +430,13 @@ int launch_psroialign(const float* feat, const float* rois, float* pooled, int32
     }
     (void)hipGetLastError();                             // no scratch: the direct form below
   }
-  const int64_t blocks = cdiv(N, 8) * 8 * cdiv(R, 4);   // image n on XCD n & 7 (see the kernel)
+  // image n on XCD n & 7; fewer than 8 images: each image on 8 / N XCDs (see the kernel)
+  const int64_t blocks = N >= 8 ? cdiv(N, 8) * 8 * cdiv(R, 4) : 8 * cdiv(cdiv(R, 4), 8 / N);
   // two channels per lane (8-byte corner loads) where the layout allows it: NHWC, even bank and channel stride,
-  // 8-byte aligned map; XDET_PSROI=element forces the one-channel form (A/B measurements)
-  static const bool force1 = getenv("XDET_PSROI") && !strcmp(getenv("XDET_PSROI"), "element");
-  static const int dedup = !(getenv("XDET_PSROI") && !strcmp(getenv("XDET_PSROI"), "nogrid"));
+  // 8-byte aligned map
+  constexpr int dedup = 1;                               // the two-channel form always reads through its LDS corner grid
   const int bank = C / (gw * gh);
-  const bool two = !force1 && layout == 1 && bank % 2 == 0 && ldc % 2 == 0 && reinterpret_cast<uintptr_t>(feat) % 8 == 0;
+  const bool two = layout == 1 && bank % 2 == 0 && ldc % 2 == 0 && reinterpret_cast<uintptr_t>(feat) % 8 == 0;
   const int cs = layout == 0 ? C : ldc;
 #define XDET_PSROI_LAUNCH(V, M)                                                                                        \
   hipLaunchKernelGGL((psroialign_fwd_kernel<V, M>), dim3((unsigned)blocks), dim3(256), 0, s, feat, rois, pooled, index, N, C, \

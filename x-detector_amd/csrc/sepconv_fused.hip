@@ -630,9 +630,8 @@ int launch_sepconv_fused(const float* in, const float* w9c, const unsigned short
     p.out = out + (size_t)nb * H * (pool_pad_l >= 0 ? (W + 1) / 2 : W) * ldo;
     p.N = n; p.H = H; p.W = W; p.ld = ld; p.ldo = ldo; p.Cout_pad = cout_pad; p.relu_in = relu_in; p.relu_out = relu_out;
     const bool hpool = pool_pad_l >= 0;
-    // 256 output channels: one pass of the 1 x 4 wave layout (XDET_SEPCONV_TWO_PASS=1: two 128-wide passes, for A/B runs)
-    static const bool two_pass = getenv("XDET_SEPCONV_TWO_PASS") != nullptr;
-    const bool wide = cout_pad % 256 == 0 && !two_pass;
+    // 256 output channels: one pass of the 1 x 4 wave layout
+    const bool wide = cout_pad % 256 == 0;
     p.Wo = (W + 1) / 2; p.pool_pad_l = hpool ? pool_pad_l : 0;
 #if SF_PROBE_LEVEL == 9
     p.dbg = g_probe_dbg;

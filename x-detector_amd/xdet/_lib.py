@@ -132,6 +132,7 @@ SIGNATURES = {
     'xdet_profile_op_name': (c_int, [c_void_p, c_int, c_int, ctypes.c_char_p, c_int]),
     'xdet_resnet_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int]),
     'xdet_resnet_set_weight': (c_int, [c_void_p, ctypes.c_char_p, PF, c_int, ctypes.POINTER(c_int64)]),
+    'xdet_resnet_set_option': (c_int, [c_void_p, ctypes.c_char_p, ctypes.c_char_p]),
     'xdet_resnet_build': (c_int, [c_void_p]),
     'xdet_resnet_forward': (c_int, [c_void_p, PF, c_int, PF, c_void_p]),
     'xdet_resnet_forward_graph': (c_int, [c_void_p, PF, c_int, PF, c_void_p]),

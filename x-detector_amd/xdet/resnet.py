@@ -9,10 +9,13 @@ from .runtime import DeviceBuffer, Stream, to_host, _host
 
 
 class ResNet50Trunk(object):
-    def __init__(self, weights, image_size=480, max_batch=8):
+    def __init__(self, weights, image_size=480, max_batch=8, options=None):
+        """options: {key: 'on' | 'off'} for xdet_resnet_set_option (include/xdet.h), e.g. {'bneck': 'off'}"""
         h = c_void_p()
         check(lib().xdet_resnet_create(ctypes.byref(h), image_size, max_batch))
         self.handle = h
+        for k, v in (options or {}).items():
+            check(lib().xdet_resnet_set_option(self.handle, k.encode(), v.encode()))
         for name, arr in weights.items():
             a = np.ascontiguousarray(arr, np.float32)
             dims = (ctypes.c_int64 * a.ndim)(*a.shape)
