@@ -1,0 +1,7 @@
+python -m pytest tests/test_gpu_e2e.py tests/test_gpu_fullsize.py -x -q -m gpu 2>&1 | tail -3
+b() { python bench.py $2 --no-cpu-baseline --no-parity --no-roofline --sustain-seconds 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['ms_per_step'], d['median_ms_per_step'])"; }
+b "b1 R1000" "--batch 1 --proposals 1000 --steps 200 --warmup 20"
+b "b1 R300" "--batch 1 --steps 200 --warmup 20"
+b "b2 R300" "--batch 2 --steps 200 --warmup 20"
+b "b3 R300" "--batch 3 --steps 200 --warmup 20"
+b "b8 R300" "--batch 8 --steps 100 --warmup 10"

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_f16_kernel(Co
     const int g = (slot / tpg) * 8 + (blockIdx.x & 7);
     const int w = slot - (slot / tpg) * tpg;
     if ((int64_t)g * p_in.group_rows >= p_in.M) return;
+    if (p_in.group_live_rows && (w / nby) * BM >= p_in.group_live_rows) return;     // a tile of padding rows only
     bx = g * mt + w / nby;
     n0 = (w % nby) * BN;
     p.wt_hi = p_in.wt_hi + (size_t)g * p_in.group_wt_stride;
@@ -525,6 +526,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void conv_dma_deep_kernel(ConvParam
     const int g = (slot / tpg) * 8 + (blockIdx.x & 7);
     const int w = slot - (slot / tpg) * tpg;
     if ((int64_t)g * p_in.group_rows >= p_in.M) return;
+    if (p_in.group_live_rows && (w / nby) * BM >= p_in.group_live_rows) return;     // a tile of padding rows only
     bx = g * mt + w / nby;
     n0 = (w % nby) * BN;
     p.wt_hi = p_in.wt_hi + (size_t)g * p_in.group_wt_stride;
@@ -839,6 +841,14 @@ int launch_conv_mfma_dma(const ConvParams& p_in, int n_tile, int nsplit, hipStre
       q.ks_partial = nullptr;
       return launch_conv_mfma_ksplit(q, 128, 3, 2, 0, s);
     }
+  }
+  if (n_tile == 128 && nsplit == 3 && p.group_rows && p.group_rows % 64 == 0 && !p.x8) {
+    // A grouped GEMM with few live rows per group (the frequency bins of a single image: 30 rows of a 128-row tile, 44 bins x
+    // 4 column tiles = 176 workgroups walking 128 K steps at ~1 us each on the two-stage kernel): 64 x 64 tiles on the
+    // six-stage ring -- twice the workgroups, half the padding rows, ~0.5 us per step.  Same K order per element: same bits.
+    const int live = p.group_live_rows ? p.group_live_rows : p.group_rows;
+    const int64_t groups = p.M / p.group_rows, wgs = groups * cdiv(live, 64) * (p.Cout_pad / 64);
+    if (live <= 64 && wgs <= 768) return launch_deep<3, false, false, true>(p, s);
   }
   if (n_tile == 128) {
     // small batches: 128 x 128 tiles leave most of the 256 CUs idle (a 900-row layer is 8 x 4..6 workgroups); halve

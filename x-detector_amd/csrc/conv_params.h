@@ -44,6 +44,9 @@ struct ConvParams {
   // and scale/shift row g (+ g*Cout_pad).  group_rows is a multiple of every M tile; 0 = one group.
   int group_rows;
   long long group_wt_stride;
+  // rows [group_live_rows, group_rows) of every group are padding whose results nobody reads (a bin holds N * F real rows, padded
+  // to whole M tiles): an M tile that lies wholly in them is not computed.  0 = every row is live.
+  int group_live_rows = 0;
   // fixed split of the reduction (conv_mfma_ksplit.hip only): the K steps are cut into `ksplit` equal ranges and the
   // result is the left fold of the per-range sums; ks_partial = scratch slabs [tiles][ksplit][128 x N tile] f32 of
   // the mode that runs the ranges in parallel

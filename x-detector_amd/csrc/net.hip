@@ -351,7 +351,7 @@ struct ConvLayer : LayerBase {
               hipStream_t s, const unsigned short* in_hi = nullptr, const unsigned short* in_lo = nullptr,
               const unsigned short* zeros = nullptr, unsigned short* out_hi = nullptr,
               unsigned short* out_lo = nullptr, int planes_relu = 0, const float* pl_scale = nullptr,
-              const float* pl_shift = nullptr, int group_rows = 0, int x8 = 0, int x8_exp = 0) const {
+              const float* pl_shift = nullptr, int group_rows = 0, int x8 = 0, int x8_exp = 0, int group_live_rows = 0) const {
     XDET_REQUIRE(ldi == ld_in(), "conv: ld_in must be round_up(cin,32) (4 for cin<=4)");
     XDET_REQUIRE(ldo == ld_out(), "conv: ld_out must be round_up(cout,32)");
     ConvParams p;
@@ -372,6 +372,7 @@ struct ConvLayer : LayerBase {
                    "conv(grouped): M must be groups * group_rows, group_rows a multiple of 128, input as planes");
       p.group_rows = group_rows;
       p.group_wt_stride = (long long)cout_pad * kp;
+      p.group_live_rows = group_live_rows;
     }
     if (precision == PREC_F32) return launch_conv_mfma_f32(p, small_cin, n_tile, s);
     if (in_hi) {   // A operand already split into f16 planes by its producer: LDS-DMA kernel
@@ -1579,7 +1580,7 @@ struct LightHeadNet : Plan {
                    }});
     ops.push_back({pre + "conv2d [spectral]", ST_LSEP, fl_a, [=](int N, hipStream_t s) {
                      return LA->forward(nullptr, 1, 1, NB * mpad(N), 2 * cin_ld, y1, 2 * mid2, nullptr, 0, s, xa_hi, xa_lo,
-                                        LA->d_zeros, nullptr, nullptr, 0, nullptr, nullptr, mpad(N));
+                                        LA->d_zeros, nullptr, nullptr, 0, nullptr, nullptr, mpad(N), 0, 0, N * F);
                    }});
     ops.back().mfma_flops = 2.0 * nsplit_of(LA) * NB * (double)F * (2.0 * cin_ld) * (2.0 * mid2);
     ops.push_back({pre + "conv2d/idft_y+bias", ST_LSEP, -1.0, [=](int N, hipStream_t s) {
@@ -1590,7 +1591,7 @@ struct LightHeadNet : Plan {
                    }});
     ops.push_back({pre + "conv2d_1 [spectral]", ST_LSEP, fl_b, [=](int N, hipStream_t s) {
                      return LB->forward(nullptr, 1, 1, NB * mpad(N), 2 * mid2, y2, 2 * co_ld, nullptr, 0, s, xb_hi, xb_lo,
-                                        LB->d_zeros, nullptr, nullptr, 0, nullptr, nullptr, mpad(N));
+                                        LB->d_zeros, nullptr, nullptr, 0, nullptr, nullptr, mpad(N), 0, 0, N * F);
                    }});
     ops.back().mfma_flops = 2.0 * nsplit_of(LB) * NB * (double)F * (2.0 * mid2) * (2.0 * co_ld);
     ops.push_back({pre + "conv2d_1/idft_x+bn+relu", ST_LSEP, -1.0, [=](int N, hipStream_t s) {
@@ -1793,12 +1794,16 @@ struct LightHeadNet : Plan {
       }
       XDET_HIP(hipEventRecord(ev_fork, s));
       XDET_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+      // The longer branch (exit flow + large-separable convs: the critical path of a single image) is issued FIRST.  In a
+      // captured graph the branch whose nodes were created first continues on the queue of the fork node; the other one
+      // starts behind a cross-queue signal -- and when the RPN branch was issued first, the replayed exit flow started only
+      // when the RPN 3x3 conv had FINISHED (76 us at one image; rocprofv3 kernel trace of round 6, 29 of 29 steps).
+      XDET_TRY(run_stage(ST_EXIT, N, s));
+      XDET_TRY(run_stage(ST_LSEP, N, s));
       XDET_TRY(run_stage(ST_RPN, N, aux));
       XDET_TRY(rpn_decode(N, aux));
       XDET_TRY(get_proposals(N, aux));
       XDET_HIP(hipEventRecord(ev_join, aux));
-      XDET_TRY(run_stage(ST_EXIT, N, s));
-      XDET_TRY(run_stage(ST_LSEP, N, s));
       XDET_HIP(hipStreamWaitEvent(s, ev_join, 0));   // join before the head consumes the proposals
     }
     XDET_TRY(get_head(N, s));

@@ -622,8 +622,8 @@ int launch_get_proposals(const float* objectness, const float* boxes, int N, int
   // The order of the (distinct) keys: a bitonic sort in LDS by ONE workgroup per image (the cheapest in CU time; the images of
   // a batch sort side by side).  Lists beyond the sort's LDS capacity (many keys sharing the threshold bin) take the
   // rank-counting pair below, which exits at once otherwise.  (Rank counting for every list of a single image, 160 workgroups
-  // instead of one, was measured twice -- 1.302 against 1.296 ms, 1.158 against 1.152 ms per image: the sort is not on the
-  // critical path of a single-image forward.)
+  // instead of one, was measured three times -- 1.302 against 1.296 ms, 1.158 against 1.152, 1.030 against 1.016 ms per image:
+  // no gain.)
   const int sort_max = SORT_MAX;
   hipLaunchKernelGGL(prop_sort_kernel, dim3(N), dim3(1024), 0, s, ws.cand, ws.cboxes, n_anchor, pre_n, ws.counts, ws.sboxes,
                      ws.sscores, sort_max);
