@@ -7,8 +7,9 @@
 #     (e.g. tools/ab.sh "--ways 1" "--ways 2";  tools/ab.sh "--pool-sub on" "--pool-sub off" --batch 8).
 set -u
 REPS=2; OTHER=""
-while getopts "r:l:" o; do case $o in r) REPS=$OPTARG;; l) OTHER=$(realpath $OPTARG);; esac; done
-shift $((OPTIND - 1))
+while [ $# -gt 2 ]; do
+  case $1 in -r) REPS=$2; shift 2;; -l) OTHER=$(realpath $2); shift 2;; *) break;; esac
+done
 A=$1; B=$2; shift 2
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for rep in $(seq $REPS); do

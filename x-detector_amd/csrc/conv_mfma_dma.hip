@@ -848,6 +848,7 @@ int launch_conv_mfma_dma(const ConvParams& p_in, int n_tile, int nsplit, hipStre
     // six-stage ring -- twice the workgroups, half the padding rows, ~0.5 us per step.  Same K order per element: same bits.
     const int live = p.group_live_rows ? p.group_live_rows : p.group_rows;
     const int64_t groups = p.M / p.group_rows, wgs = groups * cdiv(live, 64) * (p.Cout_pad / 64);
+    // (measured and dropped: a two-pair ring, 64 KB, two workgroups per CU so that the 352 tiles are one round -- 101 -> 106 us)
     if (live <= 64 && wgs <= 768) return launch_deep<3, false, false, true>(p, s);
   }
   if (n_tile == 128) {

@@ -65,13 +65,30 @@ __global__ void head_decode_probs_kernel(const float* __restrict__ rois, const f
     const float pcx = p[1] * wref + xref;
     *reinterpret_cast<float4*>(out + i * 4) =
         make_float4(pcy - ph / 2.f, pcx - pw / 2.f, pcy + ph / 2.f, pcx + pw / 2.f);
-    float m, sum;
-    bool isbad;
-    class_probs_begin(lg, num_classes, &m, &sum, &isbad);
     const int64_t img = i / R;
     const int ri = (int)(i - img * R);
-    for (int k = 0; k < num_classes; ++k) probs[(img * num_classes + k) * R + ri] = expf(lg[k] - m) / sum;
-    if (isbad) bad[img] = 1;
+    if (num_classes <= 32) {
+      // the exponentials once, in registers (class_probs_begin's values in class_probs_begin's order: the same bits)
+      float e[32];
+      float m = lg[0], lsum = lg[0];
+#pragma unroll
+      for (int k = 1; k < 32; ++k)
+        if (k < num_classes) { m = fmaxf(m, lg[k]); lsum += lg[k]; }
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        if (k < num_classes) { e[k] = expf(lg[k] - m); sum += e[k]; }
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        if (k < num_classes) probs[(img * num_classes + k) * R + ri] = e[k] / sum;
+      if (!(fabsf(lsum) <= FLT_MAX)) bad[img] = 1;
+    } else {
+      float m, sum;
+      bool isbad;
+      class_probs_begin(lg, num_classes, &m, &sum, &isbad);
+      for (int k = 0; k < num_classes; ++k) probs[(img * num_classes + k) * R + ri] = expf(lg[k] - m) / sum;
+      if (isbad) bad[img] = 1;
+    }
   }
 }
 

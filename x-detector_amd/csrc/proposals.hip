@@ -173,16 +173,23 @@ __global__ void prop_zero_kernel(ZeroRanges z) {
 
 __global__ __launch_bounds__(1024) void prop_select_kernel(const int* __restrict__ hist, int pre_n,
                                                            int* __restrict__ tbin, int* __restrict__ counts) {
-  __shared__ int part[1024];
-  const int n = blockIdx.x, t = threadIdx.x;
+  __shared__ int wsum[16];
+  const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int* h = hist + n * HIST_BINS;
   constexpr int PER = HIST_BINS / 1024;
   int s = 0;
   for (int b = 0; b < PER; ++b) s += h[t * PER + b];
-  part[t] = s;
+  // keys in bins owned by threads > t: a suffix sum over the 1024 threads (inside the wave by shuffles, then over the 16 waves)
+  int suf = s;                                     // inclusive suffix sum inside the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_down(suf, d);
+    if (lane + d < 64) suf += o;
+  }
+  if (lane == 0) wsum[wave] = suf;
   __syncthreads();
-  int above = 0;                                   // keys in bins owned by threads > t
-  for (int u = t + 1; u < 1024; ++u) above += part[u];
+  int above = suf - s;
+  for (int w = wave + 1; w < 16; ++w) above += wsum[w];
   if (t == 0) {
     const int n_valid = above + s;
     counts[n * 4 + 0] = n_valid;
