@@ -308,8 +308,9 @@ def counters_from_profiles(precision, sub_batch):
             d = json.load(open(path))
         except Exception:
             continue
-        if '--ways 1 --batch %d ' % sub_batch not in (d.get('command') or '') + ' ':
-            continue
+        cmd = (d.get('command') or '') + ' '
+        if '--ways 1 --batch %d ' % sub_batch not in cmd or any(k in cmd for k in ('--proposals', '--image-size', '--workload')):
+            continue                                  # (only the default configuration's summary: 300 proposals, 480 x 480)
         then = d.get('source_hashes')
         if not then or any(then.get(f) != now.get(f) for f in CONV_KERNEL_FILES):
             continue

@@ -16,9 +16,17 @@ python bench.py --no-cpu-baseline --no-parity --comm --voc-stream > $O/profiles/
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_b1 -- python $GRAFT_REPO_ROOT/bench.py --batch 1 --serial-rpn --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-parity --sustain-seconds 0 > $O/${TAG}_b1.log 2>&1)
 cp "$(find $O/${TAG}_b1 -name '*kernel_stats.csv' | head -1)" $O/profiles/${TAG}_batch1_kernel_stats.csv
 python tools/trace_step.py $O/${TAG}_b1 2 > $O/profiles/${TAG}_batch1_step_dispatches.txt
-# the reference's operating point: 1000 proposals, one stream of 128 images -- kernel stats (the head and PsRoiAlign grow 3.3x)
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_R1000 -- python $GRAFT_REPO_ROOT/bench.py --proposals 1000 --ways 1 --batch 128 --serial-rpn --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-parity --sustain-seconds 0 > $O/${TAG}_R1000.log 2>&1)
-cp "$(find $O/${TAG}_R1000 -name '*kernel_stats.csv' | head -1)" $O/profiles/${TAG}_R1000_kernel_stats.csv
+# the reference's operating point (rpn_post_nms_top_n = 1000, light_head_rfcn_eval.py:109-111): one stream of 128 images --
+# kernel stats + PMC summary (the head and PsRoiAlign grow 3.3x) -- and the single image: kernel stats + one step's dispatch list
+bash tools/collect_profile.sh ${TAG}_R1000 --proposals 1000 --ways 1 --batch 128 > /dev/null 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_R1000_b1 -- python $GRAFT_REPO_ROOT/bench.py --proposals 1000 --batch 1 --serial-rpn --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-parity --sustain-seconds 0 > $O/${TAG}_R1000_b1.log 2>&1)
+cp "$(find $O/${TAG}_R1000_b1 -name '*kernel_stats.csv' | head -1)" $O/profiles/${TAG}_R1000_batch1_kernel_stats.csv
+python tools/trace_step.py $O/${TAG}_R1000_b1 2 > $O/profiles/${TAG}_R1000_batch1_step_dispatches.txt
+# the single image as it runs (RPN branch on its side stream, graph replay): one step's dispatches with their queues
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_b1c -- python $GRAFT_REPO_ROOT/bench.py --batch 1 --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-parity --sustain-seconds 0 > $O/${TAG}_b1c.log 2>&1)
+python tools/trace_step.py $O/${TAG}_b1c 2 > $O/profiles/${TAG}_batch1_two_streams_step_dispatches.txt
+# the proposal stage alone: exactness at every cluster size + time per call on overlap-heavy / spread inputs
+python tools/nms_bench.py > $O/profiles/${TAG}_nms_bench.txt 2>&1
 # BASELINE config 2 and config 5's shape: stats + PMC summaries, as the default configuration's
 bash tools/collect_profile.sh ${TAG}_resnet_b8 --workload resnet50 --batch 8 --resnet-ways 1 > /dev/null 2>&1
 (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_rn -- python $GRAFT_REPO_ROOT/bench.py --workload resnet50 --batch 8 --resnet-ways 1 --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --sustain-seconds 0 > $O/${TAG}_rn.log 2>&1)

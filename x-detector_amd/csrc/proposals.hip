@@ -430,16 +430,16 @@ __device__ __forceinline__ u64 nms_pair_bits(const float4* __restrict__ ref, con
   return bits;
 }
 
-// Barrier of the G workgroups of one cluster: everything the cluster's workgroups stored before it is visible to every one
-// of them after it (cdna_hip_programming.md Guideline 16: stores drained by every wave, one agent-scope release, a relaxed
-// arrival on a monotonic counter, ONE relaxed poller, one agent-scope acquire, then the workgroup barrier).
+// Barrier of the G workgroups of one cluster.  Everything the cluster exchanges is written with agent-scope (write-through,
+// `sc1`) stores / atomics and read back with agent-scope loads, so the barrier needs no fences (cdna_hip_programming.md
+// Guideline 16, form R1: every storing wave drains its stores, ONE lane arrives on a monotonic counter and polls it relaxed):
+// a release fence would write back every dirty line of the XCD's L2 -- the large-separable convs of the main stream are
+// filling it while this runs -- and an acquire fence would drop the CU's L1 under a co-resident kernel.
 // Returns false when the poll gave up (the other workgroups of the cluster never arrived).
 __device__ __forceinline__ bool nms_cluster_barrier(unsigned* ctl, unsigned target, int* s_fail) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned spins = 0;
     while (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -450,7 +450,6 @@ __device__ __forceinline__ bool nms_cluster_barrier(unsigned* ctl, unsigned targ
         break;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
   return *s_fail == 0;
@@ -512,7 +511,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_panel_kernel(const float* __r
         const int I = v - J * (J + 1) / 2;
         u64 bits = nms_pair_bits(cb + I * 64, ca + I * 64, 64, cb[J * 64 + lane], ca[J * 64 + lane], thr, thr_hi, thr_lo);
         if (I == J) bits &= (1ull << lane) - 1ull;           // strict upper triangle: only earlier candidates suppress
-        colW[v * 64 + lane] = bits;
+        if (CLUSTER) __hip_atomic_store(&colW[v * 64 + lane], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else colW[v * 64 + lane] = bits;
       }
     }
     __syncthreads();
@@ -531,7 +531,10 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_panel_kernel(const float* __r
       const u64 sw = CLUSTER ? __hip_atomic_load(&supG[s * 8 + Jm], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : supL[Jm];
       ok = tid < rows && !((sw >> lane) & 1ull);
 #pragma unroll
-      for (int I = 0; I < NBLK; ++I) col[I] = I <= Jm && Jm < nb ? colW[(Jm * (Jm + 1) / 2 + I) * 64 + lane] : 0ull;
+      for (int I = 0; I < NBLK; ++I) {
+        u64* cw = &colW[(Jm * (Jm + 1) / 2 + I) * 64 + lane];
+        col[I] = I <= Jm && Jm < nb ? (CLUSTER ? __hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *cw) : 0ull;
+      }
     }
     {
       const u64 k0 = __ballot(ok);
