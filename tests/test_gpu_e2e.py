@@ -470,6 +470,31 @@ def test_repeated_forwards_below_max_batch(lh_weights):
                     assert np.array_equal(got[i][c][0], ref[lo + i][c][0]) and np.array_equal(got[i][c][1], ref[lo + i][c][1]), (lo, hi, rep, i, c)
 
 
+@pytest.mark.parametrize('R', [300, 1000])
+def test_nms_clusters_under_concurrent_load(lh_weights, R):
+    """The proposal NMS of a small batch runs as clusters of 16 workgroups per image that wait for each other inside the
+    kernel (proposals.hip nms_cluster_barrier).  Here two net instances run their forwards concurrently on two streams, three
+    images each, 25 times by graph replay: each stream's clusters exchange their words while the OTHER stream's convs fill the
+    caches and occupy CUs (uneven load, warm L1s: the conditions under which a missing release / acquire shows).  Every replay
+    of every image must give the detections of a net that ran the image alone."""
+    from xdet import weights as W
+    from xdet.model import LightHeadDetector, PipelinedDetector
+    from xdet.runtime import set_precision
+    imgs = W.synthetic_images(6, 480, seed=1606)
+    set_precision('f16x3')
+    try:
+        pd = PipelinedDetector(lh_weights, ways=2, max_batch=6, image_size=480, rpn_post_nms_top_n=R)
+        one = LightHeadDetector(lh_weights, image_size=480, max_batch=1, rpn_post_nms_top_n=R)
+    finally:
+        set_precision('f32')
+    ref = [one.forward(imgs[i:i + 1])[0] for i in range(6)]
+    for rep in range(25):
+        got = pd.forward(imgs)
+        for i in range(6):
+            for c in range(1, 21):
+                assert np.array_equal(got[i][c][0], ref[i][c][0]) and np.array_equal(got[i][c][1], ref[i][c][1]), (rep, i, c)
+
+
 def test_pool_pass_that_writes_the_next_projections_input(lh_weights):
     """option "pool_sub": blocks 2-3's vertical pool pass also writes the raw subsampled planes the next block's projection
     reads and stores relu(sum) for its first separable conv (on, default), or both are made by their own passes / on load
