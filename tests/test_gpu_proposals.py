@@ -126,6 +126,50 @@ def test_get_proposals_suppression_chain(oracle):
     assert np.array_equal(rois, ref)
 
 
+@pytest.mark.parametrize('n', [1, 70])          # a 16-workgroup cluster per image / one workgroup per image
+def test_get_proposals_panel_edges(n, oracle):
+    """Shapes at the seams of the panel NMS: candidate counts that are exact multiples of the 256 / 512-candidate panels and
+    one beside them, a single candidate, post_n = 1, thresholds 0 and >= 1, identical boxes (IoU = 1), and boxes that touch
+    without overlapping.  Same rois and counts as the oracle in every case (net/xception_body.py:57-67,196-213)."""
+    from xdet import ops
+    rng = np.random.default_rng(11 + n)
+
+    def check(scores, boxes, pre, post, thr, min_size=16. / 480):
+        rois, counts = ops.get_proposals(scores, boxes, None, pre, post, thr, min_size, False, 'channels_first', return_counts=True)
+        tr = []
+        m = min(scores.shape[0], 2)
+        ref = oracle.get_proposals(scores[:m], boxes[:m], pre, post, thr, min_size, tr)
+        assert np.array_equal(rois[:m], ref), (pre, post, thr)
+        for i in range(m):
+            assert counts[i, 1] == tr[i]['n_cand'] and counts[i, 2] == min(tr[i]['n_keep'], post), (pre, post, thr, counts[i], tr[i]['n_keep'])
+        if scores.shape[0] > 2:             # the last image of the batch equals its single-image run
+            alone = ops.get_proposals(scores[-1:], boxes[-1:], None, pre, post, thr, min_size, False, 'channels_first')
+            assert np.array_equal(alone[0], rois[-1])
+
+    for cnt in (1, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1024, 1025):     # every anchor valid: n_cand = cnt
+        cy, cx = rng.uniform(0.3, 0.7, (n, cnt)), rng.uniform(0.3, 0.7, (n, cnt))
+        h, w = rng.uniform(0.1, 0.3, (n, cnt)), rng.uniform(0.1, 0.3, (n, cnt))
+        boxes = np.stack([cy - h / 2, cx - w / 2, cy + h / 2, cx + w / 2], -1).astype(np.float32)
+        scores = rng.uniform(0.01, 0.99, (n, cnt)).astype(np.float32)
+        check(scores, boxes, 2000, 300, 0.7)
+    scores, boxes = _clustered(rng, n, 3000)
+    check(scores, boxes, 1500, 1, 0.7)              # the first candidate, nothing else
+    check(scores, boxes, 1500, 600, 0.0)            # threshold 0: any overlap suppresses
+    check(scores, boxes, 1500, 600, 1.0)            # IoU > 1 never: the first 600 candidates
+    check(scores, boxes, 1500, 1500, 0.5)           # post_n = pre_n
+    # identical boxes (IoU = 1) in runs of 5, and a row of boxes that share an edge (IoU = 0)
+    k = 400
+    base = np.stack([np.full(k, 0.2), 0.002 * np.arange(k), np.full(k, 0.6), 0.002 * np.arange(k) + 0.3], -1)
+    boxes = np.repeat(base, 5, 0)[None].repeat(n, 0).astype(np.float32)
+    scores = rng.permutation(5 * k)[None].repeat(n, 0).astype(np.float32) / (5 * k + 1) + 0.001
+    check(scores.astype(np.float32), boxes, 2000, 300, 0.7)
+    x0 = 0.05 * np.arange(18)
+    tiles = np.stack([np.full(18, 0.1), x0, np.full(18, 0.9), x0 + 0.05], -1)
+    boxes = tiles[None].repeat(n, 0).astype(np.float32)
+    scores = np.linspace(0.9, 0.1, 18, dtype=np.float32)[None].repeat(n, 0)
+    check(scores, boxes, 100, 50, 0.0)              # touching boxes: intersection 0, none suppressed even at threshold 0
+
+
 def test_get_proposals_few_and_none(oracle):
     """fewer survivors than post_n -> tiled upsample; none -> the [.2,.2,.8,.8] fallback (:196-213)."""
     from xdet import ops
@@ -162,6 +206,33 @@ def test_ext_decode_and_bboxes_eval(oracle):
             assert (gs > 0).sum() == (rs > 0).sum(), c
             assert np.abs(gs - rs).max() <= 1e-6
             assert np.abs(gb - rb).max() <= 1e-6
+
+
+@pytest.mark.parametrize('R,spread', [(1000, 0.7), (1000, 3.0), (1024, 0.3), (7, 3.0)])
+def test_bboxes_eval_at_the_reference_operating_point(R, spread, oracle):
+    """A12 with rpn_post_nms_top_n = 1000 (light_head_rfcn_eval.py:111) and with the kernel's maximum of 1024 ROIs: flat
+    logits put hundreds of ROIs above the class threshold (the rank sort runs over the packed valid keys, the NMS mask over
+    400 sorted candidates), peaked ones a handful; overlap-heavy boxes so that the per-class NMS has work.  Batched call ==
+    per-image calls; scores and boxes as the oracle's (utility/eval_helper.py:449-506)."""
+    from xdet import ops
+    rng = np.random.default_rng(R + int(10 * spread))
+    n = 3
+    _, boxes = _clustered(rng, n, R, centres=12, jitter=0.03)
+    boxes = np.stack([oracle.bboxes_clip([0, 0, 1, 1], b) for b in boxes])
+    logits = (rng.standard_normal((n, R, 21)) * spread).astype(np.float32)
+    got = ops.bboxes_eval(logits, boxes, (480, 480))
+    n_valid = 0
+    for i in range(n):
+        ref = oracle.bboxes_eval(logits[i], boxes[i], (480, 480))
+        alone = ops.bboxes_eval(logits[i], boxes[i], (480, 480))
+        for c in range(1, 21):
+            gs, gb = got[i][c]
+            rs, rb = ref[c]
+            assert np.array_equal(gs, alone[c][0]) and np.array_equal(gb, alone[c][1])
+            assert (gs > 0).sum() == (rs > 0).sum(), (i, c)
+            assert np.abs(gs - rs).max() <= 1e-6 and np.abs(gb - rb).max() <= 1e-6, (i, c)
+            n_valid += int((rs > 0).sum())
+    assert n_valid > 0
 
 
 def test_non_finite_head_outputs_are_loud(oracle, lh_weights):
