@@ -178,6 +178,40 @@ def test_batch_invariance_across_batch_sizes(big, lh_weights, nb):
     assert np.array_equal(s2, s[:nb]) and np.array_equal(b2, b[:nb])
 
 
+def test_batch_invariance_at_1000_proposals(lh_weights):
+    """The reference's operating point (rpn_post_nms_top_n = 1000, light_head_rfcn_eval.py:109-111): the proposal NMS of a
+    batch of 1 / 3 / 12 / 20 / 40 / 70 images runs as clusters of 16 / 16 / 8 / 4 / 2 / 1 workgroups per image
+    (proposals.hip nms_cluster_size), PsRoiAlign deals fewer than 8 images over several XCDs each, the frequency-bin GEMMs of
+    1-2 images use their own tiles: an image's detections are the same bits in every one of these batches."""
+    from xdet import weights as W
+    from xdet.model import LightHeadDetector
+    from xdet.runtime import set_precision
+    NB = 70
+    imgs = W.synthetic_images(8, 480, seed=1000)
+    imgs = np.concatenate([imgs] * 9)[:NB]
+    imgs[8:] += np.linspace(0.0, 0.05, NB - 8, dtype=np.float32)[:, None, None, None]     # no two images alike
+    set_precision('f16x3')
+    try:
+        big = LightHeadDetector(lh_weights, image_size=480, max_batch=NB, rpn_post_nms_top_n=1000)
+        one = LightHeadDetector(lh_weights, image_size=480, max_batch=1, rpn_post_nms_top_n=1000)
+    finally:
+        set_precision('f32')
+    big.set_images(imgs)
+    big.forward_device(NB, use_graph=True)
+    s, b = big.detections(NB)
+    s, b = s.copy(), b.copy()
+    assert (s > 0).any(axis=(1, 2)).all()
+    for nb in (1, 3, 12, 20, 40):
+        big.set_images(imgs[:nb])
+        big.forward_device(nb, use_graph=True)
+        s2, b2 = big.detections(nb)
+        assert np.array_equal(s2, s[:nb]) and np.array_equal(b2, b[:nb]), nb
+    for pos in (0, 9, NB - 1):
+        got = one.forward(imgs[pos:pos + 1])
+        for c in range(20):
+            assert np.array_equal(got[0][c + 1][0], s[pos, c]) and np.array_equal(got[0][c + 1][1], b[pos, c]), (pos, c)
+
+
 def test_the_configuration_the_driver_benches(oracle, lh_weights):
     """BENCH_rNN's configuration, asserted instead of only timed (BASELINE config 4 at world size 1): 2 concurrent
     sub-batches x 128 images, f16x3 + spectral, hipGraph replay, input = raw uint8 VOC-shape images through the F1
