@@ -203,7 +203,12 @@ int xdet_rpn_decode(const float* rpn_out, int ld, int cls_off, int box_off, int 
 /* ---- A7: get_proposals (net/xception_body.py:402-448) ------------------------------------
  *   objectness [N,n_anchor], boxes [N,n_anchor,4] -> rois [N,post_n,4]; workspace from
  *   xdet_proposals_workspace_bytes().  counts_out (may be NULL) i32 [N,4] device:
- *   {n_valid, n_candidates, n_kept_by_nms, 0}. */
+ *   {n_valid, n_candidates, n_kept_by_nms, 0}.  nms_thr >= 0; post_n <= 6144 (the kept list lives in LDS).
+ *   The NMS is tf.image.non_max_suppression's greedy walk (visit in score order, IoU > thr against boxes kept before,
+ *   stop at post_n) computed in panels of 256 / 512 candidates; with N <= 64 an image's panels are spread over a cluster
+ *   of up to 16 workgroups that wait for each other inside the kernel (every per-call control word is cleared by the
+ *   call itself; a cluster whose members never meet -- it cannot happen on an otherwise working GPU -- gives up after
+ *   ~1 s and marks its image, whose detection scores then come out NaN through xdet_net_forward). */
 size_t xdet_proposals_workspace_bytes(int N, int n_anchor, int pre_n, int post_n);
 int xdet_get_proposals(const float* objectness, const float* boxes, int N, int n_anchor, int pre_n, int post_n,
                        float nms_thr, float min_size, void* workspace, float* rois, int* counts_out, void* stream);
