@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, 4) void psroialign_fwd_kernel(const float* __r
                                                              const float* __restrict__ rois,
                                                              float* __restrict__ pooled, int32_t* __restrict__ index,
                                                              int N, int C, int H, int W, int R, int gw, int gh,
-                                                             int layout, int ldc, int out_ld, int corners, int dedup) {
+                                                             int layout, int ldc, int out_ld, int corners, int dedup, int split) {
   constexpr int use_max = USE_MAX ? 1 : 0;
   // pixel grids of psroi_grid_bin: [wave][entry <= 16][lane] (two-channel form only)
   __shared__ __attribute__((aligned(8))) float2 s_grid[VEC == 2 ? 4 * 16 * 64 : 1];
@@ -119,7 +119,10 @@ __global__ __launch_bounds__(256, 4) void psroialign_fwd_kernel(const float* __r
   // (1.8 MB at 30x30x490) crosses the fabric once and every further sample of it is an L2 hit.
   // Fewer than 8 images: an image's ROI blocks are dealt to P = 8 / N XCDs (the map is read P times over the fabric, and
   // all 256 CUs work -- with one XCD per image a single image's 1000 ROIs ran on 32 CUs: 90 us on the critical path).
-  const int bpi = (R + 3) >> 2;                        // workgroups (4 ROIs each) per image
+  // split (few ROIs in the whole call): ONE ROI per workgroup, its elements dealt to the four waves -- a single image's 300
+  // ROIs are then 1,200 waves of one pass each instead of 300 waves of four dependent passes (latency, not throughput)
+  const int bpi = split ? R : (R + 3) >> 2;            // workgroups (4 ROIs each; split: one) per image
+  const int e_first = (split ? (int)(threadIdx.x >> 6) * 64 : 0) + lane, e_step = split ? 256 : 64;
   const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
   int64_t n;
   int rblk;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256, 4) void psroialign_fwd_kernel(const float* __r
     rblk = slot * P + xcd / N;
     if (xcd >= N * P) return;
   }
-  const int r_roi = rblk * 4 + (threadIdx.x >> 6);
+  const int r_roi = split ? rblk : rblk * 4 + (threadIdx.x >> 6);
   if (n >= N || rblk >= bpi || r_roi >= R) return;
   const int64_t nr = n * R + r_roi;
   const float* roi = rois + nr * 4;
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256, 4) void psroialign_fwd_kernel(const float* __r
   int32_t* irow = index ? index + nr * out_ld : nullptr;
 
   if (r2 < FLT_MIN || r3 < FLT_MIN) {   // degenerate ROI: zero (reference leaves the index unwritten)
-    for (int e = lane; e < C; e += 64) {
+    for (int e = e_first; e < C; e += e_step) {
       prow[e] = 0.f;
       if (irow) irow[e] = 0;
     }
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(256, 4) void psroialign_fwd_kernel(const float* __r
   if (VEC == 2 && USE_MAX && dedup && n_h * n_w > 1 && (n_h + 1) * (n_w + 1) <= 16 && n_h <= 5 && n_w <= 5) {
     float2* grid = s_grid + (threadIdx.x >> 6) * (16 * 64) + lane;
     bool declined = false;
-    for (int ev = lane; ev * VEC < C; ev += 64) {
+    for (int ev = e_first; ev * VEC < C; ev += e_step) {
       const int e = ev * VEC;
       const int pos = e / bank;
       const int row = pos / gw;
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(256, 4) void psroialign_fwd_kernel(const float* __r
     }
     if (!declined) return;
   }
-  for (int ev = lane; ev * VEC < C; ev += 64) {
+  for (int ev = e_first; ev * VEC < C; ev += e_step) {
     const int e = ev * VEC;              // first of this lane's VEC channels (all in one bin: VEC divides bank)
     float acc[VEC];
     int arg[VEC];
@@ -431,7 +434,9 @@ int launch_psroialign(const float* feat, const float* rois, float* pooled, int32
     (void)hipGetLastError();                             // no scratch: the direct form below
   }
   // image n on XCD n & 7; fewer than 8 images: each image on 8 / N XCDs (see the kernel)
-  const int64_t blocks = N >= 8 ? cdiv(N, 8) * 8 * cdiv(R, 4) : 8 * cdiv(cdiv(R, 4), 8 / N);
+  const int split = (int64_t)N * R <= 2048 ? 1 : 0;      // one ROI per workgroup (see the kernel)
+  const int64_t bpi = split ? R : cdiv(R, 4);
+  const int64_t blocks = N >= 8 ? cdiv(N, 8) * 8 * bpi : 8 * cdiv(bpi, 8 / N);
   // two channels per lane (8-byte corner loads) where the layout allows it: NHWC, even bank and channel stride,
   // 8-byte aligned map
   constexpr int dedup = 1;                               // the two-channel form always reads through its LDS corner grid
@@ -440,7 +445,7 @@ int launch_psroialign(const float* feat, const float* rois, float* pooled, int32
   const int cs = layout == 0 ? C : ldc;
 #define XDET_PSROI_LAUNCH(V, M)                                                                                        \
   hipLaunchKernelGGL((psroialign_fwd_kernel<V, M>), dim3((unsigned)blocks), dim3(256), 0, s, feat, rois, pooled, index, N, C, \
-                     H, W, R, gw, gh, layout, cs, out_ld, rois_are_corners, (V) == 2 ? dedup : 0)
+                     H, W, R, gw, gh, layout, cs, out_ld, rois_are_corners, (V) == 2 ? dedup : 0, split)
   if (two && use_max) XDET_PSROI_LAUNCH(2, true);       // the net's form ('max', NHWC)
   else if (two) XDET_PSROI_LAUNCH(2, false);            // 'mean', NHWC: two channels per lane (8-byte corner loads), direct path
   else if (use_max) XDET_PSROI_LAUNCH(1, true);         // NCHW (the op's public contract): neighbouring channels are H*W
