@@ -92,11 +92,55 @@ __global__ void head_decode_probs_kernel(const float* __restrict__ rois, const f
   }
 }
 
+// The same pass with 32 lanes per ROI (num_classes + 4 <= 32: the light head's 21 + 4): a lane owns one column of the ROI's
+// row -- ONE coalesced 128-byte read instead of 25 row-strided ones -- the maximum is a butterfly over the 32 lanes, and the
+// sums run over the lanes' values IN CLASS ORDER (every lane adds the same 21 shuffled values: class_probs_begin's order,
+// the same bits).  A single image's 300 ROIs are 38 workgroups instead of 2 threads-per-ROI workgroups: 12 -> ~5 us on the
+// critical path of a single-image forward.
+__global__ __launch_bounds__(256) void head_decode_probs_lanes_kernel(const float* __restrict__ rois, const float* __restrict__ cls_reg,
+                                                                      int ld, int num_classes, int R, int64_t n,
+                                                                      float* __restrict__ out, float* __restrict__ probs,
+                                                                      int* __restrict__ bad) {
+  const int lane = threadIdx.x & 63, k = lane & 31, gbase = lane & 32;
+  for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 5; i < n; i += ((int64_t)gridDim.x * blockDim.x) >> 5) {
+    const float x = k < num_classes + 4 ? cls_reg[i * ld + k] : 0.f;
+    float m = k < num_classes ? x : -INFINITY;
+#pragma unroll
+    for (int d = 16; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));       // (all 32 lanes of the group end with the maximum)
+    const float e = expf(x - m);
+    float sum = 0.f, lsum = 0.f;
+    for (int c = 0; c < num_classes; ++c) {
+      sum += __shfl(e, gbase + c);
+      lsum = c == 0 ? __shfl(x, gbase) : lsum + __shfl(x, gbase + c);
+    }
+    const int64_t img = i / R;
+    const int ri = (int)(i - img * R);
+    if (k < num_classes) probs[(img * num_classes + k) * R + ri] = e / sum;
+    const float p0 = __shfl(x, gbase + num_classes), p1 = __shfl(x, gbase + num_classes + 1);
+    const float p2 = __shfl(x, gbase + num_classes + 2), p3 = __shfl(x, gbase + num_classes + 3);
+    if (k == 0) {
+      if (!(fabsf(lsum) <= FLT_MAX)) bad[img] = 1;
+      const float4 r = *reinterpret_cast<const float4*>(rois + i * 4);
+      const float href = r.z - r.x, wref = r.w - r.y;
+      const float yref = r.x + href / 2.f, xref = r.y + wref / 2.f;
+      const float ph = expf(p2) * href;
+      const float pw = expf(p3) * wref;
+      const float pcy = p0 * href + yref;
+      const float pcx = p1 * wref + xref;
+      *reinterpret_cast<float4*>(out + i * 4) = make_float4(pcy - ph / 2.f, pcx - pw / 2.f, pcy + ph / 2.f, pcx + pw / 2.f);
+    }
+  }
+}
+
 int launch_head_decode_probs(const float* rois, const float* cls_reg, int ld, int num_classes, int R, int64_t n, float* out,
                              float* probs, int* bad, hipStream_t s) {
   if (n == 0) return XDET_OK;
-  hipLaunchKernelGGL(head_decode_probs_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 2048)), dim3(256), 0, s, rois,
-                     cls_reg, ld, num_classes, R, n, out, probs, bad);
+  if (num_classes + 4 <= 32 && ld >= num_classes + 4)
+    hipLaunchKernelGGL(head_decode_probs_lanes_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n * 32, 256), 16384)), dim3(256), 0, s,
+                       rois, cls_reg, ld, num_classes, R, n, out, probs, bad);
+  else
+    hipLaunchKernelGGL(head_decode_probs_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 2048)), dim3(256), 0, s, rois,
+                       cls_reg, ld, num_classes, R, n, out, probs, bad);
   XDET_LAUNCH_CHECK();
   return XDET_OK;
 }
