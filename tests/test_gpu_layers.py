@@ -428,6 +428,29 @@ def test_ksplit_modes_are_bit_identical_and_match_the_plain_kernel(case, prec, o
     close(y, y0, 3e-6 if prec == 'f16x3' else 2e-2)
 
 
+def test_ksplit_fold_by_a_second_launch_beyond_the_ticket_array():
+    """The parallel-ranges mode folds inside the GEMM launch (the last workgroup of a tile to arrive, conv_params.h ks_ticket:
+    4096 tickets).  A launch of more tiles than that folds by a second launch (conv_ksplit_fold_kernel) -- the same left
+    fold, the same epilogue: the same bits as the sequential mode."""
+    from xdet.ops import Conv2D
+    from xdet.runtime import DeviceTensor, set_precision
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((40, 120, 120, 64)).astype(np.float32)           # 576,000 rows: 4,500 M tiles of 128
+    k = (rng.standard_normal((1, 1, 64, 64)) / 8).astype(np.float32)
+    set_precision('f16x3')
+    try:
+        xd = DeviceTensor.from_numpy(x)
+        conv = Conv2D(k, 1, 'SAME', 1, None, None, relu=True)
+        conv.set_ksplit(2, 1, 4608)
+        par = conv(xd, planes=True).numpy()
+        conv.set_ksplit(2, 2, 0)
+        seq = conv(xd, planes=True).numpy()
+    finally:
+        set_precision('f32')
+    assert np.array_equal(par, seq)
+    assert np.isfinite(par).all() and np.abs(par).max() > 0
+
+
 def test_ksplit_is_batch_invariant():
     """an image's rows do not depend on the batch it arrives in, although small batches run the ranges in parallel and
     large ones sequentially (mode 0: by grid size)."""

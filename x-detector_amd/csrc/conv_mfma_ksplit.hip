@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_ksplit_kernel
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = first ? acc[i][j] : tot[i][j] + acc[i][j];
     }
-  } else if (S > 1) {
+  } else if (S > 1 && !p.ks_ticket) {
     // park the raw accumulators: slab [tile][range][v][tid] of float4 (every store instruction one contiguous 4 / 8 KB)
     constexpr int V = TM * TN * 4;
     ks_f4* slab = reinterpret_cast<ks_f4*>(p.ks_partial) + ((size_t)tile * S + range) * V * (64 * NW);
@@ -310,6 +310,65 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_ksplit_kernel
               ks_f4{acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
     return;                                                // the fold + epilogue: conv_ksplit_fold_kernel, next launch
   }
+  if (PARALLEL && S > 1 && p.ks_ticket) {
+    // ---- the fold INSIDE this launch, by the last workgroup of the tile to arrive (round 6).  Round 4 tried this with
+    // device-scope release / acquire fences around the ticket and dropped it: the fences write back / invalidate a whole XCD's
+    // L2 (30-40 us per launch).  Here nothing is fenced (cdna_hip_programming.md Guideline 16, form R1): the slabs are written
+    // with write-through (`sc1`) 16-byte stores and read with `sc1` loads, every wave drains its stores, ONE lane takes the
+    // ticket with a relaxed agent-scope add.  Whoever draws ksplit - 1 knows that every other range's stores were drained
+    // before its add: it folds the S slabs -- its own too, from memory, so that the order is the range order whoever comes
+    // last -- and runs the epilogue.  No polling: nobody waits for anybody.
+    constexpr int V = TM * TN * 4;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.ks_partial + (size_t)tile * S * V * (NW * 256), 0,
+                                                                        S * V * (NW * 1024), 0x00020000);
+    const int vo = tid * 16;
+    typedef unsigned ks_u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const ks_f4 x = {acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ks_u4, x), rs, vo, (range * V + (i * TN + j) * 4 + q) * (NW * 1024), 16);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* s_last = reinterpret_cast<int*>(smem16);          // (the operand ring is dead)
+    if (tid == 0) {
+      const int got = __hip_atomic_fetch_add(p.ks_ticket + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *s_last = got == S - 1;
+      if (got == S - 1) __hip_atomic_store(p.ks_ticket + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+    if (!*s_last) return;
+    __syncthreads();                                       // (s_last is read before the epilogue reuses the LDS)
+    ks_f4 t[V];
+#pragma unroll 1
+    for (int r0 = 0; r0 < S; r0 += 2) {
+      ks_f4 u0[V], u1[V];
+      const bool two = r0 + 1 < S;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        u0[v] = __builtin_bit_cast(ks_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (r0 * V + v) * (NW * 1024), 16));
+        u1[v] = __builtin_bit_cast(ks_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (two ? (r0 + 1) * V + v : r0 * V + v) * (NW * 1024), 16));
+      }
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        t[v] = r0 == 0 ? u0[v] : t[v] + u0[v];             // ((p0 + p1) + p2) + ...
+        if (two) t[v] = t[v] + u1[v];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const ks_f4 x = t[(i * TN + j) * 4 + q];
+          acc[i][j][q * 4] = x.x; acc[i][j][q * 4 + 1] = x.y; acc[i][j][q * 4 + 2] = x.z; acc[i][j][q * 4 + 3] = x.w;
+        }
+  }
   if (m0 + BM <= p.M) conv_epilogue_full<WM, WN, TM, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wm, wn, m0, n0);
   else conv_epilogue<WM, WN, TM, TN, NW, NSTAGE * STAGE * 2>(p, acc, smem16, wave, lane, wm, wn, m0, n0);
 }
@@ -318,9 +377,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_dma_ksplit_kernel
 // that owned an element in the accumulator layout owns it here, so no transpose is needed -- and runs the shared epilogue
 // on its 64 x 64 (32 x 64) sub-tile.  The S loads of an element are issued together (S is a template parameter) and only
 // the additions are ordered: a fold with a run-time loop over S was a chain of dependent L2 round trips (42 us for the RPN
-// conv of one image, more than its GEMM).  (An in-kernel fold by the last workgroup to arrive needs device-scope release /
-// acquire fences around its ticket: on this chip those write back and invalidate a whole XCD's L2, 30-40 us per launch
-// with 228 workgroups doing it -- measured, dropped.  A kernel boundary orders the slab stores for free.)
+// conv of one image, more than its GEMM).  Since round 6 this launch is the FALLBACK (no ticket array, or more tiles than it
+// has tickets): the GEMM launch folds by itself, see the `ks_ticket` branch of conv_dma_ksplit_kernel.  (Round 4 had tried
+// that with device-scope release / acquire fences around the ticket -- they write back and invalidate a whole XCD's L2,
+// 30-40 us per launch with 228 workgroups doing it -- and dropped it; write-through stores need no fence.)
 template <int BN, int WAVES_M, int WAVES_N, int S>
 __global__ __launch_bounds__(64) void conv_ksplit_fold_kernel(ConvParams p) {
   constexpr int BM = 128;
@@ -407,7 +467,7 @@ static int launch_ks(const ConvParams& p, hipStream_t s) {
   dim3 grid((unsigned)(tiles * (PARALLEL ? p.ksplit : 1)));
   hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, p);
   XDET_LAUNCH_CHECK();
-  if (PARALLEL) return launch_fold<BN, WAVES_M, WAVES_N>(p, tiles, s);
+  if (PARALLEL && !p.ks_ticket) return launch_fold<BN, WAVES_M, WAVES_N>(p, tiles, s);
   return XDET_OK;
 }
 
@@ -429,7 +489,9 @@ static int launch_ks_modes(const ConvParams& p, bool par, hipStream_t s) {
 }
 
 // mode: 0 = by grid size, 1 = parallel (needs scratch for every tile), 2 = sequential
-int launch_conv_mfma_ksplit(const ConvParams& p, int n_tile, int nsplit, int mode, int64_t scratch_tiles, hipStream_t s) {
+int launch_conv_mfma_ksplit(const ConvParams& p_in, int n_tile, int nsplit, int mode, int64_t scratch_tiles, hipStream_t s) {
+  ConvParams p = p_in;
+  if (cdiv(cdiv(p.M, 128), 8) * 8 * (p.Cout_pad / (n_tile == 128 ? 128 : 64)) > 4096) p.ks_ticket = nullptr;   // (the ticket array's size: fold by a second launch)
   XDET_REQUIRE(p.Kp % 32 == 0 && p.Cin_p % 32 == 0 && p.ldi >= p.Cin_p && p.ldi % 32 == 0 && p.Kp == p.Cin_p * p.KH * p.KW,
                "conv(ksplit): channel counts must be padded to 32");
   XDET_REQUIRE(n_tile == 64 || n_tile == 128, "conv(ksplit): N tile must be 64 or 128");

@@ -61,6 +61,10 @@ struct ConvParams {
   int skip_dead = 1;   // conv_dma_f16_kernel: waves skip 32-column blocks that are pure padding of the N tile (0: A/B runs)
   int ksplit = 1;
   float* ks_partial = nullptr;
+  // parallel mode with an in-kernel fold: ks_ticket[tile] counts the ranges of a tile that have parked their slab; the LAST one
+  // to arrive folds all of them (in range order) and runs the epilogue, then puts the ticket back to 0.  >= 4096 ints, zero
+  // between launches.  NULL: the fold is a second launch (conv_ksplit_fold_kernel).
+  int* ks_ticket = nullptr;
 };
 
 }  // namespace xdet

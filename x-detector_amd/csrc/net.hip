@@ -149,6 +149,7 @@ struct ConvLayer : LayerBase {
   bool ks_narrow = false;              // 128 x 64 tiles although the layer is a multiple of 128 wide (one range, twice the workgroups)
   int64_t ks_tiles = 0;                // tiles the scratch below was sized for
   float* d_ks_partial = nullptr;
+  int* d_ks_ticket = nullptr;          // 4096 zeroed ints: arrival tickets of the in-kernel fold (conv_params.h ks_ticket)
   bool ks_owns_scratch = false;        // false: the slab belongs to the plan (one per stream, shared by its layers)
   size_t ks_scratch_bytes(int S, int64_t tiles) const {
     return S > 1 ? (size_t)std::max<int64_t>(tiles, 1) * S * 128 * (cout_pad % 128 == 0 ? 128 : 64) * sizeof(float) : 0;
@@ -157,14 +158,17 @@ struct ConvLayer : LayerBase {
   // ops of one stream run one after the other, so all its split-K layers borrow ONE slab sized for the largest of them
   int enable_ksplit(int S, int64_t max_parallel_tiles, float* shared = nullptr) {
     XDET_REQUIRE(S >= 1 && S <= 16 && dma_capable() && groups == 1, "ksplit: 1..16 ranges, a split-precision non-grouped layer");
-    if (d_ks_partial && ks_owns_scratch) (void)hipFree(d_ks_partial);
+    if (d_ks_partial && ks_owns_scratch) { (void)hipFree(d_ks_partial); (void)hipFree(d_ks_ticket); }
     d_ks_partial = nullptr;
+    d_ks_ticket = nullptr;
     ks_owns_scratch = false;
     ks_tiles = std::max<int64_t>(max_parallel_tiles, 1);
     if (S > 1) {
       if (shared) d_ks_partial = shared;
       else {
         XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_ks_partial), ks_scratch_bytes(S, ks_tiles)));
+        XDET_HIP(hipMalloc(reinterpret_cast<void**>(&d_ks_ticket), 4096 * sizeof(int)));
+        XDET_HIP(hipMemset(d_ks_ticket, 0, 4096 * sizeof(int)));
         ks_owns_scratch = true;
       }
     }
@@ -208,7 +212,7 @@ struct ConvLayer : LayerBase {
   }
 
   ~ConvLayer() override {
-    if (d_ks_partial && ks_owns_scratch) (void)hipFree(d_ks_partial);
+    if (d_ks_partial && ks_owns_scratch) { (void)hipFree(d_ks_partial); (void)hipFree(d_ks_ticket); }
     if (d_pl_scale) (void)hipFree(d_pl_scale);
     if (d_pl_shift) (void)hipFree(d_pl_shift);
     if (d_zeros) (void)hipFree(d_zeros);
@@ -392,7 +396,7 @@ struct ConvLayer : LayerBase {
                                     "filter is not 1x1 / 3x3); a split reduction cannot change kernel family: run smaller batches");
           return launch_conv_mfma_dma(p, 64, precision == PREC_F16X3 ? 3 : 1, s);
         }
-        p.ksplit = ksplit; p.ks_partial = d_ks_partial;
+        p.ksplit = ksplit; p.ks_partial = d_ks_partial; p.ks_ticket = d_ks_ticket;
         return launch_conv_mfma_ksplit(p, cout_pad % 128 == 0 && !ks_narrow ? 128 : 64, precision == PREC_F16X3 ? 3 : 1, ks_mode, ks_tiles, s);
       }
       return launch_conv_mfma_dma(p, n_tile, precision == PREC_F16X3 ? 3 : 1, s);
@@ -847,14 +851,18 @@ struct Plan {
   std::vector<KsLayer> ks_layers;
   bool ks_on_aux_stream = false;       // builders set this around layers that run on the side stream (the RPN branch)
   float* ks_slab[2] = {nullptr, nullptr};
+  int* ks_ticket[2] = {nullptr, nullptr};
   // one slab per stream (main / side), sized for the largest split-K layer on it (a slab per layer was
   // 0.5-0.8 GB per ResNet trunk)
   int finish_ksplit() {
     size_t need[2] = {0, 0};
     for (const KsLayer& k : ks_layers) need[k.aux] = std::max(need[k.aux], k.L->ks_scratch_bytes(k.L->ksplit, k.L->ks_tiles));
     for (int a = 0; a < 2; ++a)
-      if (need[a] && !ks_slab[a]) XDET_TRY(alloc_bytes(need[a], reinterpret_cast<void**>(&ks_slab[a]), false));
-    for (const KsLayer& k : ks_layers) k.L->d_ks_partial = ks_slab[k.aux];
+      if (need[a] && !ks_slab[a]) {
+        XDET_TRY(alloc_bytes(need[a], reinterpret_cast<void**>(&ks_slab[a]), false));
+        XDET_TRY(alloc_bytes(4096 * sizeof(int), reinterpret_cast<void**>(&ks_ticket[a])));     // (zeroed; every fold puts its ticket back)
+      }
+    for (const KsLayer& k : ks_layers) { k.L->d_ks_partial = ks_slab[k.aux]; k.L->d_ks_ticket = ks_ticket[k.aux]; }
     return XDET_OK;
   }
   bool fuse_sepconv = true;      // option "sepconv" = "fused" | "split"
