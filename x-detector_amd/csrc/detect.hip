@@ -11,6 +11,7 @@
 // bitmask NMS and the ordered scan all stay in LDS; output is the reference's zero-padded
 // per-class (scores[topk], boxes[topk,4]).
 #include "common.h"
+#include "nms_pairs.h"
 #include <cfloat>
 
 namespace xdet {
@@ -153,35 +154,6 @@ int launch_ext_decode_rois(const float* rois, const float* reg, int ld_reg, int6
   return XDET_OK;
 }
 
-// lane `src` (wave-uniform) of a 64-bit value as a scalar: v_readlane, not a ds_bpermute round trip (proposals.hip)
-__device__ __forceinline__ u64 readlane_u64d(u64 v, int src) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
-  return ((u64)hi << 32) | lo;
-}
-
-// IoU(a, b) > thr as tf.image.non_max_suppression decides it (corners min/max-normalised, zero when either area is <= 0,
-// strict >), from pre-normalised corners (y0, x0, y1, x1 with y0 <= y1, x0 <= x1) and pre-computed areas, without a
-// division on the fast path (as proposals.hip's nms_pair_bits): the correctly rounded quotient can only disagree with the
-// product tests inside a 1e-5 relative band around the threshold, and only there is the reference's expression evaluated.
-// An area <= 0 is passed as +inf: every test below is then false, which is the reference's "IoU = 0".
-// The per-class NMS mask is up to ~80,000 IoUs per (image, class) workgroup.
-__device__ __forceinline__ float vmin_d(float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ float vmax_d(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ bool iou_norm_gt_d(const float4 a, const float aa, const float4 b, const float ab, float thr,
-                                              float thr_hi, float thr_lo) {
-  const float ih = vmax_d(vmin_d(a.z, b.z) - vmax_d(a.x, b.x), 0.f);
-  const float iw = vmin_d(a.w, b.w) - vmax_d(a.y, b.y);
-  const float inter = ih * iw;                        // <= 0 unless the boxes overlap
-  const float uni = (aa + ab) - inter;
-  bool h = fmaf(-thr_hi, uni, inter) > 0.f;
-  if (!h && !(fmaf(-thr_lo, uni, inter) < 0.f)) {     // the band (or NaN from thr = 0): the reference's own rounding
-    const float in2 = __fmul_rn(ih, vmax_d(iw, 0.f));
-    h = __fdiv_rn(in2, __fsub_rn(__fadd_rn(aa, ab), in2)) > thr;
-  }
-  return h;
-}
-
 constexpr int EV_MAXR = 1024;   // ROIs per image supported by one workgroup
 constexpr int EV_MAXS = 512;    // 2*nms_topk upper bound (sorted candidates)
 constexpr int EV_W = EV_MAXS / 64;
@@ -205,7 +177,7 @@ __global__ __launch_bounds__(EV_T) void bboxes_eval_kernel(const float* __restri
   __shared__ float4 sbox[EV_MAXS];
   __shared__ float sscore[EV_MAXS];
   __shared__ u64 mask[EV_MAXS * EV_W];
-  __shared__ u64 s_removed[EV_W];
+  __shared__ u64 s_removed[2 * EV_W];
   // (aliases, so that two workgroups still share a CU: the sorted boxes with min/max-normalised corners -- what iou_gt_fast_d
   //  makes of its arguments -- and their areas live in `bx`, dead once the sorted copies exist; the rank counters in `mask`,
   //  which is not written before they are dead)
@@ -338,73 +310,72 @@ __global__ __launch_bounds__(EV_T) void bboxes_eval_kernel(const float* __restri
       const float ar = (y1 - y0) * (x1 - x0);
       sarea[rank] = ar > 0.f ? ar : __builtin_inff();
     }
-    if (tid < EV_W) s_removed[tid] = 0ull;
   }
   __syncthreads();
 
-  // NMS bitmask: bit (i,j) for j > i.  One wave per (row i, 64-column block): a lane keeps ITS column's box in registers across
-  // the rows, the row's box is a broadcast read, the word is a ballot -- no per-lane loop over 64 columns with divergent exits,
-  // and the blocks left of the diagonal (no j > i in them) are written as zeros without an IoU.  iou_norm_gt_d is iou_gt_fast_d
-  // on the pre-normalised corners and areas: the same comparisons on the same values.
+  // Per-class NMS as the proposal stage does it (proposals.hip nms_panel_kernel; here the whole class is one panel of up to
+  // EV_MAXS candidates): (i) the strict upper triangle of "IoU(i, j) > thr" as COLUMN bits -- a lane holds candidate j and
+  // walks the 64 boxes of row block I broadcast from LDS (nms_pairs.h: ~16 VALU operations per pair), the 64 x 64 blocks dealt
+  // round-robin to the 16 waves; (ii) the keep set as the fixed point of keep_j = ok_j & !(col_j & keep) -- unique, the greedy
+  // one, a few rounds of ballots -- instead of a serial walk over the kept boxes; (iii) the first nms_topk of it.
+  // (Rounds 3-5: row words by ballot per (row, column block) and an ordered scan by one wave: 31 + 14 us of the 60 us this
+  //  kernel took for the class that decides a single image's latency at R = 1000.)
   const int w64 = (n_sorted + 63) / 64;
   const float thr_hi = nms_thr * 1.00001f, thr_lo = nms_thr * 0.99999f;
+  u64* const colL = mask;                                   // [w64 (w64 + 1) / 2][64]
+  u64* const Kb = s_removed;                                // keep words of the current / next round: [2][EV_W]
   {
     const int wv = tid >> 6, ln = tid & 63;
-    for (int wq = 0; wq < w64; ++wq) {
-      const int col = wq * 64 + ln;
+    const int n_unit = w64 * (w64 + 1) / 2;
+    for (int v = wv; v < n_unit; v += EV_T / 64) {
+      int J = 0;
+      while ((J + 1) * (J + 2) / 2 <= v) ++J;
+      const int I = v - J * (J + 1) / 2;
+      const int col = J * 64 + ln;
       const bool col_ok = col < n_sorted;
-      const float4 cb = col_ok ? snorm[col] : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float ca = col_ok ? sarea[col] : __builtin_inff();
-      for (int i = wv; i < n_sorted; i += EV_T / 64) {
-        u64 bits = 0ull;
-        if (i < wq * 64 + 63) {                       // (wave-uniform) some column of this block is right of the diagonal
-          const float4 me = snorm[i];
-          const float ma = sarea[i];
-          bits = __ballot(col_ok && col > i && iou_norm_gt_d(me, ma, cb, ca, nms_thr, thr_hi, thr_lo));
-        }
-        if (ln == 0) mask[i * EV_W + wq] = bits;
-      }
+      const float4 me = col_ok ? snorm[col] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float ma = col_ok ? sarea[col] : __builtin_inff();
+      u64 bits = nms_pair_bits(snorm + I * 64, sarea + I * 64, min(64, n_sorted - I * 64), me, ma, nms_thr, thr_hi, thr_lo);
+      if (I == J) bits &= (1ull << ln) - 1ull;              // only earlier candidates suppress
+      colL[v * 64 + ln] = bits;
     }
   }
   __syncthreads();
-
-  // ordered scan by wave 0 (lane q < EV_W holds removed word q).  Inside a 64-box chunk only the boxes that SURVIVE are visited
-  // (lowest bit still available, then its row's bits leave the set): the same sequence as a walk over all 64 bits, in as many
-  // steps as boxes are kept.  The rows of the kept boxes then go into the later chunks' removed words in parallel (each kept
-  // lane ORs its own row in), not one LDS round trip per kept box.
-  if (tid < 64) {
-    const int lane = tid;
-    u64 removed = 0ull;
-    int n_keep = 0;
-    for (int cch = 0; cch < w64 && n_keep < nms_topk; ++cch) {
-      const int i = cch * 64 + lane;
-      const u64 diag = i < n_sorted ? mask[i * EV_W + cch] : 0ull;
-      const u64 cur = readlane_u64d(removed, cch);             // scalar chain: cur, avail, keepmask are wave-uniform
-      const int lim = __builtin_amdgcn_readfirstlane(min(64, n_sorted - cch * 64));
-      u64 avail = ~cur & (lim == 64 ? ~0ull : ((1ull << lim) - 1ull));
-      u64 keepmask = 0ull;
-      int kc = n_keep;
-      while (avail != 0ull && kc < nms_topk) {
-        const int b = __ffsll((long long)avail) - 1;
-        keepmask |= 1ull << b;
-        ++kc;
-        avail &= ~(readlane_u64d(diag, b) | (1ull << b));
-      }
-      const bool kept = (keepmask >> lane) & 1ull;
-      if (kept) s_keptidx[n_keep + __popcll(keepmask & ((1ull << lane) - 1ull))] = i;
-      n_keep = kc;
-      if (cch + 1 < w64 && n_keep < nms_topk) {
-        if (kept)
-          for (int q = cch + 1; q < w64; ++q) {
-            const u64 row = mask[i * EV_W + q];
-            if (row) atomicOr(&s_removed[q], row);
-          }
-        __threadfence_block();
-        __builtin_amdgcn_wave_barrier();
-        removed = lane < EV_W ? *reinterpret_cast<volatile u64*>(&s_removed[lane]) : 0ull;
-      }
+  {
+    const int ln = tid & 63, Jm = tid >> 6;                 // thread = candidate (tid < EV_MAXS), wave = its 64-block
+    const bool ok = tid < n_sorted;
+    u64 col[EV_W];
+#pragma unroll
+    for (int I = 0; I < EV_W; ++I) col[I] = (ok && I <= Jm) ? colL[(Jm * (Jm + 1) / 2 + I) * 64 + ln] : 0ull;
+    {
+      const u64 k0 = __ballot(ok);
+      if (ln == 0 && Jm < EV_W) Kb[Jm] = k0;
     }
-    if (lane == 0) s_nkeep = n_keep;
+    __syncthreads();
+    int cur = 0;
+    for (int round = 0; round <= EV_MAXS; ++round) {
+      u64 acc = 0ull;
+#pragma unroll
+      for (int I = 0; I < EV_W; ++I) acc |= col[I] & Kb[cur * EV_W + I];
+      const bool nk = ok && acc == 0ull;
+      const u64 kw = __ballot(nk);
+      const u64 old = Jm < EV_W ? Kb[cur * EV_W + Jm] : 0ull;
+      if (ln == 0 && Jm < EV_W) Kb[(cur ^ 1) * EV_W + Jm] = kw;
+      cur ^= 1;
+      if (!__syncthreads_or(Jm < EV_W && kw != old)) break;
+    }
+    int before = 0, total = 0;
+#pragma unroll
+    for (int I = 0; I < EV_W; ++I) {
+      const int cnt = __popcll(Kb[cur * EV_W + I]);
+      before += I < Jm ? cnt : 0;
+      total += cnt;
+    }
+    if (Jm < EV_W && ((Kb[cur * EV_W + Jm] >> ln) & 1ull)) {
+      const int slot = before + __popcll(Kb[cur * EV_W + Jm] & ((1ull << ln) - 1ull));
+      if (slot < nms_topk) s_keptidx[slot] = tid;
+    }
+    if (tid == 0) s_nkeep = min(total, nms_topk);
   }
   __syncthreads();
 

@@ -20,6 +20,7 @@
 //                wavefront; stops at post_n
 //   7. gather  : rois[j] = kept[j mod n_keep]  (tile + identity "shuffle" of :196-213)
 #include "common.h"
+#include "nms_pairs.h"
 #include <cfloat>
 #include <cstdlib>
 
@@ -381,53 +382,6 @@ __global__ void prop_scatter_kernel(const u64* __restrict__ cand, const int* __r
 __host__ __device__ inline size_t nms_lds_bytes(int post_n, int nblk) {
   const size_t p4 = (size_t)(post_n + 3) / 4 * 4;
   return p4 * 20 + (size_t)64 * nblk * 20 + (size_t)nblk * (nblk + 1) / 2 * 64 * 8 + 64 + 2 * NMS_WAVES * 8 + 16;
-}
-
-// bit i of the result: IoU(ref[i], me) > thr.  Boxes are normalised (y0 <= y1, x0 <= x1) with their areas beside them; an
-// area <= 0 is stored as +inf, which makes every IoU with that box compare false below exactly as the reference's
-// "either area <= 0 -> 0" does, at no cost per pair.
-// Two product tests decide every pair outside a 1e-5 relative band around the threshold (~16 VALU operations per pair, no
-// division); a lane that met a pair inside the band (or a NaN from thr = 0) redoes its 64 pairs with the reference's own
-// expression: separately rounded product, difference and quotient.
-__device__ __noinline__ u64 nms_pair_bits_exact(const float4* ref, const float* ref_area, int cnt, const float4 me,
-                                                const float ma, const float thr) {
-  u64 bits = 0ull;
-  for (int i = 0; i < cnt; ++i) {
-    const float4 r = ref[i];
-    const float ih = fmaxf(fminf(r.z, me.z) - fmaxf(r.x, me.x), 0.f);
-    const float iw = fmaxf(fminf(r.w, me.w) - fmaxf(r.y, me.y), 0.f);
-    const float inter = __fmul_rn(ih, iw);
-    if (__fdiv_rn(inter, __fsub_rn(__fadd_rn(ref_area[i], ma), inter)) > thr) bits |= 1ull << i;
-  }
-  return bits;
-}
-// v_min_f32 / v_max_f32 as they are: fminf / fmaxf put a canonicalising v_max_f32 x, x, x in front of every operand (IEEE
-// minNum of a signalling NaN) -- eight more VALU operations per pair for inputs that are finite by construction
-__device__ __forceinline__ float vmin(float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ float vmax(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ u64 nms_pair_bits(const float4* __restrict__ ref, const float* __restrict__ ref_area, int cnt,
-                                             const float4 me, const float ma, const float thr, const float thr_hi,
-                                             const float thr_lo) {
-  unsigned lo = 0u, hi = 0u;
-  bool band = false;
-  auto one = [&](int i) -> bool {
-    const float4 r = ref[i];
-    const float ih = vmax(vmin(r.z, me.z) - vmax(r.x, me.x), 0.f);
-    const float iw = vmin(r.w, me.w) - vmax(r.y, me.y);
-    const float inter = ih * iw;                      // <= 0 unless the boxes overlap
-    const float uni = (ref_area[i] + ma) - inter;
-    const bool h = fmaf(-thr_hi, uni, inter) > 0.f;
-    band |= !h && !(fmaf(-thr_lo, uni, inter) < 0.f);
-    return h;
-  };
-  const int c0 = min(cnt, 32);
-#pragma unroll 4
-  for (int i = 0; i < c0; ++i) lo |= one(i) ? (1u << i) : 0u;
-#pragma unroll 4
-  for (int i = 32; i < cnt; ++i) hi |= one(i) ? (1u << (i - 32)) : 0u;
-  u64 bits = ((u64)hi << 32) | lo;
-  if (band) bits = nms_pair_bits_exact(ref, ref_area, cnt, me, ma, thr);
-  return bits;
 }
 
 // Barrier of the G workgroups of one cluster.  Everything the cluster exchanges is written with agent-scope (write-through,
