@@ -7,8 +7,8 @@
 //                         (:278-317) -> bboxes_resize (:423-447) -> bboxes_sort (:333-361)
 //                         -> bboxes_nms_batch (:449-506)
 //
-// One workgroup per (image, class): softmax column, mask, clip, filter, rank-sort (top 2*topk),
-// bitmask NMS and the ordered scan all stay in LDS; output is the reference's zero-padded
+// One workgroup per (image, class): class score, mask, clip, filter, order of the valid keys (top 2*topk), the
+// per-class NMS (column bits + fixed-point resolve, nms_pairs.h) all stay in LDS; output is the reference's zero-padded
 // per-class (scores[topk], boxes[topk,4]).
 #include "common.h"
 #include "nms_pairs.h"
@@ -177,9 +177,9 @@ __global__ __launch_bounds__(EV_T) void bboxes_eval_kernel(const float* __restri
   __shared__ float4 sbox[EV_MAXS];
   __shared__ float sscore[EV_MAXS];
   __shared__ u64 mask[EV_MAXS * EV_W];
-  __shared__ u64 s_removed[2 * EV_W];
-  // (aliases, so that two workgroups still share a CU: the sorted boxes with min/max-normalised corners -- what iou_gt_fast_d
-  //  makes of its arguments -- and their areas live in `bx`, dead once the sorted copies exist; the rank counters in `mask`,
+  __shared__ u64 s_keepw[2 * EV_W];
+  // (aliases, so that two workgroups still share a CU: the sorted boxes with min/max-normalised corners -- what
+  //  nms_pair_bits takes -- and their areas live in `bx`, dead once the sorted copies exist; the rank counters in `mask`,
   //  which is not written before they are dead)
   float4* const snorm = bx;
   float* const sarea = reinterpret_cast<float*>(bx + EV_MAXS);
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(EV_T) void bboxes_eval_kernel(const float* __restri
   const int w64 = (n_sorted + 63) / 64;
   const float thr_hi = nms_thr * 1.00001f, thr_lo = nms_thr * 0.99999f;
   u64* const colL = mask;                                   // [w64 (w64 + 1) / 2][64]
-  u64* const Kb = s_removed;                                // keep words of the current / next round: [2][EV_W]
+  u64* const Kb = s_keepw;                                // keep words of the current / next round: [2][EV_W]
   {
     const int wv = tid >> 6, ln = tid & 63;
     const int n_unit = w64 * (w64 + 1) / 2;
